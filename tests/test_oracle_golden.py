@@ -1,0 +1,103 @@
+"""Pin the CPU oracle (oracle/gpode_oracle.py) to fixtures captured from the
+reference's own modules (tests/golden/make_golden.py).  fp32, CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from oracle import gpode_oracle as O
+
+GP_CASES = [('gp_rbf1_tiny', 'RBF', 1), ('gp_rbf2_tiny', 'RBF', 2), ('gp_df1_tiny', 'DF', 1),
+            ('gp_df1_tiny_q4', 'DF', 1), ('gp_rbf1_cfg1', 'RBF', 1), ('gp_df1_cfg2', 'DF', 1),
+            ('gp_rbf2_cfg3', 'RBF', 2)]
+
+
+def _close(a, b, rtol, atol, what):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    scale = b.abs().max().item()
+    assert err <= atol + rtol * scale, '%s: max|diff|=%.3e scale=%.3e' % (what, err, scale)
+
+
+@pytest.mark.parametrize('name,kernel,order', GP_CASES)
+def test_cache_and_rhs_match_reference(name, kernel, order):
+    g = load_golden(name)
+    p = O.gp_params_from_state_dict(sub(g, 'sd.'))
+    c = O.build_cache(p, sub(g, 'noise.'), kernel)
+    # same torch ops in the same order: equal up to BLAS threading / reduction order
+    for k in ('ell', 'var', 'omega', 'phase'):
+        assert torch.equal(c[k], g[k]), k
+    for k in ('Ku', 'u_prior'):
+        _close(c[k], g[k], 2e-6, 0, k)
+    assert torch.equal(O.tril_unpack(p['Us'], p['Um'].shape[0]), g['Us_dense'])
+    # cholesky / solves go through LAPACK in both: allow last-bit differences
+    # (bit-exact at equal thread count; K_uu has cond ~2e4 so blocking changes move nu by ~1e-4)
+    _close(c['Lu'], g['Lu'], 5e-5, 0, 'Lu')
+    _close(c['nu'], g['nu'], 5e-4, 0, 'nu')
+    x = g['x']
+    _close(O.gp_prior(x, c), g['f_prior_x'], 2e-6, 0, 'f_prior_x')
+    c_ref = dict(c, nu=g['nu'])
+    _close(O.gp_update(x, c_ref), g['f_update_x'], 2e-6, 0, 'f_update_x')
+    _close(O.gp_forward(x, c_ref), g['f_x'], 2e-6, 0, 'f_x')
+    Kzx = (O.rbf_K if kernel == 'RBF' else O.df_K)(c['Z'], x, c['ell'], c['var'])
+    _close(Kzx, g['Kzx'], 2e-6, 0, 'Kzx')
+    _close(O.svgp_kl(p['Um'], p['Us']), g['kl_u'], 1e-6, 0, 'kl_u')
+
+
+@pytest.mark.parametrize('name,kernel,order', GP_CASES)
+@pytest.mark.parametrize('method', ['euler', 'rk4'])
+def test_flow_matches_reference(name, kernel, order, method):
+    g = load_golden(name)
+    p = O.gp_params_from_state_dict(sub(g, 'sd.'))
+    c = O.build_cache(p, sub(g, 'noise.'), kernel)
+    zt = O.flow_forward(g['z0'], g['ts'], c, order, method)
+    _close(zt, g['zt_' + method], 5e-4 if 'cfg' in name else 2e-5, 0, 'zt')
+
+
+@pytest.mark.parametrize('name,kernel,order', GP_CASES[:4])
+@pytest.mark.parametrize('method', ['euler', 'rk4'])
+def test_flow_gradients_match_reference(name, kernel, order, method):
+    g = load_golden(name)
+    p = {k: v.clone().requires_grad_(True) for k, v in O.gp_params_from_state_dict(sub(g, 'sd.')).items()}
+    z0 = g['z0'].clone().requires_grad_(True)
+    c = O.build_cache(p, sub(g, 'noise.'), kernel)
+    zt = O.flow_forward(z0, g['ts'], c, order, method)
+    (zt * g['gw']).sum().backward()
+    gr = sub(g, 'grad_%s.' % method)
+    _close(z0.grad, gr['z0'], 1e-4, 1e-6, 'd z0')
+    for short, key in O.GP_KEYS.items():
+        ref = gr[key[len('flow.'):]]
+        _close(p[short].grad, ref, 2e-4, 1e-6, 'd ' + short)
+
+
+MODEL_CASES = [('model_rbf1_tiny', 'RBF', 1, 2, 'rk4'), ('model_rbf2_tiny', 'RBF', 2, 1, 'euler'),
+               ('model_df1_tiny', 'DF', 1, 1, 'rk4')]
+
+
+@pytest.mark.parametrize('name,kernel,order,L,method', MODEL_CASES)
+def test_full_model_loss_and_grads(name, kernel, order, L, method):
+    g = load_golden(name)
+    f = load_golden(name + '_fwd')
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v)
+          for k, v in sub(g, 'sd.').items()}
+    noises = [sub(g, 'noise%d.' % l) for l in range(L)]
+    r = O.compute_loss(g['X'], sd, noises, g['eps_s'], g.get('eps_v'), kernel=kernel, order=order,
+                       method=method, dt=0.1, Ndata=360)
+    _close(r['s_mu'], f['s_mu'], 1e-6, 1e-7, 's_mu')
+    _close(r['s_logv'], f['s_logv'], 1e-6, 1e-7, 's_logv')
+    _close(r['ztL'], f['ztL'], 5e-5, 0, 'ztL')
+    _close(r['Xrec'], f['Xrec'], 1e-4, 1e-6, 'Xrec')
+    for k in ('loss', 'nlhood', 'kl_reg', 'kl_u'):
+        _close(r[k], g[k], 1e-5, 0, k)
+    r['loss'].backward()
+    gr = sub(g, 'grad.')
+    # conv biases that feed a train-mode BatchNorm have an exactly-zero true gradient: both sides hold
+    # only round-off there, so they are compared against the scale of the matching weight gradient.
+    dead_bias = {'cnn.0.bias', 'cnn.3.bias', 'decnn.1.bias', 'decnn.4.bias', 'decnn.7.bias'}
+    for k, ref in gr.items():
+        if any(k.endswith(d) for d in dead_bias):
+            wscale = gr[k[:-4] + 'weight'].abs().max().item()
+            assert sd[k].grad.abs().max().item() <= 1e-3 * wscale + 1e-6, k
+            continue
+        _close(sd[k].grad, ref, 2e-3, 1e-6, 'd ' + k)
