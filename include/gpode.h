@@ -1,0 +1,72 @@
+/* gpode.h -- C ABI of the MI355X-native GP-ODE hot path (libgpode_hip.so).
+ *
+ * Drop-in boundary for the reference's Python operator API
+ * (/root/reference/experiments/model/core/{svpy,kernels,flow}.py).  The reference has no FFI
+ * layer of its own; each entry point below names the reference method it replaces, and
+ * INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to contiguous row-major fp32 unless stated otherwise;
+ *  - the library never allocates, frees or retains caller memory; scratch is passed in (`ws`);
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *  - return value 0 = ok, non-zero = error (message via gpode_last_error()); the Python host
+ *    raises RuntimeError on non-zero;
+ *  - all randomness enters as explicit tensors: eps_u (M,Do), rff_w (S,Do) [DF (2S,Do)],
+ *    rff_eps (Di,S,Do), rff_u (1,S,Do) in [0,1).
+ *
+ *  kernel: 0 = RBF dimwise  (kernels.py:29-195),  1 = divergence-free (kernels.py:201-393, Di==Do)
+ *  order : 1 | 2            (flow.py:27-45)
+ *  method: 0 = euler, 1 = rk4 (torchdiffeq fixed-grid 3/8 rule; flow.py:76-85)
+ */
+#ifndef GPODE_H
+#define GPODE_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPODE_KERNEL_RBF 0
+#define GPODE_KERNEL_DF 1
+#define GPODE_METHOD_EULER 0
+#define GPODE_METHOD_RK4 1
+
+/* Library / build identification. */
+const char* gpode_version(void);
+const char* gpode_last_error(void);
+/* 1 if (kernel,Di,Do) has a compiled specialisation. */
+int gpode_supported(int kernel, int Di, int Do);
+
+/* Sizes (in floats) of the packed per-draw cache consumed by rhs/rollout, and of the scratch
+ * workspace gpode_cache_build_fwd needs. */
+int gpode_cache_sizes(int kernel, int Di, int Do, int M, int S, size_t* pack_floats, size_t* ws_floats);
+
+/* SVGP_Layer.build_cache (svpy.py:103-121): kern.build_cache (kernels.py:126-137 / :305-316),
+ * sample_inducing (svpy.py:88-101), kern.K(Z) (kernels.py:98-110 / :289-303), kern.rff_forward(Z),
+ * kern.compute_nu (kernels.py:155-172 / :376-387).
+ * Inputs are the raw optvars of the state_dict and the noise.  `pack` receives the lane-major cache
+ * used by the kernels below.  The remaining outputs mirror the attributes the reference caches on
+ * `kern` and may be NULL: ell (Do,Di), var (Do), omega (Di,S,Do), phase (1,S,Do), u (M,Do),
+ * Lu (RBF: (Do,M,M); DF: (M*D,M*D)), nu (RBF: (Do,M); DF: (M*D)), u_prior (M,Do). */
+int gpode_cache_build_fwd(int kernel, int Di, int Do, int M, int S,
+                          const float* raw_ell, const float* raw_var, const float* Z,
+                          const float* Um, const float* Us_packed,
+                          const float* eps_u, const float* rff_w, const float* rff_eps, const float* rff_u,
+                          float* pack, float* ws,
+                          float* ell, float* var, float* omega, float* phase, float* u,
+                          float* Lu, float* nu, float* u_prior, void* stream);
+
+/* SVGP_Layer.forward (svpy.py:123-142): f(x) = rff_forward(x) + f_update(x, Z).
+ * x (N,Di) -> f (N,Do).  mode: 0 = prior + update, 1 = prior only, 2 = update only. */
+int gpode_rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack,
+                  const float* x, int N, float* f, int mode, void* stream);
+
+/* Flow.forward (flow.py:68-86) given a built cache: z0 (N,D), ts (T) -> zt (N,T,D),
+ * D = Di = order*Do.  One fixed-grid step per output interval. */
+int gpode_rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, int S,
+                      const float* pack, const float* z0, const float* ts, int N, int T,
+                      float* zt, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

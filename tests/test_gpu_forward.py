@@ -1,0 +1,96 @@
+"""GPU parity (forward): HIP cache build / f(x) / rollout, called through the C ABI, against
+ (a) golden vectors captured from the reference's own modules and (b) the CPU oracle in fp64.
+
+Tolerances (fp32, stated per quantity, relative to max|reference| of the tensor):
+  elementwise prep (ell, var, omega, phase, u)        1e-6
+  f_prior(Z), f(x) with the reference's nu            2e-5   (256-term cos sums; hw cos in revolutions)
+  Lu                                                  1e-4   (cond(K_uu) ~ 2e4 amplifies fp32 round-off)
+  nu, and f(x)/trajectories that depend on nu         1e-3 of max for cfg shapes, 2e-4 tiny
+The reference itself (fp32 CPU) sits 1e-4..5e-4 away from its own fp64 twin on these quantities
+(tests/test_oracle_golden.py), which is what bounds an honest fp32 tolerance here.
+"""
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from oracle import gpode_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GP_CASES = [('gp_rbf1_tiny', 'RBF', 1), ('gp_rbf2_tiny', 'RBF', 2), ('gp_df1_tiny', 'DF', 1),
+            ('gp_df1_tiny_q4', 'DF', 1), ('gp_rbf1_cfg1', 'RBF', 1), ('gp_df1_cfg2', 'DF', 1),
+            ('gp_rbf2_cfg3', 'RBF', 2)]
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def build(g, kernel, want_Lu=True):
+    from vae_gp_ode_amd import ops
+    dev = torch.device('cuda:0')
+    p = {k: v.to(dev) for k, v in O.gp_params_from_state_dict(sub(g, 'sd.')).items()}
+    nz = {k: v.to(dev) for k, v in sub(g, 'noise.').items()}
+    c = ops.cache_build(kernel, p['raw_ell'], p['raw_var'], p['Z'], p['Um'], p['Us'],
+                        nz['eps_u'], nz['rff_w'], nz['rff_eps'], nz['rff_u'], want_Lu=want_Lu)
+    c.check_factorisation()
+    return c
+
+
+@pytest.mark.parametrize('name,kernel,order', GP_CASES)
+def test_cache_build_matches_reference(name, kernel, order):
+    g = load_golden(name)
+    c = build(g, kernel)
+    big = 'cfg' in name
+    assert relerr(c.ell, g['ell']) < 1e-6
+    assert relerr(c.var, g['var']) < 1e-6
+    assert relerr(c.omega, g['omega']) < 1e-6
+    assert relerr(c.phase, g['phase']) < 1e-6
+    p = O.gp_params_from_state_dict(sub(g, 'sd.'))
+    u_ref = O.sample_inducing(p['Us'], g['noise.eps_u'], p['Um'])
+    assert relerr(c.u, u_ref) < 1e-6
+    assert relerr(c.u_prior, g['u_prior']) < 2e-5
+    assert relerr(c.Lu, g['Lu']) < 1e-4
+    assert relerr(c.nu.reshape(g['nu'].shape), g['nu']) < (1e-3 if big else 2e-4)
+
+
+@pytest.mark.parametrize('name,kernel,order', GP_CASES)
+def test_rhs_matches_reference(name, kernel, order):
+    from vae_gp_ode_amd import ops
+    g = load_golden(name)
+    c = build(g, kernel, want_Lu=False)
+    x = g['x'].cuda()
+    big = 'cfg' in name
+    assert relerr(ops.rhs(c, x, mode=1), g['f_prior_x']) < 2e-5
+    assert relerr(ops.rhs(c, x, mode=2), g['f_update_x']) < (1e-3 if big else 2e-4)
+    assert relerr(ops.rhs(c, x, mode=0), g['f_x']) < (1e-3 if big else 2e-4)
+
+
+@pytest.mark.parametrize('name,kernel,order', GP_CASES)
+@pytest.mark.parametrize('method', ['euler', 'rk4'])
+def test_rollout_matches_reference(name, kernel, order, method):
+    from vae_gp_ode_amd import ops
+    g = load_golden(name)
+    c = build(g, kernel, want_Lu=False)
+    zt = ops.rollout(c, g['z0'].cuda(), g['ts'].cuda(), order, method)
+    assert relerr(zt, g['zt_' + method]) < (1e-3 if 'cfg' in name else 2e-4)
+
+
+@pytest.mark.parametrize('name,kernel,order', GP_CASES)
+def test_closer_to_fp64_truth_than_tolerance(name, kernel, order):
+    """HIP fp32 vs the oracle's fp64 twin on the same inputs: the HIP path must be no further from
+    the fp64 truth than 2x the reference's own fp32 error (+1e-5)."""
+    from vae_gp_ode_amd import ops
+    g = load_golden(name)
+    p64 = O.to_dtype(O.gp_params_from_state_dict(sub(g, 'sd.')), torch.float64)
+    n64 = O.to_dtype(sub(g, 'noise.'), torch.float64)
+    c64 = O.build_cache(p64, n64, kernel)
+    zt64 = O.flow_forward(g['z0'].double(), g['ts'].double(), c64, order, 'rk4')
+    c = build(g, kernel, want_Lu=False)
+    zt = ops.rollout(c, g['z0'].cuda(), g['ts'].cuda(), order, 'rk4')
+    e_hip = relerr(zt, zt64)
+    e_ref = relerr(g['zt_rk4'], zt64)
+    print('%s: |hip-fp64|=%.2e |ref-fp64|=%.2e' % (name, e_hip, e_ref))
+    assert e_hip < 2 * e_ref + 1e-5

@@ -1,0 +1,59 @@
+"""ctypes binding of libgpode_hip.so (C ABI: include/gpode.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, this module
+raises.  Build it with ``python -c 'import __graft_entry__ as g; g.build()'`` or
+``make -C vae-gp-ode_amd/csrc``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgpode_hip.so')
+
+_c_float_p = ctypes.c_void_p  # device pointers travel as integers
+_i = ctypes.c_int
+_sz_p = ctypes.POINTER(ctypes.c_size_t)
+
+# name -> (restype, argtypes); mirrors include/gpode.h one to one
+SIGNATURES = {
+    'gpode_version': (ctypes.c_char_p, []),
+    'gpode_last_error': (ctypes.c_char_p, []),
+    'gpode_supported': (_i, [_i, _i, _i]),
+    'gpode_cache_sizes': (_i, [_i, _i, _i, _i, _i, _sz_p, _sz_p]),
+    'gpode_cache_build_fwd': (_i, [_i] * 5 + [_c_float_p] * 20),
+    'gpode_cache_info': (_i, [_c_float_p, ctypes.POINTER(_i), ctypes.c_void_p]),
+    'gpode_rhs_fwd': (_i, [_i] * 5 + [_c_float_p, _c_float_p, _i, _c_float_p, _i, ctypes.c_void_p]),
+    'gpode_rollout_fwd': (_i, [_i] * 7 + [_c_float_p, _c_float_p, _c_float_p, _i, _i, _c_float_p, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+class GpodeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library; raise if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GpodeError('libgpode_hip.so not found at %s -- build the HIP extension first '
+                         '(__graft_entry__.build()); there is no CPU fallback' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise GpodeError with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise GpodeError('%s failed (%d): %s' % (name, rc, lib.gpode_last_error().decode()))
+    return rc

@@ -1,0 +1,61 @@
+// capi.hip -- extern "C" surface of libgpode_hip.so (declared in include/gpode.h).
+#include "../../include/gpode.h"
+#include "gp_launch.hpp"
+
+namespace gp {
+char* error_slot() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+}  // namespace gp
+
+extern "C" {
+
+const char* gpode_version(void) { return "gpode-hip 0.1 (gfx950)"; }
+const char* gpode_last_error(void) { return gp::error_slot(); }
+int gpode_supported(int kernel, int Di, int Do) { return gp::dims_supported(kernel, Di, Do); }
+
+int gpode_cache_sizes(int kernel, int Di, int Do, int M, int S, size_t* pack_floats, size_t* ws_floats) {
+  return gp::cache_sizes(kernel, Di, Do, M, S, pack_floats, ws_floats);
+}
+
+int gpode_cache_build_fwd(int kernel, int Di, int Do, int M, int S,
+                          const float* raw_ell, const float* raw_var, const float* Z,
+                          const float* Um, const float* Us_packed,
+                          const float* eps_u, const float* rff_w, const float* rff_eps, const float* rff_u,
+                          float* pack, float* ws,
+                          float* ell, float* var, float* omega, float* phase, float* u,
+                          float* Lu, float* nu, float* u_prior, void* stream) {
+  if (!raw_ell || !raw_var || !Z || !Um || !Us_packed || !eps_u || !rff_w || !rff_eps || !rff_u || !pack || !ws)
+    return gp::set_error("gpode_cache_build_fwd: null required pointer");
+  return gp::cache_build_fwd(kernel, Di, Do, M, S, raw_ell, raw_var, Z, Um, Us_packed, eps_u, rff_w, rff_eps, rff_u,
+                             pack, ws, ell, var, omega, phase, u, Lu, nu, u_prior, (hipStream_t)stream);
+}
+
+int gpode_cache_info(const float* ws, int* host_info, void* stream) {
+  // copies the factorisation status word (bit 0: K_uu + jitter I not positive definite) to the host;
+  // synchronises `stream`.
+  hipError_t e = hipMemcpyAsync(host_info, ws, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) return gp::set_error("gpode_cache_info: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int gpode_rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack,
+                  const float* x, int N, float* f, int mode, void* stream) {
+  if (!pack || !x || !f) return gp::set_error("gpode_rhs_fwd: null pointer");
+  if (N < 0 || mode < 0 || mode > 2) return gp::set_error("gpode_rhs_fwd: N=%d mode=%d", N, mode);
+  if (N == 0) return 0;
+  return gp::rhs_fwd(kernel, Di, Do, M, S, pack, x, N, f, mode, (hipStream_t)stream);
+}
+
+int gpode_rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, int S,
+                      const float* pack, const float* z0, const float* ts, int N, int T,
+                      float* zt, void* stream) {
+  if (!pack || !z0 || !ts || !zt) return gp::set_error("gpode_rollout_fwd: null pointer");
+  if (N < 0 || T < 1) return gp::set_error("gpode_rollout_fwd: N=%d T=%d", N, T);
+  if (N == 0) return 0;
+  return gp::rollout_fwd(kernel, order, method, Di, Do, M, S, pack, z0, ts, N, T, zt, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+// gp_eval.hpp -- device evaluators of the sparse-GP vector field f(x) for CDNA4 (gfx950).
+//
+// Mapping ("wave per trajectory"): one 64-lane wavefront owns one latent state x (replicated in
+// every lane).  The RFF feature index s and the inducing index m are spread over the 64 lanes;
+// each lane accumulates its partial f[0..Do) in registers and one butterfly all-reduce per
+// evaluation leaves f in every lane, so the Runge-Kutta stage algebra needs no LDS and no barrier.
+//
+// Packed per-draw cache ("pack", written by gp_cache.hip): lane-major *records* of float4,
+//     float4 index = (rec * RQ + q) * 64 + lane
+// so a wave reads 1 KiB per instruction (global_load_dwordx4 / ds_read_b128, conflict-free).
+//
+//  RBF (kernels.py:140-153,174-181), SJ = ceil(S/64), MJ = ceil(M/64):
+//    rff record (j,d), s = 64 j + lane : [ om[0..Di) = eps[i,s,d]/(ell[d,i] 2 pi), ph = u[s,d],
+//                                          aw = sqrt(var_d/S) w[s,d] ]           RQ  = ceil((Di+2)/4)
+//    ind record j,     m = 64 j + lane : [ zz[0..Di) = Z[m,i], cc[0..Do) = var_d nu[d,m] ]
+//                                                                                RQ2 = ceil((Di+Do)/4)
+//    uniform tail: wl[d][i] = -0.5 log2(e) / ell[d,i]^2
+//  DF (kernels.py:289-303,319-351,390-393), D = Di = Do:
+//    rff record (j,i), s = 64 j + lane : [ om[0..D) = omega[k,s,i]/(2 pi), ph = u[s,i], wc = w[s,i],
+//                                          ws = w[S+s,i], bs[0..D) = B[s,i,jj] sqrt(var_jj/S) ]
+//                                                                                RQ  = ceil((2D+3)/4)
+//    ind record j,     m = 64 j + lane : [ zz[0..D) = Z[m,a], nn[0..D) = nu[(m,a)] ]   RQ2 = ceil(2D/4)
+//    uniform tail: wab[a][b] = -log2(e)/(2 ell[a,b]^2), il2[a][b] = 1/ell[a,b]^2, var[b]
+//  Lanes with s >= S or m >= M hold zeros in aw / wc,ws / cc / nn, which masks them for free.
+//
+// Numerics: cos/sin are evaluated in revolutions (v_fract + v_cos/v_sin: the phase 2*pi*u and the
+// 1/(2 pi) of omega are folded into the pack), exp as v_exp_f32 (2^x) with log2(e) folded into the
+// lengthscale weights, and the squared distance in difference form (the reference uses the
+// expanded form, kernels.py:64-79, which loses ~1e-6 to cancellation).  fp32 throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define GP_WAVE 64
+#define GP_LOG2E 1.4426950408889634f
+#define GP_INV2PI 0.15915494309189535f
+
+namespace gp {
+
+__host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+template <int DI, int DO> struct RbfLayout {
+  static constexpr int RQ = cdiv(DI + 2, 4);
+  static constexpr int RQ2 = cdiv(DI + DO, 4);
+  __host__ __device__ static size_t rff_f4(int S) { return (size_t)cdiv(S, 64) * DO * RQ * 64; }
+  __host__ __device__ static size_t ind_f4(int M) { return (size_t)cdiv(M, 64) * RQ2 * 64; }
+  __host__ __device__ static size_t uni_floats() { return (size_t)cdiv(DO * DI, 4) * 4; }
+  __host__ __device__ static size_t total_floats(int M, int S) { return 4 * (rff_f4(S) + ind_f4(M)) + uni_floats(); }
+};
+
+template <int D> struct DfLayout {
+  static constexpr int RQ = cdiv(2 * D + 3, 4);
+  static constexpr int RQ2 = cdiv(2 * D, 4);
+  __host__ __device__ static size_t rff_f4(int S) { return (size_t)cdiv(S, 64) * D * RQ * 64; }
+  __host__ __device__ static size_t ind_f4(int M) { return (size_t)cdiv(M, 64) * RQ2 * 64; }
+  __host__ __device__ static size_t uni_floats() { return (size_t)cdiv(2 * D * D + D, 4) * 4; }
+  __host__ __device__ static size_t total_floats(int M, int S) { return 4 * (rff_f4(S) + ind_f4(M)) + uni_floats(); }
+};
+
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// cos / sin of 2*pi*t, t in revolutions (any magnitude the fp32 fract can resolve)
+__device__ __forceinline__ float cos_rev(float t) { return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(t)); }
+__device__ __forceinline__ float sin_rev(float t) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t)); }
+__device__ __forceinline__ float exp2_fast(float t) { return __builtin_amdgcn_exp2f(t); }
+
+template <int NQ> __device__ __forceinline__ void unpack(const float4 (&r)[NQ], float (&f)[4 * NQ]) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    f[4 * q + 0] = r[q].x; f[4 * q + 1] = r[q].y; f[4 * q + 2] = r[q].z; f[4 * q + 3] = r[q].w;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// RBF: one rff record contributes to output d; one ind record contributes to every d.
+// ----------------------------------------------------------------------------------------------
+template <int DI, int DO>
+__device__ __forceinline__ void rbf_rff_record(const float4 (&r)[RbfLayout<DI, DO>::RQ], const float (&x)[DI], float& acc) {
+  float f[4 * RbfLayout<DI, DO>::RQ];
+  unpack(r, f);
+  float t = f[DI];
+#pragma unroll
+  for (int i = 0; i < DI; ++i) t = fmaf(x[i], f[i], t);
+  acc = fmaf(f[DI + 1], cos_rev(t), acc);
+}
+
+template <int DI, int DO>
+__device__ __forceinline__ void rbf_ind_record(const float4 (&r)[RbfLayout<DI, DO>::RQ2], const float (&x)[DI],
+                                               const float* __restrict__ wl, float (&acc)[DO]) {
+  float f[4 * RbfLayout<DI, DO>::RQ2];
+  unpack(r, f);
+  float t2[DI];
+#pragma unroll
+  for (int i = 0; i < DI; ++i) { float d = x[i] - f[i]; t2[i] = d * d; }
+#pragma unroll
+  for (int d = 0; d < DO; ++d) {
+    float e = 0.f;
+#pragma unroll
+    for (int i = 0; i < DI; ++i) e = fmaf(wl[d * DI + i], t2[i], e);
+    acc[d] = fmaf(f[DI + d], exp2_fast(e), acc[d]);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// DF
+// ----------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void df_rff_record(const float4 (&r)[DfLayout<D>::RQ], const float (&x)[D], float (&acc)[D]) {
+  float f[4 * DfLayout<D>::RQ];
+  unpack(r, f);
+  float t = f[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) t = fmaf(x[k], f[k], t);
+  t = __builtin_amdgcn_fractf(t);
+  float c = __builtin_amdgcn_cosf(t), s = __builtin_amdgcn_sinf(t);
+  float rr = fmaf(f[D + 2], s, f[D + 1] * c);
+#pragma unroll
+  for (int j = 0; j < D; ++j) acc[j] = fmaf(rr, f[D + 3 + j], acc[j]);
+}
+
+template <int D>
+__device__ __forceinline__ void df_ind_record(const float4 (&r)[DfLayout<D>::RQ2], const float (&x)[D],
+                                              const float* __restrict__ uni, float (&acc)[D]) {
+  float f[4 * DfLayout<D>::RQ2];
+  unpack(r, f);
+  const float* wab = uni;
+  const float* il2 = uni + D * D;
+  const float* var = uni + 2 * D * D;
+  float dl[D];
+  float r2 = 0.f;
+#pragma unroll
+  for (int a = 0; a < D; ++a) { dl[a] = x[a] - f[a]; r2 = fmaf(dl[a], dl[a], r2); }
+#pragma unroll
+  for (int b = 0; b < D; ++b) {
+    float sb = 0.f;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      float il = il2[a * D + b];
+      float E = exp2_fast(r2 * wab[a * D + b]);
+      float term = dl[a] * dl[b] * il;
+      if (a == b) term += (float)(D - 1) - r2 * il;
+      sb = fmaf(f[D + a] * (E * il), term, sb);
+    }
+    acc[b] = fmaf(var[b], sb, acc[b]);
+  }
+}
+
+}  // namespace gp

@@ -1,0 +1,44 @@
+// gp_launch.hpp -- host-side helpers shared by the launchers (error slot, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+
+namespace gp {
+
+char* error_slot();  // thread-local 512-byte buffer (capi.hip)
+
+inline int set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_slot(), 512, fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+inline int set_max_lds(const void* kern, size_t bytes) {
+  if (bytes <= 64 * 1024) return 0;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return set_error("hipFuncSetAttribute(max dynamic LDS=%zu): %s", bytes, hipGetErrorString(e));
+  return 0;
+}
+
+// entry points implemented across the .hip files
+int dims_supported(int kernel, int Di, int Do);
+int rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, int N, float* f, int mode, hipStream_t st);
+int rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, int S, const float* pack,
+                const float* z0, const float* ts, int N, int T, float* zt, hipStream_t st);
+int cache_sizes(int kernel, int Di, int Do, int M, int S, size_t* pack_floats, size_t* ws_floats);
+int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
+                    const float* raw_ell, const float* raw_var, const float* Z, const float* Um, const float* Us_packed,
+                    const float* eps_u, const float* rff_w, const float* rff_eps, const float* rff_u,
+                    float* pack, float* ws, float* ell, float* var, float* omega, float* phase, float* u,
+                    float* Lu, float* nu, float* u_prior, hipStream_t st);
+
+}  // namespace gp
