@@ -66,6 +66,22 @@ int gpode_rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, 
                       const float* pack, const float* z0, const float* ts, int N, int T,
                       float* zt, void* stream);
 
+/* Factorisation status of the last gpode_cache_build_fwd on `ws` (bit 0: K_uu + jitter I not positive
+ * definite -- torch.linalg.cholesky raises there, kernels.py:163/:384).  Copies one int to the host and
+ * synchronises `stream`. */
+int gpode_cache_info(const float* ws, int* host_info, void* stream);
+
+/* kern.K(X, X2) (kernels.py:98-110 / :289-303), no jitter.  X (N,Di), X2 (M2,Di).
+ * RBF: out (Do,N,M2).  DF: out (N*D, M2*D), row (n,a), col (m,b). */
+int gpode_kernel_matrix(int kernel, int Di, int Do, const float* raw_ell, const float* raw_var,
+                        const float* X, int N, const float* X2, int M2, float* out, void* stream);
+
+/* SVGP_Layer.kl (svpy.py:144-175, q_diag=False): Um (M,Do), Us_packed (Do, M(M+1)/2) -> kl (1 float).
+ * _bwd: g = d loss / d kl (1 float, device) -> dUm (M,Do), dUs (Do, M(M+1)/2). */
+int gpode_svgp_kl_fwd(int M, int Do, const float* Um, const float* Us_packed, float* kl, void* stream);
+int gpode_svgp_kl_bwd(int M, int Do, const float* Um, const float* Us_packed, const float* g,
+                      float* dUm, float* dUs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,9 @@ SIGNATURES = {
     'gpode_cache_sizes': (_i, [_i, _i, _i, _i, _i, _sz_p, _sz_p]),
     'gpode_cache_build_fwd': (_i, [_i] * 5 + [_c_float_p] * 20),
     'gpode_cache_info': (_i, [_c_float_p, ctypes.POINTER(_i), ctypes.c_void_p]),
+    'gpode_kernel_matrix': (_i, [_i, _i, _i, _c_float_p, _c_float_p, _c_float_p, _i, _c_float_p, _i, _c_float_p, ctypes.c_void_p]),
+    'gpode_svgp_kl_fwd': (_i, [_i, _i, _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p]),
+    'gpode_svgp_kl_bwd': (_i, [_i, _i] + [_c_float_p] * 5 + [ctypes.c_void_p]),
     'gpode_rhs_fwd': (_i, [_i] * 5 + [_c_float_p, _c_float_p, _i, _c_float_p, _i, ctypes.c_void_p]),
     'gpode_rollout_fwd': (_i, [_i] * 7 + [_c_float_p, _c_float_p, _c_float_p, _i, _i, _c_float_p, ctypes.c_void_p]),
 }

@@ -58,4 +58,21 @@ int gpode_rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, 
   return gp::rollout_fwd(kernel, order, method, Di, Do, M, S, pack, z0, ts, N, T, zt, (hipStream_t)stream);
 }
 
+int gpode_kernel_matrix(int kernel, int Di, int Do, const float* raw_ell, const float* raw_var,
+                        const float* X, int N, const float* X2, int M2, float* out, void* stream) {
+  if (!raw_ell || !raw_var || !X || !X2 || !out) return gp::set_error("gpode_kernel_matrix: null pointer");
+  return gp::kernel_matrix(kernel, Di, Do, raw_ell, raw_var, X, N, X2, M2, out, (hipStream_t)stream);
+}
+
+int gpode_svgp_kl_fwd(int M, int Do, const float* Um, const float* Us_packed, float* kl, void* stream) {
+  if (!Um || !Us_packed || !kl) return gp::set_error("gpode_svgp_kl_fwd: null pointer");
+  return gp::svgp_kl_fwd(M, Do, Um, Us_packed, kl, (hipStream_t)stream);
+}
+
+int gpode_svgp_kl_bwd(int M, int Do, const float* Um, const float* Us_packed, const float* g,
+                      float* dUm, float* dUs, void* stream) {
+  if (!Um || !Us_packed || !g || !dUm || !dUs) return gp::set_error("gpode_svgp_kl_bwd: null pointer");
+  return gp::svgp_kl_bwd(M, Do, Um, Us_packed, g, dUm, dUs, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -41,4 +41,9 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
                     float* pack, float* ws, float* ell, float* var, float* omega, float* phase, float* u,
                     float* Lu, float* nu, float* u_prior, hipStream_t st);
 
+int kernel_matrix(int kernel, int Di, int Do, const float* raw_ell, const float* raw_var, const float* X, int N,
+                  const float* X2, int M2, float* out, hipStream_t st);
+int svgp_kl_fwd(int M, int Do, const float* Um, const float* Us, float* kl, hipStream_t st);
+int svgp_kl_bwd(int M, int Do, const float* Um, const float* Us, const float* g, float* dUm, float* dUs, hipStream_t st);
+
 }  // namespace gp

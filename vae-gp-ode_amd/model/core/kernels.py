@@ -1,0 +1,82 @@
+"""GP covariance kernels of the latent ODE (operator API of experiments/model/core/kernels.py).
+
+Same class names, constructor signatures, parameter names/shapes (``unconstrained_lengthscales``
+(D_out,D_in), ``unconstrained_variance`` (D_out,)) and cached attributes (``nu``, ``rff_weights``,
+``rff_omega``, ``rff_phase``) as the reference; the arithmetic runs in hand-written HIP kernels
+(csrc/gp_cache.hip, csrc/gp_forward.hip) behind the C ABI of include/gpode.h.  Only the dimwise RBF
+(reference default, main.py:63) and the divergence-free kernel are on the hot path.
+"""
+import torch
+from torch import nn
+
+from .. import misc  # noqa: F401
+from ..misc.constraint_utils import invsoftplus, softplus
+from ... import ops
+
+jitter = 1e-5
+
+
+class RBF(nn.Module):
+    """Squared-exponential kernel with per-output-dimension hyper-parameters (kernels.py:29-195)."""
+    kernel_id = 'RBF'
+
+    def __init__(self, D_in, D_out=None, dimwise=False):
+        super().__init__()
+        self.D_in = D_in
+        self.D_out = D_in if D_out is None else D_out
+        if not dimwise:
+            raise NotImplementedError('dimwise=False RBF is outside the accelerated path (SURVEY 8f rank 3)')
+        self.dimwise = dimwise
+        self.unconstrained_lengthscales = nn.Parameter(torch.ones(self.D_out, self.D_in))
+        self.unconstrained_variance = nn.Parameter(torch.ones(self.D_out))
+        with torch.no_grad():  # class defaults of the reference (kernels.py:52-54)
+            self.unconstrained_lengthscales.fill_(invsoftplus(torch.tensor(0.2)).item())
+            self.unconstrained_variance.fill_(invsoftplus(torch.tensor(0.1)).item())
+        self._cache = None
+
+    @property
+    def lengthscales(self):
+        return softplus(self.unconstrained_lengthscales)
+
+    @property
+    def variance(self):
+        return softplus(self.unconstrained_variance)
+
+    # -- cached per-draw state (set by SVGP_Layer.build_cache) ---------------------------------
+    def _set_cache(self, cache, noise):
+        self._cache = cache
+        self.rff_weights = noise['rff_w']
+        self.rff_omega = cache.omega
+        self.rff_phase = cache.phase
+        self.nu = cache.nu
+
+    def _need_cache(self):
+        if self._cache is None:
+            raise RuntimeError('call SVGP_Layer.build_cache() first (flow.py:22-25 does it before every odeint)')
+        return self._cache
+
+    def rff_forward(self, x, S=None):
+        """Prior sample f_prior(x) from the cached Fourier features (kernels.py:140-153 / :319-351)."""
+        return ops.rhs(self._need_cache(), x, mode=1)
+
+    def f_update(self, x, x2=None):
+        """Pathwise update K(x,Z) nu with the cached nu (kernels.py:174-181 / :390-393)."""
+        return ops.rhs(self._need_cache(), x, mode=2)
+
+    def forward(self, X, X2=None):
+        return self.K(X, X2)
+
+    def K(self, X, X2=None):
+        """K(X, X2): (D_out,N,M) for RBF, (N*D, M*D) for DF (kernels.py:98-110 / :289-303)."""
+        return ops.kernel_matrix(self.kernel_id, self.unconstrained_lengthscales.detach(),
+                                 self.unconstrained_variance.detach(), X, X2)
+
+
+class DivergenceFreeKernel(RBF):
+    """Matrix-valued divergence-free kernel built on the dimwise RBF parameters (kernels.py:201-393)."""
+    kernel_id = 'DF'
+
+    def __init__(self, D_in, D_out):
+        if D_in != D_out:
+            raise ValueError('DivergenceFreeKernel needs D_in == D_out (kernels.py:259-262)')
+        super().__init__(D_in=D_in, D_out=D_out, dimwise=True)

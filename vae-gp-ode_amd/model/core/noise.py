@@ -1,0 +1,53 @@
+"""Where the randomness of a GP function draw comes from.
+
+The reference draws inside the modules (kernels.py:13-26,134-137; svpy.py:12-27,94): ``rff_weights``
+and the frequency noise from a FRESH UNSEEDED ``np.random.RandomState()`` (not reproducible from
+--seed), ``rff_phase`` and the inducing ``epsilon`` from the global numpy RNG.  Here every
+draw is an explicit dict of tensors handed to the HIP cache build:
+
+    eps_u (M,Do) ~ N(0,1)      rff_w (S,Do) [DF: (2S,Do)] ~ N(0,1)
+    rff_eps (Di,S,Do) ~ N(0,1) rff_u (1,S,Do) ~ U[0,1)
+
+``NumpyNoise`` reproduces the reference's generators and draw order; ``DeviceNoise`` draws on the GPU
+(no host round trip; use for throughput) and, under data parallelism, is seeded identically on every
+rank so that all shards integrate under the same function draw.
+"""
+import numpy as np
+import torch
+
+
+def draw_shapes(kernel, Di, Do, M, S):
+    return dict(rff_w=(S if kernel == 'RBF' else 2 * S, Do), rff_eps=(Di, S, Do), rff_u=(1, S, Do), eps_u=(M, Do))
+
+
+class NumpyNoise:
+    def __init__(self, unseeded_rff=True):
+        self.unseeded_rff = unseeded_rff
+
+    def draw(self, kernel, Di, Do, M, S, device):
+        sh = draw_shapes(kernel, Di, Do, M, S)
+        fresh = np.random.RandomState() if self.unseeded_rff else np.random
+        out = dict(rff_w=fresh.normal(size=sh['rff_w']))
+        fresh = np.random.RandomState() if self.unseeded_rff else np.random
+        out['rff_eps'] = fresh.normal(size=sh['rff_eps'])
+        out['rff_u'] = np.random.uniform(low=0.0, high=1.0, size=sh['rff_u'])
+        out['eps_u'] = np.random.normal(size=sh['eps_u'])
+        return {k: torch.tensor(v.astype(np.float32)).to(device) for k, v in out.items()}
+
+
+class DeviceNoise:
+    def __init__(self, seed=0, device=None):
+        self.seed = seed
+        self._gen = None
+        self._device = device
+
+    def draw(self, kernel, Di, Do, M, S, device):
+        if self._gen is None or self._gen.device != torch.device(device):
+            self._gen = torch.Generator(device=device)
+            self._gen.manual_seed(self.seed)
+        sh = draw_shapes(kernel, Di, Do, M, S)
+        g = self._gen
+        return dict(rff_w=torch.randn(sh['rff_w'], generator=g, device=device),
+                    rff_eps=torch.randn(sh['rff_eps'], generator=g, device=device),
+                    rff_u=torch.rand(sh['rff_u'], generator=g, device=device),
+                    eps_u=torch.randn(sh['eps_u'], generator=g, device=device))

@@ -1,0 +1,85 @@
+"""Sparse variational GP layer with decoupled (pathwise) sampling -- operator API of
+experiments/model/core/svpy.py, computed by HIP kernels.
+
+state_dict keys are the reference's: ``kern.unconstrained_lengthscales``, ``kern.unconstrained_variance``,
+``inducing_loc.optvar`` (M,D_in), ``Um.optvar`` (M,D_out), ``Us_sqrt.optvar`` (D_out, M(M+1)/2).
+"""
+import numpy as np
+import torch
+
+from ..misc import transforms
+from ..misc.param import Param
+from .kernels import RBF, DivergenceFreeKernel
+from .noise import NumpyNoise
+from ... import ops
+
+jitter = 1e-5
+
+
+class SVGP_Layer(torch.nn.Module):
+    def __init__(self, D_in, D_out, M, S, q_diag=False, dimwise=True, device='cpu', kernel='RBF'):
+        super().__init__()
+        if kernel == 'RBF':
+            self.kern = RBF(D_in, D_out, dimwise)
+            self.dimwise = dimwise
+        elif kernel == 'DF':
+            self.kern = DivergenceFreeKernel(D_in, D_out)
+            self.dimwise = False  # as the reference (svpy.py:62-64)
+        else:
+            raise SystemExit('Invalid kernel selection')
+        if q_diag:
+            raise NotImplementedError('q_diag=True is outside the accelerated path (SURVEY 8f rank 3)')
+        self.kernel_n = kernel
+        self.q_diag = q_diag
+        self.D_out, self.D_in, self.M, self.S = D_out, D_in, M, S
+        self.device = device
+        # initial values exactly as svpy.py:76-86 (global numpy RNG, same draw order)
+        self.inducing_loc = Param(np.random.normal(size=(M, D_in)), name='Inducing locations')
+        self.Um = Param(np.random.normal(size=(M, D_out)) * 1e-1, name='Inducing distribution (mean)')
+        self.Us_sqrt = Param(np.stack([np.eye(M)] * D_out) * 1e-3,
+                             transform=transforms.LowerTriangular(M, D_out, device=self.device),
+                             name='Inducing distribution (scale)')
+        self.noise_source = NumpyNoise()
+        self._next_noise = None
+        self.cache = None
+
+    # -- randomness ---------------------------------------------------------------------------
+    def set_noise(self, noise):
+        """Use this dict (see core/noise.py) for the next build_cache() instead of drawing."""
+        self._next_noise = noise
+
+    def _take_noise(self):
+        dev = self.inducing_loc.optvar.device
+        if self._next_noise is not None:
+            nz, self._next_noise = self._next_noise, None
+            return {k: v.to(dev) for k, v in nz.items()}
+        return self.noise_source.draw(self.kernel_n, self.D_in, self.D_out, self.M, self.S, dev)
+
+    # -- reference API ------------------------------------------------------------------------
+    def sample_inducing(self):
+        """One draw u ~ q(u) = N(m, S) in whitened form (svpy.py:88-101); returns (M,D_out)."""
+        self.build_cache()
+        return self.cache.u
+
+    def build_cache(self, noise=None, want_Lu=False):
+        """Fix one function draw: Fourier features, inducing sample, nu (svpy.py:103-121)."""
+        if noise is not None:
+            self._next_noise = noise
+        nz = self._take_noise()
+        k = self.kern
+        self.cache = ops.cache_build(self.kernel_n, k.unconstrained_lengthscales.detach(), k.unconstrained_variance.detach(),
+                                     self.inducing_loc.optvar.detach(), self.Um.optvar.detach(), self.Us_sqrt.optvar.detach(),
+                                     nz['eps_u'], nz['rff_w'], nz['rff_eps'], nz['rff_u'], want_Lu=want_Lu)
+        self.cache.noise = nz
+        k._set_cache(self.cache, nz)
+        return self.cache
+
+    def forward(self, x):
+        """f(x) = f_prior(x) + K(x,Z) nu for the cached draw (svpy.py:123-142)."""
+        if self.cache is None:
+            raise RuntimeError('call build_cache() first')
+        return ops.rhs(self.cache, x, mode=0)
+
+    def kl(self):
+        """KL(q(u) || N(0,I)) in whitened form (svpy.py:144-175)."""
+        return ops.svgp_kl(self.Um.optvar, self.Us_sqrt.optvar, self.M)

@@ -110,3 +110,71 @@ def rollout(cache, z0, ts, order, method):
     _lib.call('gpode_rollout_fwd', KERNEL_ID[cache.kernel], order, METHOD_ID[method], cache.Di, cache.Do, cache.M,
               cache.S, _ptr(cache.pack), _ptr(z0), _ptr(ts), N, T, _ptr(zt), _stream())
     return zt
+
+
+def kernel_matrix(kernel, raw_ell, raw_var, X, X2=None):
+    """kern.K(X, X2) (kernels.py:98-110 / :289-303)."""
+    X = _chk(X, 'X')
+    X2 = X if X2 is None else _chk(X2, 'X2')
+    Do, Di = raw_ell.shape
+    N, M2 = X.shape[0], X2.shape[0]
+    shape = (Do, N, M2) if kernel == 'RBF' else (N * Do, M2 * Do)
+    out = torch.empty(shape, dtype=torch.float32, device=X.device)
+    _lib.call('gpode_kernel_matrix', KERNEL_ID[kernel], Di, Do, _ptr(_chk(raw_ell, 'raw_ell')), _ptr(_chk(raw_var, 'raw_var')),
+              _ptr(X), N, _ptr(X2), M2, _ptr(out), _stream())
+    return out
+
+
+class _SvgpKL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Um, Us, M):
+        Um_c, Us_c = _chk(Um, 'Um'), _chk(Us, 'Us_sqrt.optvar')
+        kl = torch.empty((), dtype=torch.float32, device=Um.device)
+        _lib.call('gpode_svgp_kl_fwd', M, Um_c.shape[1], _ptr(Um_c), _ptr(Us_c), _ptr(kl), _stream())
+        ctx.save_for_backward(Um_c, Us_c)
+        ctx.M = M
+        return kl
+
+    @staticmethod
+    def backward(ctx, g):
+        Um, Us = ctx.saved_tensors
+        g = g.contiguous().float()
+        dUm, dUs = torch.empty_like(Um), torch.empty_like(Us)
+        _lib.call('gpode_svgp_kl_bwd', ctx.M, Um.shape[1], _ptr(Um), _ptr(Us), _ptr(g), _ptr(dUm), _ptr(dUs), _stream())
+        return dUm, dUs, None
+
+
+def svgp_kl(Um, Us_packed, M):
+    """SVGP_Layer.kl (svpy.py:144-175), differentiable."""
+    return _SvgpKL.apply(Um, Us_packed, M)
+
+
+class _Flow(torch.autograd.Function):
+    """One GP function draw + fixed-grid integration (flow.py:68-86), differentiable w.r.t. z0 and the five
+    GP parameter tensors.  Forward: gpode_cache_build_fwd + gpode_rollout_fwd.  Backward: reverse sweep
+    kernels (gpode_rollout_bwd / gpode_cache_build_bwd)."""
+
+    @staticmethod
+    def forward(ctx, z0, ts, raw_ell, raw_var, Z, Um, Us, gp, order, method):
+        cache = gp.build_cache()
+        zt = rollout(cache, z0, ts, order, method)
+        ctx.gp, ctx.cache, ctx.order, ctx.method = gp, cache, order, method
+        ctx.save_for_backward(z0, ts, zt)
+        return zt
+
+    @staticmethod
+    def backward(ctx, gzt):
+        z0, ts, zt = ctx.saved_tensors
+        grads = flow_backward(ctx.cache, z0, ts, zt, gzt.contiguous(), ctx.order, ctx.method, ctx.needs_input_grad)
+        return (grads['z0'], None, grads['raw_ell'], grads['raw_var'], grads['Z'], grads['Um'], grads['Us'], None, None, None)
+
+
+def flow(gp, z0, ts, order, method):
+    k = gp.kern
+    return _Flow.apply(z0, ts, k.unconstrained_lengthscales, k.unconstrained_variance, gp.inducing_loc.optvar,
+                       gp.Um.optvar, gp.Us_sqrt.optvar, gp, order, method)
+
+
+def flow_backward(cache, z0, ts, zt, gzt, order, method, needs):
+    raise _lib.GpodeError('the HIP reverse sweep (gpode_rollout_bwd) is not built in this version; '
+                          'there is no autograd/CPU fallback')
