@@ -70,7 +70,12 @@ def make_inputs(w, seed, dev, rank):
 def cpu_baseline(w, p, nz, z0, ts, budget_s=12.0):
     """CPU oracle (torch CPU, all host cores) on the same workload: GP draw + RK4 rollout."""
     from oracle import gpode_oracle as O
-    cores = os.cpu_count() or 1
+    # the box's CPU share, not the host's core count (a 1-GPU box is allotted 16 cores)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get('BENCH_CPU_THREADS', '16'))))
     torch.set_num_threads(cores)
     N = z0.shape[0]
 
@@ -130,8 +135,7 @@ def main():
             ev[1].record()
         return zt
 
-    chk = flow(z0d, tsd) if True else None  # the public API path once (untimed), must agree with the split form
-    gp.set_noise(nzd)
+    gp.set_noise(nzd)  # the public API path once (untimed) must agree with the bracketed form
     if not torch.equal(flow(z0d, tsd), step()):
         raise SystemExit('Flow.forward and the bracketed step disagree')
 
@@ -174,6 +178,7 @@ def main():
                              'algorithmic flops = %.3f MFLOP/traj x %d traj (SURVEY 8d)' % (w['mflop'], w['batch'])},
     }
     if rank == 0:
+        print('[bench] gpu leg done: %.1f traj/s, rollout %.3f ms/launch' % (value, roll_ms), file=sys.stderr, flush=True)
         if not a.no_cpu_baseline and n_gpus == 1:
             out['cpu_baseline'] = cpu_baseline(w, p, nz, z0, ts)
             out['gpu_over_cpu'] = value / out['cpu_baseline']['value']

@@ -113,3 +113,18 @@ def test_closer_to_fp64_truth_than_tolerance(name, kernel, order):
     e_ref = relerr(g['zt_rk4'], zt64)
     print('%s: |hip-fp64|=%.2e |ref-fp64|=%.2e' % (name, e_hip, e_ref))
     assert e_hip < 5 * e_ref + 1e-5
+
+
+@pytest.mark.parametrize('name,kernel,order', [('gp_df1_cfg2', 'DF', 1), ('gp_rbf1_cfg1', 'RBF', 1)])
+def test_bitwise_reproducible(name, kernel, order):
+    """Same inputs -> bit-identical cache and trajectories, launch after launch (no atomics, no
+    order-dependent hand-offs on the forward path)."""
+    from vae_gp_ode_amd import ops
+    g = load_golden(name)
+    ref_nu = ref_zt = None
+    for _ in range(8):
+        c = build(g, kernel, want_Lu=False)
+        zt = ops.rollout(c, g['z0'].cuda(), g['ts'].cuda(), order, 'rk4')
+        if ref_nu is None:
+            ref_nu, ref_zt = c.nu.clone(), zt.clone()
+        assert torch.equal(c.nu, ref_nu) and torch.equal(zt, ref_zt)

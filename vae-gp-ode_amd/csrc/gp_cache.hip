@@ -245,15 +245,18 @@ __device__ __forceinline__ void trinv32_wave(const float (&Lrow)[NB], float (&x)
 }
 
 // One block column k of the left-looking factorisation.  grid = (nblk - k, batch), block = 256.
+// The factored diagonal block L_kk goes to Dfac (NOT in place: the other workgroups of this launch still
+// read the unfactored A_kk), its inverse to Dinv; off-diagonal panel blocks are overwritten in place.
 __global__ __launch_bounds__(256) void k_chol_step(float* __restrict__ Aall, int np, size_t batch_stride,
-                                                    float* __restrict__ Dinv_all, size_t dinv_stride, int k,
-                                                    int* __restrict__ info) {
+                                                    float* __restrict__ Dinv_all, float* __restrict__ Dfac_all,
+                                                    size_t dinv_stride, int k, int* __restrict__ info) {
   __shared__ float sLk[NB][NB + 1];
   __shared__ float sLi[NB][NB + 1];
   __shared__ float sD[NB][NB + 1];    // diagonal block -> L_kk^-1
   __shared__ float sR[NB][NB + 1];    // this workgroup's panel block
   float* A = Aall + (size_t)blockIdx.y * batch_stride;
   float* Dinv = Dinv_all + (size_t)blockIdx.y * dinv_stride + (size_t)k * NB * NB;
+  float* Dfac = Dfac_all + (size_t)blockIdx.y * dinv_stride + (size_t)k * NB * NB;
   const int i = k + blockIdx.x;
   const int row0 = i * NB, col0 = k * NB;
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void k_chol_step(float* __restrict__ Aall, int
     if (tid < 32) {
       if (i == k) {  // the diagonal workgroup publishes L_kk (lower) and L_kk^-1
 #pragma unroll
-        for (int c = 0; c < NB; ++c) A[(size_t)(col0 + r) * np + col0 + c] = (c <= r) ? row[c] : 0.f;
+        for (int c = 0; c < NB; ++c) Dfac[r * NB + c] = (c <= r) ? row[c] : 0.f;
 #pragma unroll
         for (int rr = 0; rr < NB; ++rr) Dinv[rr * NB + r] = x[rr];
       }
@@ -318,7 +321,8 @@ __global__ __launch_bounds__(256) void k_chol_step(float* __restrict__ Aall, int
 // nu = L^-T (u - y),  y = row n of the factor (forward-solved rhs).  grid = batch, block = 256.
 //   u element (j) of batch b at u[j * u_stride + b * u_bstride]; nu written dense (batch, n).
 __global__ __launch_bounds__(256) void k_solve_back(const float* __restrict__ Aall, int n, int np, size_t batch_stride,
-                                                     const float* __restrict__ Dinv_all, size_t dinv_stride,
+                                                     const float* __restrict__ Dinv_all, const float* __restrict__ Dfac_all,
+                                                     size_t dinv_stride,
                                                      const float* __restrict__ u, int u_stride, int u_bstride,
                                                      float* __restrict__ nu) {
   extern __shared__ float sv[];  // np floats: residual, overwritten by the solution
@@ -326,8 +330,14 @@ __global__ __launch_bounds__(256) void k_solve_back(const float* __restrict__ Aa
   const float* A = Aall + (size_t)blockIdx.x * batch_stride;
   const float* Dinv = Dinv_all + (size_t)blockIdx.x * dinv_stride;
   const int tid = threadIdx.x;
-  for (int j = tid; j < np; j += blockDim.x)
-    sv[j] = j < n ? u[(size_t)j * u_stride + (size_t)blockIdx.x * u_bstride] - A[(size_t)n * np + j] : 0.f;
+  // y = row n of the factor: left of the last diagonal block it sits in A, inside it in Dfac
+  const int kl = n / NB, cl = kl * NB;
+  const float* Dl = Dfac_all + (size_t)blockIdx.x * dinv_stride + (size_t)kl * NB * NB;
+  for (int j = tid; j < np; j += blockDim.x) {
+    float y = 0.f;
+    if (j < n) y = (j < cl) ? A[(size_t)n * np + j] : Dl[(n - cl) * NB + (j - cl)];
+    sv[j] = j < n ? u[(size_t)j * u_stride + (size_t)blockIdx.x * u_bstride] - y : 0.f;
+  }
   __syncthreads();
   const int nblk = cdiv(n, NB);
   for (int k = nblk - 1; k >= 0; --k) {
@@ -356,18 +366,25 @@ __global__ __launch_bounds__(256) void k_solve_back(const float* __restrict__ Aa
 }
 
 // dense lower-triangular copy of the factor (zeros above the diagonal)
-__global__ void k_copy_L(const float* __restrict__ Aall, int n, int np, size_t batch_stride, float* __restrict__ Lu) {
+__global__ void k_copy_L(const float* __restrict__ Aall, const float* __restrict__ Dfac_all, size_t dinv_stride,
+                         int n, int np, size_t batch_stride, float* __restrict__ Lu) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = blockIdx.y, b = blockIdx.z;
   if (c >= n) return;
-  Lu[((size_t)b * n + r) * n + c] = (c <= r) ? Aall[(size_t)b * batch_stride + (size_t)r * np + c] : 0.f;
+  float v = 0.f;
+  if (c <= r) {
+    const int kb = r / NB;
+    v = (c < kb * NB) ? Aall[(size_t)b * batch_stride + (size_t)r * np + c]
+                      : Dfac_all[(size_t)b * dinv_stride + ((size_t)kb * NB + (r - kb * NB)) * NB + (c - kb * NB)];
+  }
+  Lu[((size_t)b * n + r) * n + c] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
 // workspace layout (floats)
 // ---------------------------------------------------------------------------------------------
 struct WsLayout {
-  size_t info, ell, var, omega, u, u_prior, nu, A, Dinv, total;
+  size_t info, ell, var, omega, u, u_prior, nu, A, Dinv, Dfac, total;
   int n, np, nblk, batch;
 };
 
@@ -388,6 +405,7 @@ static WsLayout ws_layout(int kernel, int Di, int Do, int M, int S) {
   w.nu = take((size_t)w.batch * w.n);
   w.A = take((size_t)w.batch * w.np * w.np);
   w.Dinv = take((size_t)w.batch * w.nblk * NB * NB);
+  w.Dfac = take((size_t)w.batch * w.nblk * NB * NB);
   w.total = o;
   return w;
 }
@@ -445,13 +463,14 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
 
   float* A = ws + w.A;
   float* Dinv = ws + w.Dinv;
+  float* Dfac = ws + w.Dfac;
   const size_t bstride = (size_t)w.np * w.np, dstride = (size_t)w.nblk * NB * NB;
   if (kernel == 0)
     hipLaunchKernelGGL(k_Kzz_rbf, dim3(cdiv(w.np, 128), w.np, Do), 128, 0, st, Di, Do, M, w.np, Z, ws + w.ell, ws + w.var, ws + w.u_prior, A);
   else
     hipLaunchKernelGGL(k_Kzz_df, dim3(cdiv(w.np, 128), w.np, 1), 128, 0, st, Do, M, w.np, Z, ws + w.ell, ws + w.var, ws + w.u_prior, A);
   for (int k = 0; k < w.nblk; ++k)
-    hipLaunchKernelGGL(k_chol_step, dim3(w.nblk - k, w.batch), 256, 0, st, A, w.np, bstride, Dinv, dstride, k, info);
+    hipLaunchKernelGGL(k_chol_step, dim3(w.nblk - k, w.batch), 256, 0, st, A, w.np, bstride, Dinv, Dfac, dstride, k, info);
   if (check_launch("cholesky")) return 1;
 
   // nu = L^-T (u - L^-1 u_prior)
@@ -459,14 +478,14 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
     const int u_stride = kernel == 0 ? Do : 1, u_bstride = kernel == 0 ? 1 : 0;
     const size_t lds = sizeof(float) * w.np;
     if (set_max_lds((const void*)k_solve_back, lds)) return 1;
-    hipLaunchKernelGGL(k_solve_back, w.batch, 256, lds, st, A, w.n, w.np, bstride, Dinv, dstride, ws + w.u, u_stride, u_bstride, ws + w.nu);
+    hipLaunchKernelGGL(k_solve_back, w.batch, 256, lds, st, A, w.n, w.np, bstride, Dinv, Dfac, dstride, ws + w.u, u_stride, u_bstride, ws + w.nu);
   }
   hipLaunchKernelGGL(k_pack_ind, cdiv((int)(MJ * 64), 256), 256, 0, st, kernel, Di, Do, M, Z, ws + w.nu, ws + w.var, pack_ind);
   if (nu) {
     e = hipMemcpyAsync(nu, ws + w.nu, sizeof(float) * w.batch * w.n, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return set_error("memcpy: %s", hipGetErrorString(e));
   }
-  if (Lu) hipLaunchKernelGGL(k_copy_L, dim3(cdiv(w.n, 128), w.n, w.batch), 128, 0, st, A, w.n, w.np, bstride, Lu);
+  if (Lu) hipLaunchKernelGGL(k_copy_L, dim3(cdiv(w.n, 128), w.n, w.batch), 128, 0, st, A, Dfac, dstride, w.n, w.np, bstride, Lu);
   return check_launch("cache build");
 }
 

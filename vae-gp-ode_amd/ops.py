@@ -41,7 +41,7 @@ class GPCache:
     """Per-draw cache: the lane-major ``pack`` the kernels consume, plus the attributes the reference
     caches on ``kern`` (kernels.py:134-137,172)."""
     __slots__ = ('kernel', 'Di', 'Do', 'M', 'S', 'pack', 'ws', 'ell', 'var', 'omega', 'phase', 'u', 'Lu', 'nu',
-                 'u_prior')
+                 'u_prior', 'noise')
 
     def check_factorisation(self):
         """Raise like torch.linalg.cholesky does when K_uu + jitter*I is not positive definite
