@@ -30,133 +30,138 @@ __device__ __forceinline__ float softplus_lower(float x) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// hyper-parameters + uniform tail
+// k_prep: everything that depends only on the raw parameters and the noise, in ONE launch.
+// Block ranges (256 threads each):
+//   [0, nb_rff)            rff records of the pack            (thread per (j, d|i, lane))
+//   [.., + nb_u)           inducing sample u = tril(Us) eps_u + Um   (one wavefront per (n,d) row)
+//   [.., + nb_ind)         inducing records: Z, zeroed coefficient fields
+//   [.., + nb_hyp)         ell, var (softplus + 1e-12), uniform tail of the pack
+//   [.., + nb_om)          API-visible omega (Di,S,Do) and phase (1,S,Do)
 // ---------------------------------------------------------------------------------------------
-__global__ void k_hyper(int kernel, int Di, int Do, const float* __restrict__ raw_ell, const float* __restrict__ raw_var,
-                        float* __restrict__ ell_ws, float* __restrict__ var_ws, float* __restrict__ ell_out,
-                        float* __restrict__ var_out, float* __restrict__ uni) {
-  const int t = threadIdx.x;
-  for (int e = t; e < Do * Di; e += blockDim.x) {
-    float l = softplus_lower(raw_ell[e]);
-    ell_ws[e] = l;
-    if (ell_out) ell_out[e] = l;
-    float il2 = 1.f / (l * l);
-    if (kernel == 0) uni[e] = -0.5f * GP_LOG2E * il2;        // wl[d][i]
-    else { uni[e] = -0.5f * GP_LOG2E * il2; uni[Do * Di + e] = il2; }  // wab[a][b], il2[a][b]
-  }
-  for (int d = t; d < Do; d += blockDim.x) {
-    float v = softplus_lower(raw_var[d]);
-    var_ws[d] = v;
-    if (var_out) var_out[d] = v;
-    if (kernel == 1) uni[2 * Do * Di + d] = v;
-  }
-}
+struct PrepArgs {
+  int kernel, Di, Do, M, S;
+  const float *raw_ell, *raw_var, *Z, *Um, *Us, *eps_u, *rff_w, *rff_eps, *rff_u;
+  float *pack, *pack_ind, *uni;
+  float *ell_ws, *var_ws, *u_ws;
+  float *ell_out, *var_out, *omega_out, *phase_out, *u_out;
+  int nb_rff, nb_u, nb_ind, nb_hyp, nb_om;
+};
 
-// omega[i,s,d] = eps[i,s,d] / ell[d,i];  phase[s,d] = u * 2 * pi  (API-visible copies)
-__global__ void k_omega(int Di, int Do, int S, const float* __restrict__ rff_eps, const float* __restrict__ rff_u,
-                        const float* __restrict__ ell, float* __restrict__ omega_ws, float* __restrict__ omega_out,
-                        float* __restrict__ phase_out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const int tot = Di * S * Do;
-  if (e < tot) {
-    const int d = e % Do, i = e / (S * Do);
-    float o = rff_eps[e] / ell[d * Di + i];
-    omega_ws[e] = o;
-    if (omega_out) omega_out[e] = o;
-  }
-  if (phase_out && e < S * Do) phase_out[e] = (rff_u[e] * 2.f) * 3.14159265358979323846f;
-}
-
-// u[n,d] = sum_{m<=n} Us[d, n(n+1)/2 + m] eps_u[m,d] + Um[n,d]   (svpy.py:94-100, transforms.py:71-77)
-__global__ void k_inducing_sample(int M, int Do, const float* __restrict__ Us, const float* __restrict__ eps_u,
-                                  const float* __restrict__ Um, float* __restrict__ u_ws, float* __restrict__ u_out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= M * Do) return;
-  const int n = e / Do, d = e % Do;
-  const float* row = Us + (size_t)d * ((size_t)M * (M + 1) / 2) + (size_t)n * (n + 1) / 2;
-  float acc = 0.f;
-  for (int m = 0; m <= n; ++m) acc = fmaf(row[m], eps_u[m * Do + d], acc);
-  acc += Um[e];
-  u_ws[e] = acc;
-  if (u_out) u_out[e] = acc;
-}
-
-__device__ __forceinline__ void put_rec(float* __restrict__ pack, size_t rec_f4_base, int RQ, int lane, int field, float v) {
+__device__ __forceinline__ void put_rec(float* __restrict__ pack, size_t rec_f4_base, int lane, int field, float v) {
   // float index of (record base in float4 units, quad q = field/4, lane, component field%4)
   pack[((rec_f4_base + (size_t)(field >> 2)) * 64 + lane) * 4 + (field & 3)] = v;
 }
 
-// RBF rff records: thread per (j,d,lane)
-__global__ void k_pack_rff_rbf(int Di, int Do, int S, const float* __restrict__ omega, const float* __restrict__ rff_u,
-                               const float* __restrict__ rff_w, const float* __restrict__ var, float* __restrict__ pack) {
-  const int RQ = cdiv(Di + 2, 4);
-  const int SJ = cdiv(S, 64);
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= SJ * Do * 64) return;
-  const int lane = e & 63, d = (e >> 6) % Do, j = (e >> 6) / Do;
-  const int s = j * 64 + lane;
-  const size_t base = (size_t)(j * Do + d) * RQ;
-  const bool ok = s < S;
-  for (int i = 0; i < Di; ++i) put_rec(pack, base, RQ, lane, i, ok ? omega[((size_t)i * S + s) * Do + d] * GP_INV2PI : 0.f);
-  put_rec(pack, base, RQ, lane, Di, ok ? rff_u[s * Do + d] : 0.f);
-  put_rec(pack, base, RQ, lane, Di + 1, ok ? sqrtf(var[d] / (float)S) * rff_w[s * Do + d] : 0.f);
-  for (int f = Di + 2; f < 4 * RQ; ++f) put_rec(pack, base, RQ, lane, f, 0.f);
-}
-
-// DF rff records: thread per (j,i,lane)
-__global__ void k_pack_rff_df(int D, int S, const float* __restrict__ omega, const float* __restrict__ rff_u,
-                              const float* __restrict__ rff_w, const float* __restrict__ var, float* __restrict__ pack) {
-  const int RQ = cdiv(2 * D + 3, 4);
-  const int SJ = cdiv(S, 64);
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= SJ * D * 64) return;
-  const int lane = e & 63, i = (e >> 6) % D, j = (e >> 6) / D;
-  const int s = j * 64 + lane;
-  const size_t base = (size_t)(j * D + i) * RQ;
-  const bool ok = s < S;
-  // theta_si = u[s,i] + sum_k x_k omega[k,s,i]
-  for (int k = 0; k < D; ++k) put_rec(pack, base, RQ, lane, k, ok ? omega[((size_t)k * S + s) * D + i] * GP_INV2PI : 0.f);
-  put_rec(pack, base, RQ, lane, D, ok ? rff_u[s * D + i] : 0.f);
-  put_rec(pack, base, RQ, lane, D + 1, ok ? rff_w[s * D + i] : 0.f);
-  put_rec(pack, base, RQ, lane, D + 2, ok ? rff_w[(S + s) * D + i] : 0.f);
-  // B[s,i,jj] = norm_{s,jj} delta_{i,jj} - (sum_k omega[i,s,k] omega[jj,s,k]) / norm_{s,jj},
-  // norm_{s,jj} = sqrt(sum_k' omega[k',s,jj]^2)   (kernels.py:327-336)
-  for (int jj = 0; jj < D; ++jj) {
-    float v = 0.f;
-    if (ok) {
-      float n2 = 0.f, g = 0.f;
-      for (int k = 0; k < D; ++k) {
-        float o = omega[((size_t)k * S + s) * D + jj];
-        n2 = fmaf(o, o, n2);
-        g = fmaf(omega[((size_t)i * S + s) * D + k], omega[((size_t)jj * S + s) * D + k], g);
+__global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
+  const int Di = a.Di, Do = a.Do, S = a.S, M = a.M;
+  int blk = blockIdx.x;
+  const int tid = threadIdx.x;
+  __shared__ float sEll[256], sVar[16];  // Do*Di <= 256, Do <= 16 for every compiled specialisation
+  for (int e = tid; e < Do * Di; e += 256) sEll[e] = softplus_lower(a.raw_ell[e]);
+  if (tid < Do) sVar[tid] = softplus_lower(a.raw_var[tid]);
+  __syncthreads();
+  auto ELL = [&](int d, int i) { return sEll[d * Di + i]; };   // ell[d,i]
+  auto VAR = [&](int d) { return sVar[d]; };
+  // omega[i,s,d] = eps[i,s,d] / ell[d,i]   (kernels.py:112-124)
+  auto OM = [&](int i, int s, int d) { return a.rff_eps[((size_t)i * S + s) * Do + d] / ELL(d, i); };
+  if (blk < a.nb_rff) {
+    const int e = blk * 256 + tid;
+    const int SJ = cdiv(S, 64);
+    if (e >= SJ * Do * 64) return;
+    const int lane = e & 63, dd = (e >> 6) % Do, j = (e >> 6) / Do;
+    const int s = j * 64 + lane;
+    const bool ok = s < S;
+    if (a.kernel == 0) {
+      const int RQ = cdiv(Di + 2, 4);
+      const size_t base = (size_t)(j * Do + dd) * RQ;
+      for (int i = 0; i < Di; ++i) put_rec(a.pack, base, lane, i, ok ? OM(i, s, dd) * GP_INV2PI : 0.f);
+      put_rec(a.pack, base, lane, Di, ok ? a.rff_u[s * Do + dd] : 0.f);
+      put_rec(a.pack, base, lane, Di + 1, ok ? sqrtf(VAR(dd) / (float)S) * a.rff_w[s * Do + dd] : 0.f);
+      for (int f = Di + 2; f < 4 * RQ; ++f) put_rec(a.pack, base, lane, f, 0.f);
+    } else {
+      const int D = Do, i = dd;
+      const int RQ = cdiv(2 * D + 3, 4);
+      const size_t base = (size_t)(j * D + i) * RQ;
+      // theta_si = u[s,i] + sum_k x_k omega[k,s,i]
+      for (int k = 0; k < D; ++k) put_rec(a.pack, base, lane, k, ok ? OM(k, s, i) * GP_INV2PI : 0.f);
+      put_rec(a.pack, base, lane, D, ok ? a.rff_u[s * D + i] : 0.f);
+      put_rec(a.pack, base, lane, D + 1, ok ? a.rff_w[s * D + i] : 0.f);
+      put_rec(a.pack, base, lane, D + 2, ok ? a.rff_w[(S + s) * D + i] : 0.f);
+      // B[s,i,jj] = norm_{s,jj} delta_{i,jj} - (sum_k omega[i,s,k] omega[jj,s,k]) / norm_{s,jj},
+      // norm_{s,jj} = sqrt(sum_k' omega[k',s,jj]^2)   (kernels.py:327-336)
+      for (int jj = 0; jj < D; ++jj) {
+        float v = 0.f;
+        if (ok) {
+          float n2 = 0.f, g = 0.f;
+          for (int k = 0; k < D; ++k) {
+            float o = OM(k, s, jj);
+            n2 = fmaf(o, o, n2);
+            g = fmaf(OM(i, s, k), OM(jj, s, k), g);
+          }
+          float nrm = sqrtf(n2);
+          v = (((i == jj) ? nrm : 0.f) - g / nrm) * sqrtf(VAR(jj) / (float)S);
+        }
+        put_rec(a.pack, base, lane, D + 3 + jj, v);
       }
-      float nrm = sqrtf(n2);
-      v = ((i == jj) ? nrm : 0.f) - g / nrm;
-      v *= sqrtf(var[jj] / (float)S);
+      for (int f = 2 * D + 3; f < 4 * RQ; ++f) put_rec(a.pack, base, lane, f, 0.f);
     }
-    put_rec(pack, base, RQ, lane, D + 3 + jj, v);
+    return;
   }
-  for (int f = 2 * D + 3; f < 4 * RQ; ++f) put_rec(pack, base, RQ, lane, f, 0.f);
-}
-
-// inducing records: thread per (j,lane).  nu == nullptr -> coefficient fields are zero.
-__global__ void k_pack_ind(int kernel, int Di, int Do, int M, const float* __restrict__ Z, const float* __restrict__ nu,
-                           const float* __restrict__ var, float* __restrict__ pack_ind) {
-  const int RQ2 = cdiv(Di + Do, 4);
-  const int MJ = cdiv(M, 64);
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= MJ * 64) return;
-  const int lane = e & 63, j = e >> 6;
-  const int m = j * 64 + lane;
-  const size_t base = (size_t)j * RQ2;
-  const bool ok = m < M;
-  for (int i = 0; i < Di; ++i) put_rec(pack_ind, base, RQ2, lane, i, ok ? Z[m * Di + i] : 0.f);
-  for (int d = 0; d < Do; ++d) {
-    float v = 0.f;
-    if (ok && nu) v = (kernel == 0) ? var[d] * nu[(size_t)d * M + m] : nu[(size_t)m * Do + d];
-    put_rec(pack_ind, base, RQ2, lane, Di + d, v);
+  blk -= a.nb_rff;
+  if (blk < a.nb_u) {
+    // u[n,d] = sum_{m<=n} Us[d, n(n+1)/2 + m] eps_u[m,d] + Um[n,d]   (svpy.py:94-100, transforms.py:71-77)
+    const int row = blk * 4 + (tid >> 6), lane = tid & 63;
+    if (row >= M * Do) return;
+    const int n = row / Do, d = row % Do;
+    const float* us = a.Us + (size_t)d * ((size_t)M * (M + 1) / 2) + (size_t)n * (n + 1) / 2;
+    float acc = 0.f;
+    for (int m = lane; m <= n; m += 64) acc = fmaf(us[m], a.eps_u[m * Do + d], acc);
+    acc = wave_allreduce_sum(acc) + a.Um[row];
+    if (lane == 0) {
+      a.u_ws[row] = acc;
+      if (a.u_out) a.u_out[row] = acc;
+    }
+    return;
   }
-  for (int f = Di + Do; f < 4 * RQ2; ++f) put_rec(pack_ind, base, RQ2, lane, f, 0.f);
+  blk -= a.nb_u;
+  if (blk < a.nb_ind) {
+    const int e = blk * 256 + tid;
+    const int RQ2 = cdiv(Di + Do, 4);
+    if (e >= cdiv(M, 64) * 64) return;
+    const int lane = e & 63, j = e >> 6;
+    const int m = j * 64 + lane;
+    const size_t base = (size_t)j * RQ2;
+    for (int i = 0; i < Di; ++i) put_rec(a.pack_ind, base, lane, i, m < M ? a.Z[m * Di + i] : 0.f);
+    for (int f = Di; f < 4 * RQ2; ++f) put_rec(a.pack_ind, base, lane, f, 0.f);
+    return;
+  }
+  blk -= a.nb_ind;
+  if (blk < a.nb_hyp) {
+    for (int e = tid; e < Do * Di; e += 256) {
+      float l = sEll[e];
+      a.ell_ws[e] = l;
+      if (a.ell_out) a.ell_out[e] = l;
+      float il2 = 1.f / (l * l);
+      a.uni[e] = -0.5f * GP_LOG2E * il2;            // RBF wl[d][i]  /  DF wab[a][b]
+      if (a.kernel == 1) a.uni[Do * Di + e] = il2;  // DF il2[a][b]
+    }
+    for (int d = tid; d < Do; d += 256) {
+      float v = sVar[d];
+      a.var_ws[d] = v;
+      if (a.var_out) a.var_out[d] = v;
+      if (a.kernel == 1) a.uni[2 * Do * Di + d] = v;
+    }
+    return;
+  }
+  blk -= a.nb_hyp;
+  {
+    const int e = blk * 256 + tid;
+    if (a.omega_out && e < Di * S * Do) {
+      const int d = e % Do, i = e / (S * Do);
+      a.omega_out[e] = a.rff_eps[e] / ELL(d, i);
+    }
+    if (a.phase_out && e < S * Do) a.phase_out[e] = (a.rff_u[e] * 2.f) * 3.14159265358979323846f;  // kernels.py:137
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -210,159 +215,219 @@ __global__ void k_Kzz_df(int D, int M, int np, const float* __restrict__ Z, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// 32x32 Cholesky / triangular inverse in the registers of one wavefront.
-// Lane r (lanes 32..63 mirror lanes 0..31) holds row r.  Only entries c <= r are meaningful.
+// Right-looking blocked Cholesky, NB = 32, one launch per block column k.
+// grid.x enumerates the tiles (i,j), k <= j <= i, of the trailing matrix; grid.y = batch; block = 256.
+// Every workgroup loads A_kk, A_ik, A_jk (trailing-updated so far), factors the diagonal tile and
+// solves its two panel tiles in ONE LDS pivot loop (a 96 x 32 tall panel, one barrier per pivot, all
+// 256 threads), then either publishes a result tile (j == k) or applies the rank-32 update to A_ij.
+// The work per launch is constant (no K loop), so the chain is nblk x (one tile round trip).
+// Results go to separate storage (Lmat for L_ik, Dfac for L_kk): the unfactored column-k tiles are
+// still being read by the other workgroups of the launch, so nothing they read is written in place.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void chol32_wave(float (&row)[NB], int r, int* __restrict__ info) {
+#define GP_BCAST(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (l)))
+
+// Cholesky of a 32x32 tile fused with the triangular solve of one 32x32 panel tile, in the registers of
+// ONE wavefront: lanes 0..31 hold the rows of the diagonal tile D, lanes 32..63 the rows of the panel
+// tile R.  Eliminating column j scales it by 1/sqrt(pivot) and subtracts row[j] * L[c][j] from every
+// later column c -- the same instruction stream turns D into L (lower part) and R into R L^-T, so the
+// panel solve costs no extra instructions.  Broadcasts are v_readlane (SGPR), nothing touches LDS.
+__device__ __forceinline__ void chol32_panel_wave(float (&row)[NB], int lane, bool report, int* __restrict__ info) {
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
-    float piv = __shfl(row[j], j, 64);
-    if (!(piv > 0.f) && r == 0 && info) atomicOr(info, 1);  // not positive definite (reference raises)
-    float s = sqrtf(piv);
-    float inv = 1.f / s;
-    row[j] = (r == j) ? s : row[j] * inv;
+    const float piv = GP_BCAST(row[j], j);
+    if (report && !(piv > 0.f) && lane == 0) atomicOr(info, 1);  // not positive definite (reference raises)
+    float inv = __builtin_amdgcn_rsqf(piv);
+    inv = inv * (1.5f - 0.5f * piv * inv * inv);  // one Newton step: full fp32 accuracy
+    row[j] = (lane == j) ? piv * inv : row[j] * inv;
 #pragma unroll
     for (int c = j + 1; c < NB; ++c) {
-      float lcj = __shfl(row[j], c, 64);
+      const float lcj = GP_BCAST(row[j], c);
       row[c] = fmaf(-row[j], lcj, row[c]);
     }
   }
 }
 
-// lane c gets column c of L^-1: x[r] = Linv[r][c]
-__device__ __forceinline__ void trinv32_wave(const float (&Lrow)[NB], float (&x)[NB], int c) {
-#pragma unroll
-  for (int r = 0; r < NB; ++r) {
-    float acc = (r == c) ? 1.f : 0.f;
-#pragma unroll
-    for (int p = 0; p < r; ++p) {
-      float l = __shfl(Lrow[p], r, 64);
-      acc = fmaf(-l, x[p], acc);
-    }
-    float d = __shfl(Lrow[r], r, 64);
-    x[r] = acc / d;
-  }
-}
-
-// One block column k of the left-looking factorisation.  grid = (nblk - k, batch), block = 256.
-// The factored diagonal block L_kk goes to Dfac (NOT in place: the other workgroups of this launch still
-// read the unfactored A_kk), its inverse to Dinv; off-diagonal panel blocks are overwritten in place.
-__global__ __launch_bounds__(256) void k_chol_step(float* __restrict__ Aall, int np, size_t batch_stride,
-                                                    float* __restrict__ Dinv_all, float* __restrict__ Dfac_all,
-                                                    size_t dinv_stride, int k, int* __restrict__ info) {
-  __shared__ float sLk[NB][NB + 1];
-  __shared__ float sLi[NB][NB + 1];
-  __shared__ float sD[NB][NB + 1];    // diagonal block -> L_kk^-1
-  __shared__ float sR[NB][NB + 1];    // this workgroup's panel block
+__global__ __launch_bounds__(256) void k_chol_rl(float* __restrict__ Aall, float* __restrict__ Lall, int np,
+                                                  size_t batch_stride, float* __restrict__ Dfac_all, size_t dfac_stride,
+                                                  int k, int* __restrict__ info) {
+  __shared__ float sD[NB][NB + 1], sI[NB][NB + 1], sJ[NB][NB + 1];     // loaded tiles A_kk, A_ik, A_jk
+  __shared__ float lD[NB][NB + 1], lI[NB][NB + 1], lJ[NB][NB + 1];     // factored: L_kk, L_ik, L_jk
   float* A = Aall + (size_t)blockIdx.y * batch_stride;
-  float* Dinv = Dinv_all + (size_t)blockIdx.y * dinv_stride + (size_t)k * NB * NB;
-  float* Dfac = Dfac_all + (size_t)blockIdx.y * dinv_stride + (size_t)k * NB * NB;
-  const int i = k + blockIdx.x;
-  const int row0 = i * NB, col0 = k * NB;
+  float* Lm = Lall + (size_t)blockIdx.y * batch_stride;
+  float* Dfac = Dfac_all + (size_t)blockIdx.y * dfac_stride + (size_t)k * NB * NB;
+  // tile decode: t -> (ii, jj), jj <= ii, row-major over the lower triangle
+  const int t = blockIdx.x;
+  int ii = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+  while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+  while (ii * (ii + 1) / 2 > t) --ii;
+  const int jj = t - ii * (ii + 1) / 2;
+  const int i = k + ii, j = k + jj;
+  const bool hasI = i > k, hasJ = (j > k) && (j != i);
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-  float accD[4] = {0.f, 0.f, 0.f, 0.f}, accR[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int p = 0; p < k; ++p) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = ty + 8 * q;
-      sLk[r][tx] = A[(size_t)(col0 + r) * np + p * NB + tx];
-      sLi[r][tx] = A[(size_t)(row0 + r) * np + p * NB + tx];
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int c = 0; c < NB; ++c) {
-      const float b = sLk[tx][c];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        accD[q] = fmaf(sLk[ty + 8 * q][c], b, accD[q]);
-        accR[q] = fmaf(sLi[ty + 8 * q][c], b, accR[q]);
-      }
-    }
-    __syncthreads();
-  }
+  const int c0 = k * NB;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int r = ty + 8 * q;
-    sD[r][tx] = A[(size_t)(col0 + r) * np + col0 + tx] - accD[q];
-    sR[r][tx] = A[(size_t)(row0 + r) * np + col0 + tx] - accR[q];
+    sD[r][tx] = A[(size_t)(c0 + r) * np + c0 + tx];
+    sI[r][tx] = hasI ? A[(size_t)(i * NB + r) * np + c0 + tx] : 0.f;
+    sJ[r][tx] = hasJ ? A[(size_t)(j * NB + r) * np + c0 + tx] : 0.f;
   }
   __syncthreads();
-  if (tid < 64) {
-    const int r = tid & 31;
-    float row[NB], x[NB];
+  const int wv = tid >> 6, lane = tid & 63;
+  if (wv == 0 || (wv == 1 && hasJ)) {
+    // wave 0: [D ; A_ik], wave 1: [D ; A_jk] (D refactored redundantly, no cross-wave traffic)
+    const int r = lane & 31;
+    const bool panel = lane >= 32;
+    float row[NB];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) row[c] = sD[r][c];
-    chol32_wave(row, r, (blockIdx.x == 0) ? info : nullptr);
-    trinv32_wave(row, x, r);
-    if (tid < 32) {
-      if (i == k) {  // the diagonal workgroup publishes L_kk (lower) and L_kk^-1
+    for (int c = 0; c < NB; ++c) row[c] = panel ? (wv == 0 ? sI[r][c] : sJ[r][c]) : sD[r][c];
+    chol32_panel_wave(row, lane, wv == 0 && t == 0, info);
 #pragma unroll
-        for (int c = 0; c < NB; ++c) Dfac[r * NB + c] = (c <= r) ? row[c] : 0.f;
-#pragma unroll
-        for (int rr = 0; rr < NB; ++rr) Dinv[rr * NB + r] = x[rr];
-      }
-#pragma unroll
-      for (int rr = 0; rr < NB; ++rr) sD[rr][r] = x[rr];  // sD <- L_kk^-1 (row rr, col r)
+    for (int c = 0; c < NB; ++c) {
+      if (panel) { if (wv == 0) lI[r][c] = row[c]; else lJ[r][c] = row[c]; }
+      else if (wv == 0) lD[r][c] = (c <= r) ? row[c] : 0.f;
     }
   }
   __syncthreads();
-  if (i != k) {
-    // X = R L_kk^-T :  X[r][c] = sum_{p<=c} R[r][p] Linv[c][p]
+  if (j == k) {
+    // column-k tiles: publish the factor
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = ty + 8 * q;
+      if (i == k) Dfac[r * NB + tx] = lD[r][tx];
+      else Lm[(size_t)(i * NB + r) * np + c0 + tx] = lI[r][tx];
+    }
+  } else {
+    // trailing tile: A_ij -= L_ik L_jk^T   (j == i: L_jk is L_ik)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = ty + 8 * q;
       float acc = 0.f;
-      for (int p = 0; p <= tx; ++p) acc = fmaf(sR[r][p], sD[tx][p], acc);
-      A[(size_t)(row0 + r) * np + col0 + tx] = acc;
+      if (hasJ) {
+#pragma unroll 8
+        for (int p = 0; p < NB; ++p) acc = fmaf(lI[r][p], lJ[tx][p], acc);
+      } else {
+#pragma unroll 8
+        for (int p = 0; p < NB; ++p) acc = fmaf(lI[r][p], lI[tx][p], acc);
+      }
+      float* dst = A + (size_t)(i * NB + r) * np + j * NB + tx;
+      *dst = *dst - acc;
     }
   }
 }
 
 // nu = L^-T (u - y),  y = row n of the factor (forward-solved rhs).  grid = batch, block = 256.
-//   u element (j) of batch b at u[j * u_stride + b * u_bstride]; nu written dense (batch, n).
+//   u element j of batch b at u[j * u_stride + b * u_bstride]; nu written dense (batch, n) and, scaled, into
+//   the coefficient fields of the pack's inducing records (RBF: var_d nu[d,m]; DF: nu[(m,a)]).
+// Right-looking block back-substitution.  CPT > 0: every thread owns CPT columns and prefetches the next
+// block row of L into registers while the current 32x32 diagonal system is solved in wave 0 (the global
+// loads do not depend on the solution, so their latency leaves the dependency chain).  CPT == 0: any n,
+// loads issued inside the chain.
+template <int CPT>
 __global__ __launch_bounds__(256) void k_solve_back(const float* __restrict__ Aall, int n, int np, size_t batch_stride,
-                                                     const float* __restrict__ Dinv_all, const float* __restrict__ Dfac_all,
-                                                     size_t dinv_stride,
+                                                     const float* __restrict__ Dfac_all, size_t dfac_stride,
                                                      const float* __restrict__ u, int u_stride, int u_bstride,
-                                                     float* __restrict__ nu) {
+                                                     float* __restrict__ nu, float* __restrict__ nu_out,
+                                                     int kernel, int Di, int Do, int M, const float* __restrict__ var,
+                                                     float* __restrict__ pack_ind) {
   extern __shared__ float sv[];  // np floats: residual, overwritten by the solution
   __shared__ float sx[NB];
-  const float* A = Aall + (size_t)blockIdx.x * batch_stride;
-  const float* Dinv = Dinv_all + (size_t)blockIdx.x * dinv_stride;
-  const int tid = threadIdx.x;
-  // y = row n of the factor: left of the last diagonal block it sits in A, inside it in Dfac
-  const int kl = n / NB, cl = kl * NB;
-  const float* Dl = Dfac_all + (size_t)blockIdx.x * dinv_stride + (size_t)kl * NB * NB;
-  for (int j = tid; j < np; j += blockDim.x) {
+  const int b = blockIdx.x;
+  const float* A = Aall + (size_t)b * batch_stride;
+  const float* Dfac = Dfac_all + (size_t)b * dfac_stride;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int kl = n / NB, cl = kl * NB;  // block holding the rhs row n
+  for (int j = tid; j < np; j += 256) {
     float y = 0.f;
-    if (j < n) y = (j < cl) ? A[(size_t)n * np + j] : Dl[(n - cl) * NB + (j - cl)];
-    sv[j] = j < n ? u[(size_t)j * u_stride + (size_t)blockIdx.x * u_bstride] - y : 0.f;
+    if (j < n) y = (j < cl) ? A[(size_t)n * np + j] : Dfac[(size_t)kl * NB * NB + (n - cl) * NB + (j - cl)];
+    sv[j] = j < n ? u[(size_t)j * u_stride + (size_t)b * u_bstride] - y : 0.f;
   }
-  __syncthreads();
   const int nblk = cdiv(n, NB);
+  constexpr int CP = CPT > 0 ? CPT : 1;
+  float cur[CP][NB], nxt[CP][NB];
+  auto prefetch = [&](float (&dst)[CP][NB], int k) {
+    if (CPT == 0 || k < 0) return;
+    const int c0 = k * NB;
+#pragma unroll
+    for (int q = 0; q < CP; ++q) {
+      const int c = tid + 256 * q;
+#pragma unroll
+      for (int r = 0; r < NB; ++r) dst[q][r] = (c < c0) ? A[(size_t)(c0 + r) * np + c] : 0.f;
+    }
+  };
+  // lane c of wave 0 holds column c of the current diagonal block L_kk (prefetched one step ahead)
+  const int cc = lane & 31;
+  float Lc[NB], Lc_nxt[NB];
+  auto prefetch_diag = [&](float (&dst)[NB], int k) {
+    if (k < 0 || tid >= 64) return;
+    const float* Lk = Dfac + (size_t)k * NB * NB;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) dst[r] = Lk[r * NB + cc];
+  };
+  prefetch(cur, nblk - 1);
+  prefetch_diag(Lc, nblk - 1);
+  __syncthreads();
   for (int k = nblk - 1; k >= 0; --k) {
     const int c0 = k * NB;
-    if (tid < NB) {
-      // x_k[c] = sum_{r>=c, c0+r<n} Linv_kk[r][c] * res[c0+r]
-      const float* Li = Dinv + (size_t)k * NB * NB;
-      float acc = 0.f;
-      for (int r = tid; r < NB; ++r)
-        if (c0 + r < n) acc = fmaf(Li[r * NB + tid], sv[c0 + r], acc);
-      sx[tid] = (c0 + tid < n) ? acc : 0.f;
+    prefetch(nxt, k - 1);
+    prefetch_diag(Lc_nxt, k - 1);
+    if (tid < 64) {
+      // 32x32 transposed solve in wave 0: lane c holds column c of L_kk and residual c
+      const int c = cc;
+      float res = sv[c0 + c];
+      float d = 1.f;
+#pragma unroll
+      for (int r = 0; r < NB; ++r) d = (r == c) ? Lc[r] : d;
+      const float myinv = 1.f / d;
+#pragma unroll
+      for (int r = NB - 1; r >= 0; --r) {
+        // x_r = res_r / L_rr  (rows past n are padding: x = 0)
+        float xr = GP_BCAST(res, r) * GP_BCAST(myinv, r);
+        xr = (c0 + r < n) ? xr : 0.f;
+        res = (c == r) ? xr : fmaf(-Lc[r], xr, res);  // lanes c < r consume L[r][c]; lanes c > r hold x already
+      }
+      if (lane < NB) { sx[lane] = res; sv[c0 + lane] = res; }
+#pragma unroll
+      for (int r = 0; r < NB; ++r) Lc[r] = Lc_nxt[r];
     }
     __syncthreads();
-    if (tid < NB) sv[c0 + tid] = sx[tid];
-    // res[c] -= sum_r L[c0+r][c] x_k[r]  for c < c0
-    for (int c = tid; c < c0; c += blockDim.x) {
-      float acc = sv[c];
+    if (CPT > 0) {
+#pragma unroll
+      for (int q = 0; q < CP; ++q) {
+        const int c = tid + 256 * q;
+        if (c < c0) {
+          float acc = sv[c];
+#pragma unroll
+          for (int r = 0; r < NB; ++r) acc = fmaf(-cur[q][r], sx[r], acc);
+          sv[c] = acc;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < CP; ++q)
+#pragma unroll
+        for (int r = 0; r < NB; ++r) cur[q][r] = nxt[q][r];
+    } else {
+      for (int c = tid; c < c0; c += 256) {
+        float acc = sv[c];
 #pragma unroll 8
-      for (int r = 0; r < NB; ++r)
-        if (c0 + r < n) acc = fmaf(-A[(size_t)(c0 + r) * np + c], sx[r], acc);
-      sv[c] = acc;
+        for (int r = 0; r < NB; ++r) acc = fmaf(-A[(size_t)(c0 + r) * np + c], sx[r], acc);
+        sv[c] = acc;
+      }
     }
     __syncthreads();
   }
-  for (int j = tid; j < n; j += blockDim.x) nu[(size_t)blockIdx.x * n + j] = sv[j];
+  for (int j = tid; j < n; j += 256) {
+    const float v = sv[j];
+    nu[(size_t)b * n + j] = v;
+    if (nu_out) nu_out[(size_t)b * n + j] = v;
+    // coefficient field of the inducing record (gp_eval.hpp)
+    const int RQ2 = cdiv(Di + Do, 4);
+    int m, d;
+    float coef;
+    if (kernel == 0) { m = j; d = b; coef = var[d] * v; } else { m = j / Do; d = j % Do; coef = v; }
+    const int field = Di + d;
+    pack_ind[(((size_t)(m >> 6) * RQ2 + (field >> 2)) * 64 + (m & 63)) * 4 + (field & 3)] = coef;
+  }
 }
 
 // dense lower-triangular copy of the factor (zeros above the diagonal)
@@ -384,7 +449,7 @@ __global__ void k_copy_L(const float* __restrict__ Aall, const float* __restrict
 // workspace layout (floats)
 // ---------------------------------------------------------------------------------------------
 struct WsLayout {
-  size_t info, ell, var, omega, u, u_prior, nu, A, Dinv, Dfac, total;
+  size_t info, ell, var, u, u_prior, nu, A, Lmat, Dfac, total;
   int n, np, nblk, batch;
 };
 
@@ -399,12 +464,11 @@ static WsLayout ws_layout(int kernel, int Di, int Do, int M, int S) {
   w.info = take(4);
   w.ell = take((size_t)Do * Di);
   w.var = take(Do);
-  w.omega = take((size_t)Di * S * Do);
   w.u = take((size_t)M * Do);
   w.u_prior = take((size_t)M * Do);
   w.nu = take((size_t)w.batch * w.n);
   w.A = take((size_t)w.batch * w.np * w.np);
-  w.Dinv = take((size_t)w.batch * w.nblk * NB * NB);
+  w.Lmat = take((size_t)w.batch * w.np * w.np);
   w.Dfac = take((size_t)w.batch * w.nblk * NB * NB);
   w.total = o;
   return w;
@@ -440,52 +504,61 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
   int* info = reinterpret_cast<int*>(ws + w.info);
   hipError_t e = hipMemsetAsync(info, 0, 16, st);
   if (e != hipSuccess) return set_error("memset: %s", hipGetErrorString(e));
-
-  hipLaunchKernelGGL(k_hyper, 1, 256, 0, st, kernel, Di, Do, raw_ell, raw_var, ws + w.ell, ws + w.var, ell, var, uni);
   {
-    const int tot = Di * S * Do;
-    hipLaunchKernelGGL(k_omega, cdiv(tot, 256), 256, 0, st, Di, Do, S, rff_eps, rff_u, ws + w.ell, ws + w.omega, omega, phase);
+    PrepArgs a;
+    a.kernel = kernel; a.Di = Di; a.Do = Do; a.M = M; a.S = S;
+    a.raw_ell = raw_ell; a.raw_var = raw_var; a.Z = Z; a.Um = Um; a.Us = Us_packed;
+    a.eps_u = eps_u; a.rff_w = rff_w; a.rff_eps = rff_eps; a.rff_u = rff_u;
+    a.pack = pack; a.pack_ind = pack_ind; a.uni = uni;
+    a.ell_ws = ws + w.ell; a.var_ws = ws + w.var; a.u_ws = ws + w.u;
+    a.ell_out = ell; a.var_out = var; a.omega_out = omega; a.phase_out = phase; a.u_out = u;
+    a.nb_rff = cdiv((int)(SJ * Do * 64), 256);
+    a.nb_u = cdiv(M * Do, 4);
+    a.nb_ind = cdiv((int)(MJ * 64), 256);
+    a.nb_hyp = 1;
+    a.nb_om = (omega || phase) ? cdiv(Di * S * Do, 256) : 0;
+    hipLaunchKernelGGL(k_prep, a.nb_rff + a.nb_u + a.nb_ind + a.nb_hyp + a.nb_om, 256, 0, st, a);
+    if (check_launch("cache prep")) return 1;
   }
-  hipLaunchKernelGGL(k_inducing_sample, cdiv(M * Do, 128), 128, 0, st, M, Do, Us_packed, eps_u, Um, ws + w.u, u);
-  if (kernel == 0)
-    hipLaunchKernelGGL(k_pack_rff_rbf, cdiv((int)(SJ * Do * 64), 256), 256, 0, st, Di, Do, S, ws + w.omega, rff_u, rff_w, ws + w.var, pack);
-  else
-    hipLaunchKernelGGL(k_pack_rff_df, cdiv((int)(SJ * Do * 64), 256), 256, 0, st, Do, S, ws + w.omega, rff_u, rff_w, ws + w.var, pack);
-  hipLaunchKernelGGL(k_pack_ind, cdiv((int)(MJ * 64), 256), 256, 0, st, kernel, Di, Do, M, Z, (const float*)nullptr, ws + w.var, pack_ind);
-  if (check_launch("cache prep")) return 1;
 
   // u_prior = f_prior(Z): the rhs kernel in prior-only mode on the M inducing locations
-  if (rhs_fwd(kernel, Di, Do, M, S, pack, Z, M, ws + w.u_prior, 1, st)) return 1;
-  if (u_prior) {
-    e = hipMemcpyAsync(u_prior, ws + w.u_prior, sizeof(float) * M * Do, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return set_error("memcpy: %s", hipGetErrorString(e));
-  }
+  float* up = u_prior ? u_prior : ws + w.u_prior;
+  if (rhs_fwd(kernel, Di, Do, M, S, pack, Z, M, up, 1, st)) return 1;
 
   float* A = ws + w.A;
-  float* Dinv = ws + w.Dinv;
+  float* Lmat = ws + w.Lmat;
   float* Dfac = ws + w.Dfac;
   const size_t bstride = (size_t)w.np * w.np, dstride = (size_t)w.nblk * NB * NB;
   if (kernel == 0)
-    hipLaunchKernelGGL(k_Kzz_rbf, dim3(cdiv(w.np, 128), w.np, Do), 128, 0, st, Di, Do, M, w.np, Z, ws + w.ell, ws + w.var, ws + w.u_prior, A);
+    hipLaunchKernelGGL(k_Kzz_rbf, dim3(cdiv(w.np, 128), w.np, Do), 128, 0, st, Di, Do, M, w.np, Z, ws + w.ell, ws + w.var, up, A);
   else
-    hipLaunchKernelGGL(k_Kzz_df, dim3(cdiv(w.np, 128), w.np, 1), 128, 0, st, Do, M, w.np, Z, ws + w.ell, ws + w.var, ws + w.u_prior, A);
+    hipLaunchKernelGGL(k_Kzz_df, dim3(cdiv(w.np, 128), w.np, 1), 128, 0, st, Do, M, w.np, Z, ws + w.ell, ws + w.var, up, A);
   for (int k = 0; k < w.nblk; ++k)
-    hipLaunchKernelGGL(k_chol_step, dim3(w.nblk - k, w.batch), 256, 0, st, A, w.np, bstride, Dinv, Dfac, dstride, k, info);
+  {
+    const int T = w.nblk - k;
+    hipLaunchKernelGGL(k_chol_rl, dim3(T * (T + 1) / 2, w.batch), 256, 0, st, A, Lmat, w.np, bstride, Dfac, dstride, k, info);
+  }
   if (check_launch("cholesky")) return 1;
 
-  // nu = L^-T (u - L^-1 u_prior)
+  // nu = L^-T (u - L^-1 u_prior), written to ws, to the optional output and into the pack
   {
     const int u_stride = kernel == 0 ? Do : 1, u_bstride = kernel == 0 ? 1 : 0;
     const size_t lds = sizeof(float) * w.np;
-    if (set_max_lds((const void*)k_solve_back, lds)) return 1;
-    hipLaunchKernelGGL(k_solve_back, w.batch, 256, lds, st, A, w.n, w.np, bstride, Dinv, Dfac, dstride, ws + w.u, u_stride, u_bstride, ws + w.nu);
+    const int cpt = cdiv(w.n, 256);
+#define GP_SOLVE(CPT)                                                                                              \
+  do {                                                                                                             \
+    if (set_max_lds((const void*)k_solve_back<CPT>, lds)) return 1;                                                \
+    hipLaunchKernelGGL(k_solve_back<CPT>, w.batch, 256, lds, st, Lmat, w.n, w.np, bstride, Dfac, dstride, ws + w.u,   \
+                       u_stride, u_bstride, ws + w.nu, nu, kernel, Di, Do, M, ws + w.var, pack_ind);               \
+  } while (0)
+    if (cpt == 1) GP_SOLVE(1);
+    else if (cpt == 2) GP_SOLVE(2);
+    else if (cpt == 3) GP_SOLVE(3);
+    else if (cpt == 4) GP_SOLVE(4);
+    else GP_SOLVE(0);
+#undef GP_SOLVE
   }
-  hipLaunchKernelGGL(k_pack_ind, cdiv((int)(MJ * 64), 256), 256, 0, st, kernel, Di, Do, M, Z, ws + w.nu, ws + w.var, pack_ind);
-  if (nu) {
-    e = hipMemcpyAsync(nu, ws + w.nu, sizeof(float) * w.batch * w.n, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return set_error("memcpy: %s", hipGetErrorString(e));
-  }
-  if (Lu) hipLaunchKernelGGL(k_copy_L, dim3(cdiv(w.n, 128), w.n, w.batch), 128, 0, st, A, Dfac, dstride, w.n, w.np, bstride, Lu);
+  if (Lu) hipLaunchKernelGGL(k_copy_L, dim3(cdiv(w.n, 128), w.n, w.batch), 128, 0, st, Lmat, Dfac, dstride, w.n, w.np, bstride, Lu);
   return check_launch("cache build");
 }
 

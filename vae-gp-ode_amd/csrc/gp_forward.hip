@@ -288,9 +288,9 @@ static int launch_rhs_df(const float* pack, int M, int S, const float* x, int N,
   const size_t f4 = L::rff_f4(S) + L::ind_f4(M);
   int grid, block;
   grid_for(N, grid, block);
-  if (f4 * 16 <= kLdsLimitBytes) {
-    if (N <= 1024) { block = 64; grid = N < 256 ? N : 256; }
-    else { block = 256; grid = 256; }
+  // one evaluation per row: staging the pack in LDS only pays when a workgroup evaluates many rows
+  if (f4 * 16 <= kLdsLimitBytes && N >= 2048) {
+    block = 256; grid = 256;
     auto kern = rhs_kernel<DfEval<D, true>, D, D, true>;
     if (set_max_lds((const void*)kern, f4 * 16)) return 1;
     hipLaunchKernelGGL(kern, grid, block, f4 * 16, st, pack, M, S, f4, x, N, f, mode);
