@@ -128,3 +128,28 @@ def test_bitwise_reproducible(name, kernel, order):
         if ref_nu is None:
             ref_nu, ref_zt = c.nu.clone(), zt.clone()
         assert torch.equal(c.nu, ref_nu) and torch.equal(zt, ref_zt)
+
+
+@pytest.mark.parametrize('name,kernel,order', [('gp_rbf1_cfg1', 'RBF', 1), ('gp_df1_cfg2', 'DF', 1), ('gp_rbf2_cfg3', 'RBF', 2),
+                                               ('gp_df1_tiny_q4', 'DF', 1), ('gp_rbf1_tiny', 'RBF', 1)])
+def test_wave_and_team_mappings_agree(name, kernel, order):
+    """Batches > 2048 rows take the one-wave-per-trajectory kernels, smaller ones the 4-wave team kernels.
+    Same cache, same rows: the two mappings must agree to summation-order round-off, and a grid-stride
+    pass (more rows than workgroups) must equal the chunked evaluation."""
+    from vae_gp_ode_amd import ops
+    g = load_golden(name)
+    c = build(g, kernel, want_Lu=False)
+    gen = torch.Generator().manual_seed(5)
+    N = 2600
+    x = torch.randn(N, c.Di, generator=gen).cuda()
+    ts = g['ts'].cuda()
+    f_wave = ops.rhs(c, x)                                    # N > 2048 -> wave mapping
+    f_team = torch.cat([ops.rhs(c, x[i:i + 650]) for i in range(0, N, 650)])
+    assert relerr(f_team, f_wave) < 3e-5   # nu reaches |90|: sums of large cancelling terms, order differs
+    z_wave = ops.rollout(c, x, ts, order, 'rk4')
+    z_team = torch.cat([ops.rollout(c, x[i:i + 650], ts, order, 'rk4') for i in range(0, N, 650)])
+    assert relerr(z_team, z_wave) < 3e-4
+    ref = O.gp_forward(x.cpu().double(), O.to_dtype(dict(kernel=kernel, omega=c.omega.cpu(), phase=c.phase.cpu(),
+                       w=g['noise.rff_w'], var=c.var.cpu(), S=c.S,
+                       Z=g['sd.flow.odefunc.diffeq.inducing_loc.optvar'], nu=c.nu.cpu(), ell=c.ell.cpu()), torch.float64))
+    assert relerr(f_wave, ref) < 5e-5

@@ -29,6 +29,7 @@
 // expanded form, kernels.py:64-79, which loses ~1e-6 to cancellation).  fp32 throughout.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "wave_reduce.hpp"
 
 #define GP_WAVE 64
 #define GP_LOG2E 1.4426950408889634f
@@ -145,6 +146,69 @@ __device__ __forceinline__ void df_ind_record(const float4 (&r)[DfLayout<D>::RQ2
       sb = fmaf(f[D + a] * (E * il), term, sb);
     }
     acc[b] = fmaf(var[b], sb, acc[b]);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Half-range variants for the 4-wave team mapping: one wave handles the output dims
+// [half*DH, min(DO,(half+1)*DH)) of one inducing record, DH = ceil(DO/2).  `half` is wave-uniform;
+// every register index below is a compile-time constant (runtime choices are selects), so nothing
+// is demoted to scratch.  Results are merged into acc[] at their global positions.
+// ----------------------------------------------------------------------------------------------
+template <int DI, int DO>
+__device__ __forceinline__ void rbf_ind_record_half(const float4 (&r)[RbfLayout<DI, DO>::RQ2], const float (&x)[DI],
+                                                    const float* __restrict__ wl, int half, float (&acc)[DO]) {
+  constexpr int DH = (DO + 1) / 2;
+  float f[4 * RbfLayout<DI, DO>::RQ2];
+  unpack(r, f);
+  float t2[DI];
+#pragma unroll
+  for (int i = 0; i < DI; ++i) { float d = x[i] - f[i]; t2[i] = d * d; }
+  const float* wlh = wl + half * DH * DI;  // wave-uniform base -> scalar loads
+#pragma unroll
+  for (int dd = 0; dd < DH; ++dd) {
+    float e = 0.f;
+#pragma unroll
+    for (int i = 0; i < DI; ++i) e = fmaf(wlh[dd * DI + i], t2[i], e);
+    const float c_lo = f[DI + dd];
+    const float c_hi = (DH + dd < DO) ? f[DI + (DH + dd < DO ? DH + dd : 0)] : 0.f;
+    const float v = (half ? c_hi : c_lo) * exp2_fast(e);
+    acc[dd] += half ? 0.f : v;
+    if (DH + dd < DO) acc[DH + dd < DO ? DH + dd : 0] += half ? v : 0.f;
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void df_ind_record_half(const float4 (&r)[DfLayout<D>::RQ2], const float (&x)[D],
+                                                   const float* __restrict__ uni, int half, float (&acc)[D]) {
+  constexpr int DH = (D + 1) / 2;
+  float f[4 * DfLayout<D>::RQ2];
+  unpack(r, f);
+  const float* wab = uni;
+  const float* il2 = uni + D * D;
+  const float* var = uni + 2 * D * D;
+  float dl[D];
+  float r2 = 0.f;
+#pragma unroll
+  for (int a = 0; a < D; ++a) { dl[a] = x[a] - f[a]; r2 = fmaf(dl[a], dl[a], r2); }
+  const int b0 = half * DH;  // wave-uniform
+#pragma unroll
+  for (int bb = 0; bb < DH; ++bb) {
+    const bool valid = (DH + bb < D);                     // does the upper half have this column?
+    const int bidx = b0 + bb < D ? b0 + bb : D - 1;       // uniform index for the scalar loads
+    const float dlb = half ? (valid ? dl[DH + bb < D ? DH + bb : 0] : 0.f) : dl[bb];
+    float sb = 0.f;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      const float il = il2[a * D + bidx];
+      const float E = exp2_fast(r2 * wab[a * D + bidx]);
+      float term = dl[a] * dlb * il;
+      term += (a == bidx) ? ((float)(D - 1) - r2 * il) : 0.f;
+      sb = fmaf(f[D + a] * (E * il), term, sb);
+    }
+    const float v = var[bidx] * sb;
+    acc[bb] += half ? 0.f : v;
+    if (valid) acc[DH + bb < D ? DH + bb : 0] += half ? v : 0.f;
   }
 }
 

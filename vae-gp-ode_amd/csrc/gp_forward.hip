@@ -50,8 +50,7 @@ template <int DI, int DO, int SJ, int MJ> struct RbfRegEval {
 #pragma unroll
       for (int j = 0; j < MJ; ++j) rbf_ind_record<DI, DO>(ind[j], x, wl, acc);
     }
-#pragma unroll
-    for (int d = 0; d < DO; ++d) f[d] = wave_allreduce_sum(acc[d]);
+    wave_sum_all<DO>(acc, f);
   }
 };
 
@@ -90,8 +89,7 @@ template <int DI, int DO> struct RbfStreamEval {
         rbf_ind_record<DI, DO>(r, x, wl, acc);
       }
     }
-#pragma unroll
-    for (int d = 0; d < DO; ++d) f[d] = wave_allreduce_sum(acc[d]);
+    wave_sum_all<DO>(acc, f);
   }
 };
 
@@ -136,8 +134,7 @@ template <int D, bool USE_LDS> struct DfEval {
         df_ind_record<D>(r, x, uni, acc);
       }
     }
-#pragma unroll
-    for (int d = 0; d < D; ++d) f[d] = wave_allreduce_sum(acc[d]);
+    wave_sum_all<D>(acc, f);
   }
 };
 
@@ -245,6 +242,206 @@ __global__ __launch_bounds__(256) void rollout_kernel(const float* __restrict__ 
 }
 
 // ----------------------------------------------------------------------------------------------
+// 4-wave TEAM mapping (few trajectories: batch <~ 2048).
+// One 256-thread workgroup = one trajectory at a time.  Wave w owns RFF lane-groups j = w, w+4, ...
+// and the inducing work unit u = w (u = 2 j + half: record j, output-dim half), so its parameter slice
+// is a quarter of the pack (cfg1: 60 floats per lane, cfg2: 108) and lives in VGPRs for the whole
+// launch -- no spills, no LDS/L2 re-reads.  Per evaluation each wave reduces its partial f over its 64
+// lanes (transposing reduction -> wave-uniform), lane 0 drops it in an LDS slot, ONE s_barrier, and all
+// four waves sum the four slots in fixed order (deterministic).  Slots are double-buffered by
+// evaluation parity: a wave can run at most one evaluation ahead of the slowest one.
+// ----------------------------------------------------------------------------------------------
+constexpr int TEAM = 4;
+
+template <int DO> struct TeamCombine {
+  static constexpr int DP = (DO + 3) / 4 * 4;
+  float* slots;  // [2][TEAM][DP] in LDS
+  int wave, lane, parity;
+  __device__ __forceinline__ void init(float* s, int w, int l) { slots = s; wave = w; lane = l; parity = 0; }
+  __device__ __forceinline__ void run(const float (&part)[DO], float (&f)[DO]) {
+    float* mine = slots + (parity * TEAM + wave) * DP;
+    if (lane == 0) {
+#pragma unroll
+      for (int d = 0; d < DO; ++d) mine[d] = part[d];
+    }
+    __syncthreads();
+    const float* base = slots + parity * TEAM * DP;
+#pragma unroll
+    for (int d = 0; d < DO; ++d) {
+      float v = base[d];
+#pragma unroll
+      for (int w = 1; w < TEAM; ++w) v += base[w * DP + d];
+      f[d] = v;
+    }
+    parity ^= 1;
+  }
+};
+
+template <int DI, int DO, int NJ> struct RbfTeamEval {
+  using L = RbfLayout<DI, DO>;
+  float4 rff[NJ * DO][L::RQ];
+  float4 ind[L::RQ2];
+  const float* wl;
+  int half;
+  TeamCombine<DO> comb;
+  static __host__ bool fits(int M, int S) { return cdiv(S, 64) <= TEAM * NJ && cdiv(M, 64) * 2 <= TEAM; }
+  __device__ __forceinline__ void init(const float* pack, int M, int S, float* lds, int wave, int lane) {
+    const float4* p4 = reinterpret_cast<const float4*>(pack);
+    const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int jn = 0; jn < NJ; ++jn) {
+      const int j = wave + TEAM * jn;
+#pragma unroll
+      for (int d = 0; d < DO; ++d)
+#pragma unroll
+        for (int q = 0; q < L::RQ; ++q) rff[jn * DO + d][q] = j < SJ ? p4[((j * DO + d) * L::RQ + q) * 64 + lane] : z;
+    }
+    const float4* i4 = p4 + L::rff_f4(S);
+    const int j = wave >> 1;
+    half = wave & 1;
+#pragma unroll
+    for (int q = 0; q < L::RQ2; ++q) ind[q] = j < MJ ? i4[(j * L::RQ2 + q) * 64 + lane] : z;
+    wl = pack + 4 * (L::rff_f4(S) + L::ind_f4(M));
+    comb.init(lds, wave, lane);
+  }
+  template <int MODE> __device__ __forceinline__ void eval(const float (&x)[DI], float (&f)[DO]) {
+    float acc[DO];
+#pragma unroll
+    for (int d = 0; d < DO; ++d) acc[d] = 0.f;
+    if (MODE != 2) {
+#pragma unroll
+      for (int r = 0; r < NJ * DO; ++r) rbf_rff_record<DI, DO>(rff[r], x, acc[r % DO]);
+    }
+    if (MODE != 1) rbf_ind_record_half<DI, DO>(ind, x, wl, half, acc);
+    float part[DO];
+    wave_sum_all<DO>(acc, part);
+    comb.run(part, f);
+  }
+};
+
+template <int D, int NJ> struct DfTeamEval {
+  using L = DfLayout<D>;
+  float4 rff[NJ * D][L::RQ];
+  float4 ind[L::RQ2];
+  const float* uni;
+  int half;
+  TeamCombine<D> comb;
+  static __host__ bool fits(int M, int S) { return cdiv(S, 64) <= TEAM * NJ && cdiv(M, 64) * 2 <= TEAM; }
+  __device__ __forceinline__ void init(const float* pack, int M, int S, float* lds, int wave, int lane) {
+    const float4* p4 = reinterpret_cast<const float4*>(pack);
+    const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int jn = 0; jn < NJ; ++jn) {
+      const int j = wave + TEAM * jn;
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int q = 0; q < L::RQ; ++q) rff[jn * D + i][q] = j < SJ ? p4[((j * D + i) * L::RQ + q) * 64 + lane] : z;
+    }
+    const float4* i4 = p4 + L::rff_f4(S);
+    const int j = wave >> 1;
+    half = wave & 1;
+#pragma unroll
+    for (int q = 0; q < L::RQ2; ++q) ind[q] = j < MJ ? i4[(j * L::RQ2 + q) * 64 + lane] : z;
+    uni = pack + 4 * (L::rff_f4(S) + L::ind_f4(M));
+    comb.init(lds, wave, lane);
+  }
+  template <int MODE> __device__ __forceinline__ void eval(const float (&x)[D], float (&f)[D]) {
+    float acc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = 0.f;
+    if (MODE != 2) {
+#pragma unroll
+      for (int r = 0; r < NJ * D; ++r) df_rff_record<D>(rff[r], x, acc);
+    }
+    if (MODE != 1) df_ind_record_half<D>(ind, x, uni, half, acc);
+    float part[D];
+    wave_sum_all<D>(acc, part);
+    comb.run(part, f);
+  }
+};
+
+template <class EV, int DI, int DO>
+__global__ __launch_bounds__(256) void rhs_team_kernel(const float* __restrict__ pack, int M, int S,
+                                                        const float* __restrict__ x, int N, float* __restrict__ f, int mode) {
+  __shared__ float slots[2 * TEAM * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  EV ev;
+  ev.init(pack, M, S, slots, wave, lane);
+  for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    float xv[DI], fv[DO];
+#pragma unroll
+    for (int i = 0; i < DI; ++i) xv[i] = x[(size_t)n * DI + i];
+    if (mode == 0) ev.template eval<0>(xv, fv);
+    else if (mode == 1) ev.template eval<1>(xv, fv);
+    else ev.template eval<2>(xv, fv);
+    if (wave == 0 && lane < DO) {
+      float v = fv[0];
+#pragma unroll
+      for (int d = 1; d < DO; ++d) v = (lane == d) ? fv[d] : v;
+      f[(size_t)n * DO + lane] = v;
+    }
+  }
+}
+
+template <class EV, int DI, int DO, int ORDER>
+__device__ __forceinline__ void ode_rhs_mut(EV& ev, const float (&y)[DI], float (&dy)[DI]) {
+  float fv[DO];
+  ev.template eval<0>(y, fv);
+  if (ORDER == 1) {
+#pragma unroll
+    for (int i = 0; i < DO; ++i) dy[i] = fv[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < DO; ++i) { dy[i] = y[DO + i]; dy[DO + i] = fv[i]; }
+  }
+}
+
+template <class EV, int DI, int DO, int ORDER, int METHOD>
+__global__ __launch_bounds__(256) void rollout_team_kernel(const float* __restrict__ pack, int M, int S,
+                                                            const float* __restrict__ z0, const float* __restrict__ ts,
+                                                            int N, int T, float* __restrict__ zt) {
+  static_assert(DI == ORDER * DO, "state dim = order * D_out");
+  __shared__ float slots[2 * TEAM * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  EV ev;
+  ev.init(pack, M, S, slots, wave, lane);
+  const float third = (float)(1.0 / 3.0);
+  for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    float y[DI];
+#pragma unroll
+    for (int i = 0; i < DI; ++i) y[i] = z0[(size_t)n * DI + i];
+    float* out = zt + (size_t)n * T * DI;
+    if (wave == 0) store_state<DI>(out, y, lane);
+    for (int t = 0; t + 1 < T; ++t) {
+      const float dt = ts[t + 1] - ts[t];
+      float k1[DI];
+      ode_rhs_mut<EV, DI, DO, ORDER>(ev, y, k1);
+      if (METHOD == 0) {
+#pragma unroll
+        for (int i = 0; i < DI; ++i) y[i] = y[i] + dt * k1[i];
+      } else {
+        float k2[DI], k3[DI], k4[DI], xs[DI];
+#pragma unroll
+        for (int i = 0; i < DI; ++i) xs[i] = y[i] + dt * k1[i] * third;
+        ode_rhs_mut<EV, DI, DO, ORDER>(ev, xs, k2);
+#pragma unroll
+        for (int i = 0; i < DI; ++i) xs[i] = y[i] + dt * (k2[i] - k1[i] * third);
+        ode_rhs_mut<EV, DI, DO, ORDER>(ev, xs, k3);
+#pragma unroll
+        for (int i = 0; i < DI; ++i) xs[i] = y[i] + dt * (k1[i] - k2[i] + k3[i]);
+        ode_rhs_mut<EV, DI, DO, ORDER>(ev, xs, k4);
+#pragma unroll
+        for (int i = 0; i < DI; ++i) y[i] = y[i] + (k1[i] + 3.f * (k2[i] + k3[i]) + k4[i]) * dt * 0.125f;
+      }
+      if (wave == 0) store_state<DI>(out + (size_t)(t + 1) * DI, y, lane);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
 // host launchers
 // ----------------------------------------------------------------------------------------------
 static const size_t kLdsLimitBytes = 150 * 1024;  // 160 KiB per CU; leave headroom
@@ -261,10 +458,19 @@ static inline void grid_for(int N, int& grid, int& block) {
   if (grid < 1) grid = 1;
 }
 
+static const int kTeamMaxRows = 2048;  // below this, 4 waves per trajectory beat 1 (all 1024 SIMDs busy sooner)
+static inline int team_grid(int N) { return N < 2048 ? N : 2048; }
+
 template <int DI, int DO>
 static int launch_rhs_rbf(const float* pack, int M, int S, const float* x, int N, float* f, int mode, hipStream_t st) {
   int grid, block;
   grid_for(N, grid, block);
+  if (N <= kTeamMaxRows && DO <= 16) {
+    if (RbfTeamEval<DI, DO, 1>::fits(M, S)) {
+      hipLaunchKernelGGL((rhs_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO>), team_grid(N), 256, 0, st, pack, M, S, x, N, f, mode);
+      return check_launch("rhs_rbf_team");
+    }
+  }
   const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
   if constexpr (rbf_reg_fits<DI, DO, 4, 2>()) {
     if (SJ == 4 && MJ == 2) {
@@ -288,6 +494,12 @@ static int launch_rhs_df(const float* pack, int M, int S, const float* x, int N,
   const size_t f4 = L::rff_f4(S) + L::ind_f4(M);
   int grid, block;
   grid_for(N, grid, block);
+  if constexpr (D <= 8) {
+    if (N <= kTeamMaxRows && DfTeamEval<D, 1>::fits(M, S)) {
+      hipLaunchKernelGGL((rhs_team_kernel<DfTeamEval<D, 1>, D, D>), team_grid(N), 256, 0, st, pack, M, S, x, N, f, mode);
+      return check_launch("rhs_df_team");
+    }
+  }
   // one evaluation per row: staging the pack in LDS only pays when a workgroup evaluates many rows
   if (f4 * 16 <= kLdsLimitBytes && N >= 2048) {
     block = 256; grid = 256;
@@ -304,6 +516,12 @@ template <int DI, int DO, int ORDER, int METHOD>
 static int launch_rollout_rbf(const float* pack, int M, int S, const float* z0, const float* ts, int N, int T, float* zt, hipStream_t st) {
   int grid, block;
   grid_for(N, grid, block);
+  if (N <= kTeamMaxRows && DO <= 16) {
+    if (RbfTeamEval<DI, DO, 1>::fits(M, S)) {
+      hipLaunchKernelGGL((rollout_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO, ORDER, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt);
+      return check_launch("rollout_rbf_team");
+    }
+  }
   const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
   if constexpr (rbf_reg_fits<DI, DO, 4, 2>()) {
     if (SJ == 4 && MJ == 2) {
@@ -327,6 +545,12 @@ static int launch_rollout_df(const float* pack, int M, int S, const float* z0, c
   const size_t f4 = L::rff_f4(S) + L::ind_f4(M);
   int grid, block;
   grid_for(N, grid, block);
+  if constexpr (D <= 8) {
+    if (N <= kTeamMaxRows && DfTeamEval<D, 1>::fits(M, S)) {
+      hipLaunchKernelGGL((rollout_team_kernel<DfTeamEval<D, 1>, D, D, 1, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt);
+      return check_launch("rollout_df_team");
+    }
+  }
   if (f4 * 16 <= kLdsLimitBytes) {
     if (N <= 1024) { block = 64; grid = N < 256 ? N : 256; }
     else { block = 256; grid = 256; }
