@@ -231,20 +231,57 @@ __global__ void k_Kzz_df(int D, int M, int np, const float* __restrict__ Z, cons
 // tile R.  Eliminating column j scales it by 1/sqrt(pivot) and subtracts row[j] * L[c][j] from every
 // later column c -- the same instruction stream turns D into L (lower part) and R into R L^-T, so the
 // panel solve costs no extra instructions.  Broadcasts are v_readlane (SGPR), nothing touches LDS.
-__device__ __forceinline__ void chol32_panel_wave(float (&row)[NB], int lane, bool report, int* __restrict__ info) {
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const float piv = GP_BCAST(row[j], j);
-    if (report && !(piv > 0.f) && lane == 0) atomicOr(info, 1);  // not positive definite (reference raises)
+// Broadcast columns C..C+3 of the pivot column and apply the rank-1 update to them.
+// The v_readlane_b32 are pinned (inline asm) right in front of their FMAs: left to itself the scheduler
+// hoists all 31 broadcasts of a pivot to the top, runs out of SGPRs and spills them through v_writelane.
+// gfx950 needs wait states between a VALU SGPR write and a VALU read of that SGPR; hipcc does not see
+// inside asm, so every group pads itself: in a full group the later v_readlane are the padding, short
+// tail groups end in an explicit s_nop.
+template <int J, int C> __device__ __forceinline__ void chol_cols(float (&row)[NB], float nsc) {
+  if constexpr (C < NB) {
+    constexpr int G = (NB - C) < 4 ? (NB - C) : 4;
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+    // every group opens with s_nop 1: its input row[J] (first group) may have been written by the VALU
+    // instruction right before, and a v_readlane of a just-written VGPR needs wait states that hipcc does
+    // not insert in front of an asm statement (without it the broadcast returns the STALE register)
+    if constexpr (G == 4) {
+      asm volatile("s_nop 1\n\tv_readlane_b32 %0, %4, %5\n\tv_readlane_b32 %1, %4, %6\n\tv_readlane_b32 %2, %4, %7\n\tv_readlane_b32 %3, %4, %8"
+                   : "=s"(l0), "=s"(l1), "=s"(l2), "=s"(l3) : "v"(row[J]), "n"(C), "n"(C + 1), "n"(C + 2), "n"(C + 3));
+    } else if constexpr (G == 3) {
+      asm volatile("s_nop 1\n\tv_readlane_b32 %0, %3, %4\n\tv_readlane_b32 %1, %3, %5\n\tv_readlane_b32 %2, %3, %6\n\ts_nop 1"
+                   : "=s"(l0), "=s"(l1), "=s"(l2) : "v"(row[J]), "n"(C), "n"(C + 1), "n"(C + 2));
+    } else if constexpr (G == 2) {
+      asm volatile("s_nop 1\n\tv_readlane_b32 %0, %2, %3\n\tv_readlane_b32 %1, %2, %4\n\ts_nop 2"
+                   : "=s"(l0), "=s"(l1) : "v"(row[J]), "n"(C), "n"(C + 1));
+    } else {
+      asm volatile("s_nop 1\n\tv_readlane_b32 %0, %1, %2\n\ts_nop 3" : "=s"(l0) : "v"(row[J]), "n"(C));
+    }
+    row[C] = fmaf(nsc, l0, row[C]);
+    if constexpr (G > 1) row[C + 1] = fmaf(nsc, l1, row[C + 1]);
+    if constexpr (G > 2) row[C + 2] = fmaf(nsc, l2, row[C + 2]);
+    if constexpr (G > 3) row[C + 3] = fmaf(nsc, l3, row[C + 3]);
+    chol_cols<J, C + 4>(row, nsc);
+  }
+}
+
+template <int J> __device__ __forceinline__ void chol_pivots(float (&row)[NB], int lane, bool& bad) {
+  if constexpr (J < NB) {
+    const float piv = GP_BCAST(row[J], J);
+    bad |= !(piv > 0.f);
     float inv = __builtin_amdgcn_rsqf(piv);
     inv = inv * (1.5f - 0.5f * piv * inv * inv);  // one Newton step: full fp32 accuracy
-    row[j] = (lane == j) ? piv * inv : row[j] * inv;
-#pragma unroll
-    for (int c = j + 1; c < NB; ++c) {
-      const float lcj = GP_BCAST(row[j], c);
-      row[c] = fmaf(-row[j], lcj, row[c]);
-    }
+    const float sc = row[J] * inv;
+    row[J] = (lane == J) ? piv * inv : sc;
+    chol_cols<J, J + 1>(row, -row[J]);
+    chol_pivots<J + 1>(row, lane, bad);
   }
+}
+
+// returns true when a pivot was not positive (matrix not positive definite)
+__device__ __forceinline__ bool chol32_panel_wave(float (&row)[NB], int lane) {
+  bool bad = false;
+  chol_pivots<0>(row, lane, bad);
+  return bad;
 }
 
 __global__ __launch_bounds__(256) void k_chol_rl(float* __restrict__ Aall, float* __restrict__ Lall, int np,
@@ -281,12 +318,13 @@ __global__ __launch_bounds__(256) void k_chol_rl(float* __restrict__ Aall, float
     float row[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) row[c] = panel ? (wv == 0 ? sI[r][c] : sJ[r][c]) : sD[r][c];
-    chol32_panel_wave(row, lane, wv == 0 && t == 0, info);
+    const bool bad = chol32_panel_wave(row, lane);
+    if (bad && wv == 0 && t == 0 && lane == 0) atomicOr(info, 1);  // not positive definite (reference raises)
+    // branch-free write-back: panel halves go to lI / lJ, D halves to lD (both waves hold the same L_kk;
+    // the duplicate store writes identical values)
+    float* dst = panel ? (wv == 0 ? &lI[r][0] : &lJ[r][0]) : &lD[r][0];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) {
-      if (panel) { if (wv == 0) lI[r][c] = row[c]; else lJ[r][c] = row[c]; }
-      else if (wv == 0) lD[r][c] = (c <= r) ? row[c] : 0.f;
-    }
+    for (int c = 0; c < NB; ++c) dst[c] = (panel || c <= r) ? row[c] : 0.f;
   }
   __syncthreads();
   if (j == k) {
@@ -319,18 +357,18 @@ __global__ __launch_bounds__(256) void k_chol_rl(float* __restrict__ Aall, float
 // nu = L^-T (u - y),  y = row n of the factor (forward-solved rhs).  grid = batch, block = 256.
 //   u element j of batch b at u[j * u_stride + b * u_bstride]; nu written dense (batch, n) and, scaled, into
 //   the coefficient fields of the pack's inducing records (RBF: var_d nu[d,m]; DF: nu[(m,a)]).
-// Right-looking block back-substitution.  CPT > 0: every thread owns CPT columns and prefetches the next
-// block row of L into registers while the current 32x32 diagonal system is solved in wave 0 (the global
-// loads do not depend on the solution, so their latency leaves the dependency chain).  CPT == 0: any n,
-// loads issued inside the chain.
-template <int CPT>
+// Right-looking block back-substitution.  CP4 > 0: every thread owns 4*CP4 consecutive columns and keeps
+// the block row of L it needs NEXT in registers: the float4 loads for step k-1 are issued right after
+// step k's update and land while wave 0 solves the next 32x32 diagonal system (v_readlane broadcasts), so
+// global-load latency is off the dependency chain.  CP4 == 0: any n, loads issued inside the chain.
+template <int CP4>
 __global__ __launch_bounds__(256) void k_solve_back(const float* __restrict__ Aall, int n, int np, size_t batch_stride,
                                                      const float* __restrict__ Dfac_all, size_t dfac_stride,
                                                      const float* __restrict__ u, int u_stride, int u_bstride,
                                                      float* __restrict__ nu, float* __restrict__ nu_out,
                                                      int kernel, int Di, int Do, int M, const float* __restrict__ var,
                                                      float* __restrict__ pack_ind) {
-  extern __shared__ float sv[];  // np floats: residual, overwritten by the solution
+  extern __shared__ __attribute__((aligned(16))) float sv[];  // np floats: residual, overwritten by the solution
   __shared__ float sx[NB];
   const int b = blockIdx.x;
   const float* A = Aall + (size_t)b * batch_stride;
@@ -343,19 +381,21 @@ __global__ __launch_bounds__(256) void k_solve_back(const float* __restrict__ Aa
     sv[j] = j < n ? u[(size_t)j * u_stride + (size_t)b * u_bstride] - y : 0.f;
   }
   const int nblk = cdiv(n, NB);
-  constexpr int CP = CPT > 0 ? CPT : 1;
-  float cur[CP][NB], nxt[CP][NB];
-  auto prefetch = [&](float (&dst)[CP][NB], int k) {
-    if (CPT == 0 || k < 0) return;
+  constexpr int CP = CP4 > 0 ? CP4 : 1;
+  float4 cur[CP][NB];
+  auto prefetch = [&](int k) {  // rows of block k, this thread's columns (left of the diagonal block only)
+    if (CP4 == 0 || k < 0) return;
     const int c0 = k * NB;
 #pragma unroll
     for (int q = 0; q < CP; ++q) {
-      const int c = tid + 256 * q;
+      const int c = 4 * (tid + 256 * q);
+      if (c < c0) {
 #pragma unroll
-      for (int r = 0; r < NB; ++r) dst[q][r] = (c < c0) ? A[(size_t)(c0 + r) * np + c] : 0.f;
+        for (int r = 0; r < NB; ++r) cur[q][r] = *reinterpret_cast<const float4*>(A + (size_t)(c0 + r) * np + c);
+      }
     }
   };
-  // lane c of wave 0 holds column c of the current diagonal block L_kk (prefetched one step ahead)
+  // lane c of wave 0 holds column c of the current diagonal block L_kk (fetched one step ahead)
   const int cc = lane & 31;
   float Lc[NB], Lc_nxt[NB];
   auto prefetch_diag = [&](float (&dst)[NB], int k) {
@@ -364,14 +404,13 @@ __global__ __launch_bounds__(256) void k_solve_back(const float* __restrict__ Aa
 #pragma unroll
     for (int r = 0; r < NB; ++r) dst[r] = Lk[r * NB + cc];
   };
-  prefetch(cur, nblk - 1);
+  prefetch(nblk - 1);
   prefetch_diag(Lc, nblk - 1);
   __syncthreads();
   for (int k = nblk - 1; k >= 0; --k) {
     const int c0 = k * NB;
-    prefetch(nxt, k - 1);
-    prefetch_diag(Lc_nxt, k - 1);
     if (tid < 64) {
+      prefetch_diag(Lc_nxt, k - 1);
       // 32x32 transposed solve in wave 0: lane c holds column c of L_kk and residual c
       const int c = cc;
       float res = sv[c0 + c];
@@ -391,21 +430,22 @@ __global__ __launch_bounds__(256) void k_solve_back(const float* __restrict__ Aa
       for (int r = 0; r < NB; ++r) Lc[r] = Lc_nxt[r];
     }
     __syncthreads();
-    if (CPT > 0) {
+    if (CP4 > 0) {
 #pragma unroll
       for (int q = 0; q < CP; ++q) {
-        const int c = tid + 256 * q;
-        if (c < c0) {
-          float acc = sv[c];
+        const int c = 4 * (tid + 256 * q);
+        if (c < c0) {  // c0 is a multiple of 32: the four columns are all left of the diagonal block
+          float4 acc = *reinterpret_cast<float4*>(sv + c);
 #pragma unroll
-          for (int r = 0; r < NB; ++r) acc = fmaf(-cur[q][r], sx[r], acc);
-          sv[c] = acc;
+          for (int r = 0; r < NB; ++r) {
+            const float x = sx[r];
+            acc.x = fmaf(-cur[q][r].x, x, acc.x); acc.y = fmaf(-cur[q][r].y, x, acc.y);
+            acc.z = fmaf(-cur[q][r].z, x, acc.z); acc.w = fmaf(-cur[q][r].w, x, acc.w);
+          }
+          *reinterpret_cast<float4*>(sv + c) = acc;
         }
       }
-#pragma unroll
-      for (int q = 0; q < CP; ++q)
-#pragma unroll
-        for (int r = 0; r < NB; ++r) cur[q][r] = nxt[q][r];
+      prefetch(k - 1);
     } else {
       for (int c = tid; c < c0; c += 256) {
         float acc = sv[c];
@@ -544,7 +584,7 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
   {
     const int u_stride = kernel == 0 ? Do : 1, u_bstride = kernel == 0 ? 1 : 0;
     const size_t lds = sizeof(float) * w.np;
-    const int cpt = cdiv(w.n, 256);
+    const int cpt = cdiv(w.n, 1024);  // 4 columns per thread per unit
 #define GP_SOLVE(CPT)                                                                                              \
   do {                                                                                                             \
     if (set_max_lds((const void*)k_solve_back<CPT>, lds)) return 1;                                                \
@@ -553,8 +593,6 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
   } while (0)
     if (cpt == 1) GP_SOLVE(1);
     else if (cpt == 2) GP_SOLVE(2);
-    else if (cpt == 3) GP_SOLVE(3);
-    else if (cpt == 4) GP_SOLVE(4);
     else GP_SOLVE(0);
 #undef GP_SOLVE
   }
