@@ -61,10 +61,30 @@ int gpode_rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack,
                   const float* x, int N, float* f, int mode, void* stream);
 
 /* Flow.forward (flow.py:68-86) given a built cache: z0 (N,D), ts (T) -> zt (N,T,D),
- * D = Di = order*Do.  One fixed-grid step per output interval. */
+ * D = Di = order*Do.  One fixed-grid step per output interval.
+ * xstage (nullable): (N, T-1, NS, D) receives the input of every RHS evaluation (NS = 1 euler, 4 rk4);
+ * pass it when gradients are needed -- gpode_rollout_bwd walks it backwards. */
 int gpode_rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, int S,
                       const float* pack, const float* z0, const float* ts, int N, int T,
-                      float* zt, void* stream);
+                      float* zt, float* xstage, void* stream);
+
+/* Gradient of a scalar loss through Flow.forward = what loss.backward() computes through the unrolled
+ * solver in the reference (main.py:209-210, use_adjoint=False).
+ *   gzt (N,T,D) = dL/dzt  ->  gz0 (N,D) = dL/dz0  and  astage (N,T-1,NS,Do) = dL/df at every RHS evaluation. */
+int gpode_rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S,
+                      const float* pack, const float* xstage, const float* gzt, const float* ts, int N, int T,
+                      float* gz0, float* astage, void* stream);
+
+/* gx (R,Di) = J_f(x)^T a for rows x (R,Di), a (R,Do): autograd of SVGP_Layer.forward w.r.t. its input. */
+int gpode_rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack,
+                  const float* x, const float* a, int R, float* gx, void* stream);
+
+/* Parameter gradient of sum_r <a_r, f(x_r)> in PACK LAYOUT (same indexing as `pack`: d/d of every record
+ * field and of the uniform tail); rows x (R,Di), a (R,Do).  slab: nchunk * pack_floats floats of scratch.
+ * accumulate != 0 adds into gpack.  Deterministic (fixed-order two-stage sum, no float atomics). */
+int gpode_param_grad(int kernel, int Di, int Do, int M, int S, const float* pack,
+                     const float* x, const float* a, int R, float* slab, int nchunk, float* gpack, int accumulate,
+                     void* stream);
 
 /* Factorisation status of the last gpode_cache_build_fwd on `ws` (bit 0: K_uu + jitter I not positive
  * definite -- torch.linalg.cholesky raises there, kernels.py:163/:384).  Copies one int to the host and

@@ -152,9 +152,11 @@ def df_B_omega(omega):
     return torch.cat((b, b), 0)
 
 
-def df_rff_forward(x, omega, phase, w, var, S):
-    """kernels.py:319-351 -> (N,D); w is (2S,D)."""
-    B = df_B_omega(omega)
+def df_rff_forward(x, omega, phase, w, var, S, B=None):
+    """kernels.py:319-351 -> (N,D); w is (2S,D).  B: optional precomputed df_B_omega(omega) (tests that
+    differentiate w.r.t. B as an independent quantity pass it in)."""
+    if B is None:
+        B = df_B_omega(omega)
     xo = torch.einsum('nd,dfk->nfk', x, omega)
     phi_ = torch.cat((torch.cos(xo + phase), torch.sin(xo + phase)), 1).unsqueeze(-1)
     phi = (phi_ * B.unsqueeze(0)) * torch.sqrt(var / S)
@@ -212,8 +214,9 @@ def build_cache(p, noise, kernel):
 
 
 def gp_prior(x, c):
-    fn = rbf_rff_forward if c['kernel'] == 'RBF' else df_rff_forward
-    return fn(x, c['omega'], c['phase'], c['w'], c['var'], c['S'])
+    if c['kernel'] == 'RBF':
+        return rbf_rff_forward(x, c['omega'], c['phase'], c['w'], c['var'], c['S'])
+    return df_rff_forward(x, c['omega'], c['phase'], c['w'], c['var'], c['S'], c.get('B'))
 
 
 def gp_update(x, c):

@@ -1,0 +1,98 @@
+"""GPU parity (backward): reverse sweep (dL/dz0) and parameter gradients in pack layout, against the
+reference's autograd results (golden) and the oracle's fp64 autograd on the same inputs.
+
+Tolerance: |hip - ref| <= 5e-4 + 3 |ref - fp64 twin| relative to max|ref| (gradients pass through the same
+ill-conditioned nu as the forward; see tests/test_gpu_forward.py)."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from oracle import gpode_oracle as O
+from pack_layout import PackView
+from test_gpu_forward import GP_CASES, build, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_leaf_grads(g, kernel, order, method, dtype=torch.float64):
+    """fp64 autograd of L = sum(zt * gw) w.r.t. z0 and the cache-level quantities treated as leaves."""
+    p = O.to_dtype(O.gp_params_from_state_dict(sub(g, 'sd.')), dtype)
+    c = O.build_cache(p, O.to_dtype(sub(g, 'noise.'), dtype), kernel)
+    leaf = {k: c[k].detach().clone().requires_grad_(True) for k in ('omega', 'var', 'nu', 'Z', 'ell')}
+    cl = dict(c, **leaf)
+    if kernel == 'DF':
+        leaf['B'] = O.df_B_omega(c['omega']).detach().clone().requires_grad_(True)
+        cl['B'] = leaf['B']
+    z0 = g['z0'].to(dtype).clone().requires_grad_(True)
+    zt = O.flow_forward(z0, g['ts'].to(dtype), cl, order, method)
+    (zt * g['gw'].to(dtype)).sum().backward()
+    out = {k: v.grad for k, v in leaf.items()}
+    out['z0'] = z0.grad
+    out['cache'] = c
+    return out
+
+
+@pytest.mark.parametrize('name,kernel,order', GP_CASES)
+@pytest.mark.parametrize('method', ['euler', 'rk4'])
+def test_dz0_matches_reference(name, kernel, order, method):
+    from vae_gp_ode_amd import ops
+    g = load_golden(name)
+    c = build(g, kernel, want_Lu=False)
+    zt, xs = ops.rollout(c, g['z0'].cuda(), g['ts'].cuda(), order, method, save_stages=True)
+    gz0, ast = ops.rollout_bwd(c, xs, g['gw'].cuda(), g['ts'].cuda(), order, method)
+    ref = g['grad_%s.z0' % method]
+    twin = oracle_leaf_grads(g, kernel, order, method)['z0']
+    tol = 5e-4 + 3 * relerr(ref, twin)
+    assert relerr(gz0, ref) < tol, (relerr(gz0, ref), tol)
+
+
+@pytest.mark.parametrize('name,kernel,order', GP_CASES)
+def test_param_grads_in_pack_layout(name, kernel, order):
+    """Kernel B against the oracle's fp64 autograd with the cache quantities as leaves."""
+    from vae_gp_ode_amd import ops
+    g = load_golden(name)
+    method = 'rk4'
+    c = build(g, kernel, want_Lu=False)
+    zt, xs = ops.rollout(c, g['z0'].cuda(), g['ts'].cuda(), order, method, save_stages=True)
+    gz0, ast = ops.rollout_bwd(c, xs, g['gw'].cuda(), g['ts'].cuda(), order, method)
+    gp = ops.param_grad(c, xs.reshape(-1, c.Di), ast.reshape(-1, c.Do), nchunk=37).cpu().double()
+    gp2 = ops.param_grad(c, xs.reshape(-1, c.Di), ast.reshape(-1, c.Do), nchunk=5).cpu().double()
+    pv = PackView(kernel, c.Di, c.Do, c.M, c.S)
+    for view in (pv.rff, pv.ind, pv.uni):  # chunking only changes the summation order (padding lanes are not compared)
+        assert relerr(view(gp2), view(gp)) < 2e-5
+    tw = oracle_leaf_grads(g, kernel, order, method)
+    c64 = tw['cache']
+    rff, ind, uni = pv.rff(gp), pv.ind(gp), pv.uni(gp)
+    Di, Do, S = c.Di, c.Do, c.S
+    var, ell, nu = c64['var'], c64['ell'], c64['nu']
+    tol = 2e-3
+    if kernel == 'RBF':
+        g_omega = rff[:, :, :Di].permute(2, 0, 1) / (2 * math.pi)           # (Di,S,Do)
+        assert relerr(g_omega, tw['omega']) < tol
+        aw = torch.sqrt(var / S) * c64['w']                                  # (S,Do)
+        g_var = (rff[:, :, Di + 1] * aw / (2 * var)).sum(0) + (ind[:, Di:Di + Do] * nu.squeeze(2).T).sum(0)
+        assert relerr(g_var, tw['var']) < tol
+        assert relerr(ind[:, :Di], tw['Z']) < tol
+        assert relerr((ind[:, Di:Di + Do] * var).T.unsqueeze(2), tw['nu']) < tol
+        g_ell = uni.view(Do, Di) * math.log2(math.e) / ell ** 3
+        assert relerr(g_ell, tw['ell']) < tol
+    else:
+        D = Do
+        # rff record (s,i): fields [om_k (D), ph, wc, ws, bs_j (D)]
+        g_omega = rff[:, :, :D].permute(2, 0, 1) / (2 * math.pi)             # [k, s, i]
+        assert relerr(g_omega, tw['omega']) < tol
+        sc = torch.sqrt(var / S)                                             # per column j
+        g_B = rff[:, :, D + 3:2 * D + 3] * sc                                # (S, i, j)
+        ref_B = tw['B'][:S] + tw['B'][S:]                                    # cos and sin halves share B
+        assert relerr(g_B, ref_B) < tol
+        assert relerr(ind[:, :D], tw['Z']) < tol
+        assert relerr(ind[:, D:2 * D].reshape(-1, 1), tw['nu']) < tol
+        wab, il2, gvar = uni[:D * D].view(D, D), uni[D * D:2 * D * D].view(D, D), uni[2 * D * D:]
+        # wab = -log2e/(2 l^2), il2 = 1/l^2
+        g_ell = wab * math.log2(math.e) / ell ** 3 + il2 * (-2.0) / ell ** 3
+        assert relerr(g_ell, tw['ell']) < tol
+        bs = O.df_B_omega(c64['omega'])[:S] * sc
+        g_var = gvar + (rff[:, :, D + 3:2 * D + 3] * bs / (2 * var)).sum((0, 1))
+        assert relerr(g_var, tw['var']) < tol

@@ -26,7 +26,10 @@ SIGNATURES = {
     'gpode_svgp_kl_fwd': (_i, [_i, _i, _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p]),
     'gpode_svgp_kl_bwd': (_i, [_i, _i] + [_c_float_p] * 5 + [ctypes.c_void_p]),
     'gpode_rhs_fwd': (_i, [_i] * 5 + [_c_float_p, _c_float_p, _i, _c_float_p, _i, ctypes.c_void_p]),
-    'gpode_rollout_fwd': (_i, [_i] * 7 + [_c_float_p, _c_float_p, _c_float_p, _i, _i, _c_float_p, ctypes.c_void_p]),
+    'gpode_rollout_fwd': (_i, [_i] * 7 + [_c_float_p, _c_float_p, _c_float_p, _i, _i, _c_float_p, _c_float_p, ctypes.c_void_p]),
+    'gpode_rollout_bwd': (_i, [_i] * 7 + [_c_float_p] * 4 + [_i, _i, _c_float_p, _c_float_p, ctypes.c_void_p]),
+    'gpode_rhs_vjp': (_i, [_i] * 5 + [_c_float_p, _c_float_p, _c_float_p, _i, _c_float_p, ctypes.c_void_p]),
+    'gpode_param_grad': (_i, [_i] * 5 + [_c_float_p, _c_float_p, _c_float_p, _i, _c_float_p, _i, _c_float_p, _i, ctypes.c_void_p]),
 }
 
 _lib = None

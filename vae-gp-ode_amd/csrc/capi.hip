@@ -51,11 +51,33 @@ int gpode_rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack,
 
 int gpode_rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, int S,
                       const float* pack, const float* z0, const float* ts, int N, int T,
-                      float* zt, void* stream) {
+                      float* zt, float* xstage, void* stream) {
   if (!pack || !z0 || !ts || !zt) return gp::set_error("gpode_rollout_fwd: null pointer");
   if (N < 0 || T < 1) return gp::set_error("gpode_rollout_fwd: N=%d T=%d", N, T);
   if (N == 0) return 0;
-  return gp::rollout_fwd(kernel, order, method, Di, Do, M, S, pack, z0, ts, N, T, zt, (hipStream_t)stream);
+  return gp::rollout_fwd(kernel, order, method, Di, Do, M, S, pack, z0, ts, N, T, zt, xstage, (hipStream_t)stream);
+}
+
+int gpode_rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S,
+                      const float* pack, const float* xstage, const float* gzt, const float* ts, int N, int T,
+                      float* gz0, float* astage, void* stream) {
+  if (!pack || !xstage || !gzt || !ts || !gz0 || !astage) return gp::set_error("gpode_rollout_bwd: null pointer");
+  if (N < 0 || T < 1) return gp::set_error("gpode_rollout_bwd: N=%d T=%d", N, T);
+  if (N == 0) return 0;
+  return gp::rollout_bwd(kernel, order, method, Di, Do, M, S, pack, xstage, gzt, ts, N, T, gz0, astage, (hipStream_t)stream);
+}
+
+int gpode_rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack,
+                  const float* x, const float* a, int R, float* gx, void* stream) {
+  if (!pack || !x || !a || !gx) return gp::set_error("gpode_rhs_vjp: null pointer");
+  return gp::rhs_vjp(kernel, Di, Do, M, S, pack, x, a, R, gx, (hipStream_t)stream);
+}
+
+int gpode_param_grad(int kernel, int Di, int Do, int M, int S, const float* pack,
+                     const float* x, const float* a, int R, float* slab, int nchunk, float* gpack, int accumulate,
+                     void* stream) {
+  if (!pack || !x || !a || !slab || !gpack) return gp::set_error("gpode_param_grad: null pointer");
+  return gp::param_grad(kernel, Di, Do, M, S, pack, x, a, R, slab, nchunk, gpack, accumulate, (hipStream_t)stream);
 }
 
 int gpode_kernel_matrix(int kernel, int Di, int Do, const float* raw_ell, const float* raw_var,

@@ -1,0 +1,430 @@
+// gp_backward.hip -- reverse sweep of the fixed-grid rollout and parameter gradients of f.
+//
+// The reference back-propagates through the unrolled solver with autograd (use_adjoint=False,
+// main.py:85,209-210): 4(T-1) RHS graphs per draw.  Here the same discretise-then-optimise gradient is
+// computed by two kernels per draw:
+//
+//  A  rollout_bwd_team_kernel  one workgroup (4 waves) per trajectory walks the steps backwards over the
+//     stage inputs the forward stored (xstage), applying the adjoint of the 3/8-rule (or Euler) stage
+//     algebra; each stage costs one vector-Jacobian product J_f(x)^T a.  Outputs dL/dz0 and the stage
+//     adjoints a (astage).  Sequential in t, parallel over trajectories.
+//  B  param_grad_team_kernel   with (x, a) known for every (trajectory, step, stage) row, the parameter
+//     gradient is a plain sum over rows -- no sequential dependence left.  Each wave keeps its quarter of
+//     the pack AND the matching gradient accumulators in registers and streams a chunk of rows; chunk
+//     results go to a slab that a second kernel sums in fixed order (deterministic, no float atomics).
+//     Gradients come out in PACK LAYOUT (d/d om, d/d aw, d/d z, d/d cc ... + the uniform tail), which
+//     gp_cache_bwd.hip chains back to the raw parameters.
+#include "gp_eval.hpp"
+#include "gp_team.hpp"
+#include "gp_launch.hpp"
+
+namespace gp {
+
+template <int DI> __device__ __forceinline__ void store_vec(float* __restrict__ dst, const float (&y)[DI], int lane) {
+  if (lane < DI) {
+    float v = y[0];
+#pragma unroll
+    for (int i = 1; i < DI; ++i) v = (lane == i) ? y[i] : v;
+    dst[lane] = v;
+  }
+}
+
+// ODE-level VJP (flow.py:27-45): order 1: dy = f(y); order 2: dy = [y[q:], f(y)].
+// a (DI) = adjoint of dy  ->  gx (DI) = (d dy / d y)^T a ;  af (DO) = the part that multiplies J_f.
+template <class EV, int DI, int DO, int ORDER>
+__device__ __forceinline__ void ode_vjp(EV& ev, const float (&x)[DI], const float (&a)[DI], float (&gx)[DI], float (&af)[DO]) {
+  if (ORDER == 1) {
+#pragma unroll
+    for (int i = 0; i < DO; ++i) af[i] = a[i];
+    ev.vjp(x, af, gx);
+  } else {
+#pragma unroll
+    for (int i = 0; i < DO; ++i) af[i] = a[DO + i];
+    ev.vjp(x, af, gx);
+#pragma unroll
+    for (int i = 0; i < DO; ++i) gx[DO + i] += a[i];
+  }
+}
+
+template <class EV, int DI, int DO, int ORDER, int METHOD>
+__global__ __launch_bounds__(256) void rollout_bwd_team_kernel(const float* __restrict__ pack, int M, int S,
+                                                                const float* __restrict__ xstage, const float* __restrict__ gzt,
+                                                                const float* __restrict__ ts, int N, int T,
+                                                                float* __restrict__ gz0, float* __restrict__ astage) {
+  constexpr int NS = METHOD == 0 ? 1 : 4;
+  __shared__ float slots[2 * TEAM * TeamCombine::DP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  EV ev;
+  ev.init(pack, M, S, slots, wave, lane);
+  const float third = (float)(1.0 / 3.0);
+  for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    const float* gz = gzt + (size_t)n * T * DI;
+    const float* xs = xstage + (size_t)n * (T - 1) * NS * DI;
+    float* as = astage + (size_t)n * (T - 1) * NS * DO;
+    float lam[DI];
+#pragma unroll
+    for (int i = 0; i < DI; ++i) lam[i] = gz[(size_t)(T - 1) * DI + i];
+    for (int t = T - 2; t >= 0; --t) {
+      const float dt = ts[t + 1] - ts[t];
+      const float* xt = xs + (size_t)t * NS * DI;
+      float* at = as + (size_t)t * NS * DO;
+      float x[DI], g[DI], af[DO];
+      if (METHOD == 0) {
+        float a1[DI];
+#pragma unroll
+        for (int i = 0; i < DI; ++i) { a1[i] = dt * lam[i]; x[i] = xt[i]; }
+        ode_vjp<EV, DI, DO, ORDER>(ev, x, a1, g, af);
+        if (wave == 0) store_vec<DO>(at, af, lane);
+#pragma unroll
+        for (int i = 0; i < DI; ++i) lam[i] += g[i];
+      } else {
+        // y1 = y + (k1 + 3(k2+k3) + k4) dt/8 ;  x2 = y + dt k1/3 ; x3 = y + dt(k2 - k1/3) ; x4 = y + dt(k1 - k2 + k3)
+        float a1[DI], a2[DI], a3[DI], a4[DI], ay[DI];
+#pragma unroll
+        for (int i = 0; i < DI; ++i) {
+          const float l8 = lam[i] * dt * 0.125f;
+          a1[i] = l8; a4[i] = l8; a2[i] = 3.f * l8; a3[i] = 3.f * l8; ay[i] = lam[i];
+        }
+#pragma unroll
+        for (int i = 0; i < DI; ++i) x[i] = xt[3 * DI + i];
+        ode_vjp<EV, DI, DO, ORDER>(ev, x, a4, g, af);
+        if (wave == 0) store_vec<DO>(at + 3 * DO, af, lane);
+#pragma unroll
+        for (int i = 0; i < DI; ++i) { ay[i] += g[i]; a1[i] += dt * g[i]; a2[i] -= dt * g[i]; a3[i] += dt * g[i]; }
+#pragma unroll
+        for (int i = 0; i < DI; ++i) x[i] = xt[2 * DI + i];
+        ode_vjp<EV, DI, DO, ORDER>(ev, x, a3, g, af);
+        if (wave == 0) store_vec<DO>(at + 2 * DO, af, lane);
+#pragma unroll
+        for (int i = 0; i < DI; ++i) { ay[i] += g[i]; a2[i] += dt * g[i]; a1[i] -= dt * third * g[i]; }
+#pragma unroll
+        for (int i = 0; i < DI; ++i) x[i] = xt[1 * DI + i];
+        ode_vjp<EV, DI, DO, ORDER>(ev, x, a2, g, af);
+        if (wave == 0) store_vec<DO>(at + 1 * DO, af, lane);
+#pragma unroll
+        for (int i = 0; i < DI; ++i) { ay[i] += g[i]; a1[i] += dt * third * g[i]; }
+#pragma unroll
+        for (int i = 0; i < DI; ++i) x[i] = xt[i];
+        ode_vjp<EV, DI, DO, ORDER>(ev, x, a1, g, af);
+        if (wave == 0) store_vec<DO>(at, af, lane);
+#pragma unroll
+        for (int i = 0; i < DI; ++i) lam[i] = ay[i] + g[i];
+      }
+#pragma unroll
+      for (int i = 0; i < DI; ++i) lam[i] += gz[(size_t)t * DI + i];
+    }
+    if (wave == 0) store_vec<DI>(gz0 + (size_t)n * DI, lam, lane);
+  }
+}
+
+// rows (R,DI), adjoints (R,DO) -> gx (R,DI) = J_f(x)^T a   (used for the f_prior(Z) path of the cache backward)
+template <class EV, int DI, int DO>
+__global__ __launch_bounds__(256) void rhs_vjp_team_kernel(const float* __restrict__ pack, int M, int S,
+                                                            const float* __restrict__ x, const float* __restrict__ a, int R,
+                                                            float* __restrict__ gx) {
+  __shared__ float slots[2 * TEAM * TeamCombine::DP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  EV ev;
+  ev.init(pack, M, S, slots, wave, lane);
+  for (int n = blockIdx.x; n < R; n += gridDim.x) {
+    float xv[DI], av[DO], g[DI];
+#pragma unroll
+    for (int i = 0; i < DI; ++i) xv[i] = x[(size_t)n * DI + i];
+#pragma unroll
+    for (int i = 0; i < DO; ++i) av[i] = a[(size_t)n * DO + i];
+    ev.vjp(xv, av, g);
+    if (wave == 0) store_vec<DI>(gx + (size_t)n * DI, g, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// B: parameter gradients in pack layout
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void st4(float* __restrict__ base, size_t f4_index, const float* v) {
+  reinterpret_cast<float4*>(base)[f4_index] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <int DI, int DO, int NJ>
+__global__ __launch_bounds__(256) void param_grad_rbf_kernel(const float* __restrict__ pack, int M, int S,
+                                                              const float* __restrict__ xr, const float* __restrict__ ar,
+                                                              int R, int rows_per_chunk, float* __restrict__ slab,
+                                                              size_t pack_floats) {
+  using EV = RbfTeamEval<DI, DO, NJ>;
+  using L = RbfLayout<DI, DO>;
+  constexpr int DH = (DO + 1) / 2;
+  __shared__ float slots[2 * TEAM * TeamCombine::DP];
+  __shared__ __attribute__((aligned(16))) float sInd[2][64][4 * L::RQ2];
+  __shared__ float sUni[TEAM][DH * DI];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  EV ev;
+  ev.init(pack, M, S, slots, wave, lane);
+  typename EV::Grads G;
+  G.zero();
+  const int r0 = blockIdx.x * rows_per_chunk;
+  const int r1 = min(R, r0 + rows_per_chunk);
+  for (int r = r0; r < r1; ++r) {
+    float x[DI], a[DO];
+#pragma unroll
+    for (int i = 0; i < DI; ++i) x[i] = xr[(size_t)r * DI + i];
+#pragma unroll
+    for (int i = 0; i < DO; ++i) a[i] = ar[(size_t)r * DO + i];
+    ev.grad_row(x, a, G);
+  }
+  float* out = slab + (size_t)blockIdx.x * pack_floats;
+  const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
+#pragma unroll
+  for (int jn = 0; jn < NJ; ++jn) {
+    const int j = wave + TEAM * jn;
+    if (j < SJ) {
+#pragma unroll
+      for (int d = 0; d < DO; ++d)
+#pragma unroll
+        for (int q = 0; q < L::RQ; ++q) st4(out, (size_t)((j * DO + d) * L::RQ + q) * 64 + lane, &G.rff[jn * DO + d][4 * q]);
+    }
+  }
+  // inducing record j = wave>>1: the two halves share the z fields -> add through LDS, lower half stores
+  const int j = wave >> 1, half = wave & 1;
+  if (half == 1) {
+#pragma unroll
+    for (int q = 0; q < 4 * L::RQ2; ++q) sInd[j][lane][q] = G.ind[q];
+  }
+  // uniform tail: lane-reduce this wave's partial of d/d wl[half*DH+dd][i]
+  {
+    float flat[DH * DI], red[DH * DI];
+#pragma unroll
+    for (int e = 0; e < DH * DI; ++e) flat[e] = G.gwl[e / DI][e % DI];
+    wave_sum_all<DH * DI>(flat, red);
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < DH * DI; ++e) sUni[wave][e] = red[e];
+    }
+  }
+  __syncthreads();
+  if (half == 0 && j < MJ) {
+    float* ind_out = out + 4 * L::rff_f4(S);
+    float v[4 * L::RQ2];
+#pragma unroll
+    for (int q = 0; q < 4 * L::RQ2; ++q) v[q] = G.ind[q] + sInd[j][lane][q];
+#pragma unroll
+    for (int q = 0; q < L::RQ2; ++q) st4(ind_out, (size_t)(j * L::RQ2 + q) * 64 + lane, &v[4 * q]);
+  }
+  if (threadIdx.x < DO * DI) {
+    const int d = threadIdx.x / DI, i = threadIdx.x % DI;
+    const int h = d / DH, dd = d % DH;
+    float* uni_out = out + 4 * (L::rff_f4(S) + L::ind_f4(M));
+    uni_out[d * DI + i] = sUni[h][dd * DI + i] + sUni[h + 2][dd * DI + i];
+  }
+}
+
+template <int D, int NJ>
+__global__ __launch_bounds__(256) void param_grad_df_kernel(const float* __restrict__ pack, int M, int S,
+                                                             const float* __restrict__ xr, const float* __restrict__ ar,
+                                                             int R, int rows_per_chunk, float* __restrict__ slab,
+                                                             size_t pack_floats) {
+  using EV = DfTeamEval<D, NJ>;
+  using L = DfLayout<D>;
+  constexpr int DH = (D + 1) / 2;
+  constexpr int NU = 2 * D * DH + DH;  // gwab, gil2, gvar partials of one wave
+  __shared__ float slots[2 * TEAM * TeamCombine::DP];
+  __shared__ __attribute__((aligned(16))) float sInd[2][64][4 * L::RQ2];
+  __shared__ float sUni[TEAM][NU];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  EV ev;
+  ev.init(pack, M, S, slots, wave, lane);
+  typename EV::Grads G;
+  G.zero();
+  const int r0 = blockIdx.x * rows_per_chunk;
+  const int r1 = min(R, r0 + rows_per_chunk);
+  for (int r = r0; r < r1; ++r) {
+    float x[D], a[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { x[i] = xr[(size_t)r * D + i]; a[i] = ar[(size_t)r * D + i]; }
+    ev.grad_row(x, a, G);
+  }
+  float* out = slab + (size_t)blockIdx.x * pack_floats;
+  const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
+#pragma unroll
+  for (int jn = 0; jn < NJ; ++jn) {
+    const int j = wave + TEAM * jn;
+    if (j < SJ) {
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int q = 0; q < L::RQ; ++q) st4(out, (size_t)((j * D + i) * L::RQ + q) * 64 + lane, &G.rff[jn * D + i][4 * q]);
+    }
+  }
+  const int j = wave >> 1, half = wave & 1;
+  if (half == 1) {
+#pragma unroll
+    for (int q = 0; q < 4 * L::RQ2; ++q) sInd[j][lane][q] = G.ind[q];
+  }
+  {
+    // lane-reduce the uniform partials in chunks of <= 8
+    float flat[NU];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b < DH; ++b) { flat[a * DH + b] = G.gwab[a][b]; flat[D * DH + a * DH + b] = G.gil2[a][b]; }
+#pragma unroll
+    for (int b = 0; b < DH; ++b) flat[2 * D * DH + b] = G.gvar[b];
+    float red[NU];
+    wave_sum_all<NU>(flat, red);
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < NU; ++e) sUni[wave][e] = red[e];
+    }
+  }
+  __syncthreads();
+  if (half == 0 && j < MJ) {
+    float* ind_out = out + 4 * L::rff_f4(S);
+    float v[4 * L::RQ2];
+#pragma unroll
+    for (int q = 0; q < 4 * L::RQ2; ++q) v[q] = G.ind[q] + sInd[j][lane][q];
+#pragma unroll
+    for (int q = 0; q < L::RQ2; ++q) st4(ind_out, (size_t)(j * L::RQ2 + q) * 64 + lane, &v[4 * q]);
+  }
+  {
+    float* uni_out = out + 4 * (L::rff_f4(S) + L::ind_f4(M));
+    const int t = threadIdx.x;
+    if (t < D * D) {  // wab and il2: entry (a,b)
+      const int a = t / D, b = t % D, h = b / DH, bb = b % DH;
+      uni_out[a * D + b] = sUni[h][a * DH + bb] + sUni[h + 2][a * DH + bb];
+      uni_out[D * D + a * D + b] = sUni[h][D * DH + a * DH + bb] + sUni[h + 2][D * DH + a * DH + bb];
+    }
+    if (t < D) {
+      const int h = t / DH, bb = t % DH;
+      uni_out[2 * D * D + t] = sUni[h][2 * D * DH + bb] + sUni[h + 2][2 * D * DH + bb];
+    }
+  }
+}
+
+// gpack[e] = sum_c slab[c][e] in fixed order
+__global__ void reduce_slab_kernel(const float* __restrict__ slab, int nchunk, size_t pack_floats, float* __restrict__ gpack,
+                                   int accumulate) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= pack_floats) return;
+  float acc = accumulate ? gpack[e] : 0.f;
+  for (int c = 0; c < nchunk; ++c) acc += slab[(size_t)c * pack_floats + e];
+  gpack[e] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static inline int team_grid_b(int N) { return N < 2048 ? N : 2048; }
+
+template <int DI, int DO, int ORDER, int METHOD>
+static int launch_bwd_rbf(const float* pack, int M, int S, const float* xstage, const float* gzt, const float* ts, int N, int T,
+                          float* gz0, float* astage, hipStream_t st) {
+  if (!RbfTeamEval<DI, DO, 1>::fits(M, S)) return set_error("gpode_rollout_bwd: S=%d M=%d exceed the register-resident team mapping (S<=256, M<=128)", S, M);
+  hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO, ORDER, METHOD>), team_grid_b(N), 256, 0, st,
+                     pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+  return check_launch("rollout_bwd_rbf");
+}
+
+template <int D, int METHOD>
+static int launch_bwd_df(const float* pack, int M, int S, const float* xstage, const float* gzt, const float* ts, int N, int T,
+                         float* gz0, float* astage, hipStream_t st) {
+  if constexpr (D <= 8) {
+    if (!DfTeamEval<D, 1>::fits(M, S)) return set_error("gpode_rollout_bwd: S=%d M=%d exceed the register-resident team mapping", S, M);
+    hipLaunchKernelGGL((rollout_bwd_team_kernel<DfTeamEval<D, 1>, D, D, 1, METHOD>), team_grid_b(N), 256, 0, st,
+                       pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+    return check_launch("rollout_bwd_df");
+  } else {
+    return set_error("gpode_rollout_bwd: DF backward is built for D <= 8");
+  }
+}
+
+#define GP_BWD_RBF_DIMS(X) X(6, 6) X(6, 3) X(4, 4) X(4, 2) X(2, 2) X(2, 1) X(8, 8) X(8, 4) X(3, 3)
+#define GP_BWD_DF_DIMS(X) X(6) X(4) X(2) X(3) X(8)
+
+template <int DI, int DO>
+static int bwd_rbf_dispatch(int order, int method, const float* pack, int M, int S, const float* xstage, const float* gzt,
+                            const float* ts, int N, int T, float* gz0, float* astage, hipStream_t st) {
+  if constexpr (DI == DO) {
+    if (order == 1 && method == 0) return launch_bwd_rbf<DI, DO, 1, 0>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
+    if (order == 1 && method == 1) return launch_bwd_rbf<DI, DO, 1, 1>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
+  }
+  if constexpr (DI == 2 * DO) {
+    if (order == 2 && method == 0) return launch_bwd_rbf<DI, DO, 2, 0>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
+    if (order == 2 && method == 1) return launch_bwd_rbf<DI, DO, 2, 1>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
+  }
+  return set_error("gpode_rollout_bwd: order=%d needs Di == order*Do (Di=%d Do=%d)", order, DI, DO);
+}
+
+int rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S, const float* pack, const float* xstage,
+                const float* gzt, const float* ts, int N, int T, float* gz0, float* astage, hipStream_t st) {
+  if (method != 0 && method != 1) return set_error("gpode_rollout_bwd: method %d", method);
+  if (kernel == 0) {
+#define X(a, b) if (Di == a && Do == b) return bwd_rbf_dispatch<a, b>(order, method, pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
+    GP_BWD_RBF_DIMS(X)
+#undef X
+  } else {
+    if (order != 1) return set_error("gpode_rollout_bwd: DF kernel is first-order only");
+#define X(a) if (Di == a && Do == a) return method == 0 ? launch_bwd_df<a, 0>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st) \
+                                                          : launch_bwd_df<a, 1>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
+    GP_BWD_DF_DIMS(X)
+#undef X
+  }
+  return set_error("gpode_rollout_bwd: no specialisation for kernel=%d Di=%d Do=%d", kernel, Di, Do);
+}
+
+int rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, const float* a, int R, float* gx, hipStream_t st) {
+  if (R <= 0) return 0;
+  if (kernel == 0) {
+#define X(p, q)                                                                                                              \
+  if (Di == p && Do == q) {                                                                                                  \
+    if (!RbfTeamEval<p, q, 1>::fits(M, S)) return set_error("gpode_rhs_vjp: S=%d M=%d too large for the team mapping", S, M); \
+    hipLaunchKernelGGL((rhs_vjp_team_kernel<RbfTeamEval<p, q, 1>, p, q>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx); \
+    return check_launch("rhs_vjp_rbf");                                                                                      \
+  }
+    GP_BWD_RBF_DIMS(X)
+#undef X
+  } else {
+#define X(p)                                                                                                                 \
+  if (Di == p && Do == p) {                                                                                                  \
+    if (!DfTeamEval<p, 1>::fits(M, S)) return set_error("gpode_rhs_vjp: S=%d M=%d too large for the team mapping", S, M);     \
+    hipLaunchKernelGGL((rhs_vjp_team_kernel<DfTeamEval<p, 1>, p, p>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx);   \
+    return check_launch("rhs_vjp_df");                                                                                       \
+  }
+    GP_BWD_DF_DIMS(X)
+#undef X
+  }
+  return set_error("gpode_rhs_vjp: no specialisation for kernel=%d Di=%d Do=%d", kernel, Di, Do);
+}
+
+// rows (R,Di) x adjoints (R,Do) -> gpack (pack layout).  slab: nchunk * pack_floats floats of scratch.
+int param_grad(int kernel, int Di, int Do, int M, int S, const float* pack, const float* xr, const float* ar, int R,
+               float* slab, int nchunk, float* gpack, int accumulate, hipStream_t st) {
+  size_t pf = 0;
+  if (cache_sizes(kernel, Di, Do, M, S, &pf, nullptr)) return 1;
+  if (R <= 0 || nchunk <= 0) return set_error("gpode_param_grad: R=%d nchunk=%d", R, nchunk);
+  const int rpc = cdiv(R, nchunk);
+  const int used = cdiv(R, rpc);
+  if (kernel == 0) {
+#define X(p, q)                                                                                                              \
+  if (Di == p && Do == q) {                                                                                                  \
+    if (!RbfTeamEval<p, q, 1>::fits(M, S)) return set_error("gpode_param_grad: S=%d M=%d too large for the team mapping", S, M); \
+    hipLaunchKernelGGL((param_grad_rbf_kernel<p, q, 1>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf);           \
+    if (check_launch("param_grad_rbf")) return 1;                                                                           \
+    hipLaunchKernelGGL(reduce_slab_kernel, cdiv((int)pf, 256), 256, 0, st, slab, used, pf, gpack, accumulate);              \
+    return check_launch("reduce_slab");                                                                                      \
+  }
+    GP_BWD_RBF_DIMS(X)
+#undef X
+  } else {
+#define X(p)                                                                                                                 \
+  if (Di == p && Do == p) {                                                                                                  \
+    if (!DfTeamEval<p, 1>::fits(M, S)) return set_error("gpode_param_grad: S=%d M=%d too large for the team mapping", S, M);  \
+    hipLaunchKernelGGL((param_grad_df_kernel<p, 1>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf);               \
+    if (check_launch("param_grad_df")) return 1;                                                                            \
+    hipLaunchKernelGGL(reduce_slab_kernel, cdiv((int)pf, 256), 256, 0, st, slab, used, pf, gpack, accumulate);              \
+    return check_launch("reduce_slab");                                                                                      \
+  }
+    GP_BWD_DF_DIMS(X)
+#undef X
+  }
+  return set_error("gpode_param_grad: no specialisation for kernel=%d Di=%d Do=%d", kernel, Di, Do);
+}
+
+}  // namespace gp

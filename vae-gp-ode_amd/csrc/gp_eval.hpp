@@ -212,4 +212,172 @@ __device__ __forceinline__ void df_ind_record_half(const float4 (&r)[DfLayout<D>
   }
 }
 
+// ==============================================================================================
+// Backward building blocks.  `a` is the (wave-uniform) upstream adjoint of f; gx accumulates J^T a;
+// g* accumulate the gradient w.r.t. the fields of the record, in the record's own float layout.
+// d/dt cos(2 pi t) = -2 pi sin(2 pi t): the 2 pi of "revolutions" shows up in every chain rule below.
+// ==============================================================================================
+#define GP_2PI 6.283185307179586f
+#define GP_LN2 0.6931471805599453f
+
+// RBF rff record for output d.  WITH_G: also accumulate g[i] (om_i) and g[DI+1] (aw).
+template <int DI, int DO, bool WITH_G>
+__device__ __forceinline__ void rbf_rff_bwd(const float4 (&r)[RbfLayout<DI, DO>::RQ], const float (&x)[DI], float a_d,
+                                            float (&gx)[DI], float (&g)[4 * RbfLayout<DI, DO>::RQ]) {
+  float f[4 * RbfLayout<DI, DO>::RQ];
+  unpack(r, f);
+  float t = f[DI];
+#pragma unroll
+  for (int i = 0; i < DI; ++i) t = fmaf(x[i], f[i], t);
+  t = __builtin_amdgcn_fractf(t);
+  const float sn = __builtin_amdgcn_sinf(t);
+  const float coef = a_d * f[DI + 1] * (-GP_2PI) * sn;  // a_d * d f_d / d t
+#pragma unroll
+  for (int i = 0; i < DI; ++i) gx[i] = fmaf(coef, f[i], gx[i]);
+  if (WITH_G) {
+    const float c = __builtin_amdgcn_cosf(t);
+#pragma unroll
+    for (int i = 0; i < DI; ++i) g[i] = fmaf(coef, x[i], g[i]);
+    g[DI + 1] = fmaf(a_d, c, g[DI + 1]);
+  }
+}
+
+// RBF inducing record, output dims of one half.  gwl[dd][i]: per-lane partial of d/d wl[half*DH+dd][i].
+template <int DI, int DO, bool WITH_G>
+__device__ __forceinline__ void rbf_ind_half_bwd(const float4 (&r)[RbfLayout<DI, DO>::RQ2], const float (&x)[DI],
+                                                 const float* __restrict__ wl, int half, const float (&a)[DO],
+                                                 float (&gx)[DI], float (&g)[4 * RbfLayout<DI, DO>::RQ2],
+                                                 float (&gwl)[(DO + 1) / 2][DI]) {
+  constexpr int DH = (DO + 1) / 2;
+  float f[4 * RbfLayout<DI, DO>::RQ2];
+  unpack(r, f);
+  float dl[DI], t2[DI];
+#pragma unroll
+  for (int i = 0; i < DI; ++i) { dl[i] = x[i] - f[i]; t2[i] = dl[i] * dl[i]; }
+  const float* wlh = wl + half * DH * DI;
+  float gxi[DI];
+#pragma unroll
+  for (int i = 0; i < DI; ++i) gxi[i] = 0.f;
+#pragma unroll
+  for (int dd = 0; dd < DH; ++dd) {
+    const bool hi_ok = DH + dd < DO;
+    float e = 0.f;
+#pragma unroll
+    for (int i = 0; i < DI; ++i) e = fmaf(wlh[dd * DI + i], t2[i], e);
+    const float E = exp2_fast(e);
+    const float c_lo = f[DI + dd], c_hi = hi_ok ? f[DI + (hi_ok ? DH + dd : 0)] : 0.f;
+    const float a_lo = a[dd], a_hi = hi_ok ? a[hi_ok ? DH + dd : 0] : 0.f;
+    const float cc = half ? c_hi : c_lo, ad = half ? a_hi : a_lo;
+    const float aE = ad * E;           // d L / d cc
+    const float w = aE * cc * GP_LN2;  // d L / d e
+#pragma unroll
+    for (int i = 0; i < DI; ++i) gxi[i] = fmaf(w * wlh[dd * DI + i], 2.f * dl[i], gxi[i]);
+    if (WITH_G) {
+      g[DI + dd] += half ? 0.f : aE;
+      if (hi_ok) g[DI + (hi_ok ? DH + dd : 0)] += half ? aE : 0.f;
+#pragma unroll
+      for (int i = 0; i < DI; ++i) gwl[dd][i] = fmaf(w, t2[i], gwl[dd][i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DI; ++i) {
+    gx[i] += gxi[i];
+    if (WITH_G) g[i] -= gxi[i];  // d/dz = -d/dx
+  }
+}
+
+// DF rff record (s,i).  WITH_G: g[k] (om_k), g[D+3+j] (bs_j).
+template <int D, bool WITH_G>
+__device__ __forceinline__ void df_rff_bwd(const float4 (&r)[DfLayout<D>::RQ], const float (&x)[D], const float (&a)[D],
+                                           float (&gx)[D], float (&g)[4 * DfLayout<D>::RQ]) {
+  float f[4 * DfLayout<D>::RQ];
+  unpack(r, f);
+  float t = f[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) t = fmaf(x[k], f[k], t);
+  t = __builtin_amdgcn_fractf(t);
+  const float c = __builtin_amdgcn_cosf(t), sn = __builtin_amdgcn_sinf(t);
+  float A = 0.f;
+#pragma unroll
+  for (int j = 0; j < D; ++j) A = fmaf(a[j], f[D + 3 + j], A);
+  const float rt = GP_2PI * fmaf(f[D + 2], c, -f[D + 1] * sn);  // d rr / d t
+  const float coef = A * rt;
+#pragma unroll
+  for (int k = 0; k < D; ++k) gx[k] = fmaf(coef, f[k], gx[k]);
+  if (WITH_G) {
+    const float rr = fmaf(f[D + 2], sn, f[D + 1] * c);
+#pragma unroll
+    for (int k = 0; k < D; ++k) g[k] = fmaf(coef, x[k], g[k]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) g[D + 3 + j] = fmaf(a[j], rr, g[D + 3 + j]);
+  }
+}
+
+// DF inducing record, output columns b of one half.  Uniform-parameter partials (per lane):
+//   gwab[a][bb], gil2[a][bb] for b = half*DH + bb, gvar[bb].
+template <int D, bool WITH_G>
+__device__ __forceinline__ void df_ind_half_bwd(const float4 (&r)[DfLayout<D>::RQ2], const float (&x)[D],
+                                                const float* __restrict__ uni, int half, const float (&a)[D],
+                                                float (&gx)[D], float (&g)[4 * DfLayout<D>::RQ2],
+                                                float (&gwab)[D][(D + 1) / 2], float (&gil2)[D][(D + 1) / 2],
+                                                float (&gvar)[(D + 1) / 2]) {
+  constexpr int DH = (D + 1) / 2;
+  float f[4 * DfLayout<D>::RQ2];
+  unpack(r, f);
+  const float* wab = uni;
+  const float* il2 = uni + D * D;
+  const float* var = uni + 2 * D * D;
+  float dl[D];
+  float r2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < D; ++q) { dl[q] = x[q] - f[q]; r2 = fmaf(dl[q], dl[q], r2); }
+  const int b0 = half * DH;
+  float gd[D];      // d L / d delta_c
+  float gr2 = 0.f;  // d L / d r2 (through E and the diagonal term), applied as 2 delta_c at the end
+#pragma unroll
+  for (int q = 0; q < D; ++q) gd[q] = 0.f;
+#pragma unroll
+  for (int bb = 0; bb < DH; ++bb) {
+    const bool hi_ok = DH + bb < D;
+    const int bidx = b0 + bb < D ? b0 + bb : D - 1;  // wave-uniform
+    const bool live = half ? hi_ok : true;
+    const float dlb = half ? (hi_ok ? dl[hi_ok ? DH + bb : 0] : 0.f) : dl[bb];
+    const float ab = live ? (half ? (hi_ok ? a[hi_ok ? DH + bb : 0] : 0.f) : a[bb]) : 0.f;
+    const float vb = var[bidx];
+    float gdb = 0.f;  // d L / d delta_b from the cross term
+    float gv = 0.f;
+#pragma unroll
+    for (int aa = 0; aa < D; ++aa) {
+      const float il = il2[aa * D + bidx], wv = wab[aa * D + bidx];
+      const float E = exp2_fast(r2 * wv);
+      const bool diag = (aa == bidx);
+      const float term = dl[aa] * dlb * il + (diag ? ((float)(D - 1) - r2 * il) : 0.f);
+      const float G = ab * f[D + aa];               // upstream x coefficient nu[(m,aa)]
+      const float GE = G * vb * E * il;             // G * dT/dterm
+      // T = vb * E * il * term
+      gr2 = fmaf(GE, term * (GP_LN2 * wv) - (diag ? il : 0.f), gr2);
+      gd[aa] = fmaf(GE * il, dlb, gd[aa]);
+      gdb = fmaf(GE * il, dl[aa], gdb);
+      if (WITH_G) {
+        g[D + aa] = fmaf(ab, vb * E * il * term, g[D + aa]);                       // d/d nu[(m,aa)]
+        gv = fmaf(G, E * il * term, gv);                                           // d/d var_b
+        gwab[aa][bb] = fmaf(G * vb * il * term, E * GP_LN2 * r2, gwab[aa][bb]);    // d/d wab[aa][b]
+        gil2[aa][bb] = fmaf(G * vb * E, term + il * (dl[aa] * dlb - (diag ? r2 : 0.f)), gil2[aa][bb]);
+      }
+    }
+    if (WITH_G) gvar[bb] += gv;
+    // scatter d/d delta_b to its compile-time slot
+    if (live) {
+      if (half) { if (hi_ok) gd[hi_ok ? DH + bb : 0] += gdb; }
+      else gd[bb] += gdb;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < D; ++q) {
+    const float v = fmaf(2.f * gr2, dl[q], gd[q]);
+    gx[q] += v;
+    if (WITH_G) g[q] -= v;
+  }
+}
+
 }  // namespace gp

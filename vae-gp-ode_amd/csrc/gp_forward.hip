@@ -11,6 +11,7 @@
 //   DF  "lds"    : the pack (cfg2: 98 KB) is staged once per workgroup in LDS, read with ds_read_b128.
 //   DF  "stream" : pack larger than LDS (cfg5): records are re-read from L2.
 #include "gp_eval.hpp"
+#include "gp_team.hpp"
 #include "gp_launch.hpp"
 
 namespace gp {
@@ -201,8 +202,9 @@ template <int DI> __device__ __forceinline__ void store_state(float* __restrict_
 template <class EV, int DI, int DO, int ORDER, int METHOD, bool USE_LDS>
 __global__ __launch_bounds__(256) void rollout_kernel(const float* __restrict__ pack, int M, int S, size_t lds_f4,
                                const float* __restrict__ z0, const float* __restrict__ ts, int N, int T,
-                               float* __restrict__ zt) {
+                               float* __restrict__ zt, float* __restrict__ xstage) {
   static_assert(DI == ORDER * DO, "state dim = order * D_out");
+  constexpr int NS = METHOD == 0 ? 1 : 4;
   if (USE_LDS) stage_pack_lds(pack, lds_f4);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
@@ -214,10 +216,12 @@ __global__ __launch_bounds__(256) void rollout_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < DI; ++i) y[i] = z0[(size_t)n * DI + i];
     float* out = zt + (size_t)n * T * DI;
+    float* xs_out = xstage ? xstage + (size_t)n * (T - 1) * NS * DI : nullptr;
     store_state<DI>(out, y, lane);
     for (int t = 0; t + 1 < T; ++t) {
       const float dt = ts[t + 1] - ts[t];
       float k1[DI];
+      if (xs_out) store_state<DI>(xs_out + (size_t)(t * NS) * DI, y, lane);
       ode_rhs<EV, DI, DO, ORDER>(ev, y, k1);
       if (METHOD == 0) {
 #pragma unroll
@@ -226,12 +230,15 @@ __global__ __launch_bounds__(256) void rollout_kernel(const float* __restrict__ 
         float k2[DI], k3[DI], k4[DI], xs[DI];
 #pragma unroll
         for (int i = 0; i < DI; ++i) xs[i] = y[i] + dt * k1[i] * third;
+        if (xs_out) store_state<DI>(xs_out + (size_t)(t * NS + 1) * DI, xs, lane);
         ode_rhs<EV, DI, DO, ORDER>(ev, xs, k2);
 #pragma unroll
         for (int i = 0; i < DI; ++i) xs[i] = y[i] + dt * (k2[i] - k1[i] * third);
+        if (xs_out) store_state<DI>(xs_out + (size_t)(t * NS + 2) * DI, xs, lane);
         ode_rhs<EV, DI, DO, ORDER>(ev, xs, k3);
 #pragma unroll
         for (int i = 0; i < DI; ++i) xs[i] = y[i] + dt * (k1[i] - k2[i] + k3[i]);
+        if (xs_out) store_state<DI>(xs_out + (size_t)(t * NS + 3) * DI, xs, lane);
         ode_rhs<EV, DI, DO, ORDER>(ev, xs, k4);
 #pragma unroll
         for (int i = 0; i < DI; ++i) y[i] = y[i] + (k1[i] + 3.f * (k2[i] + k3[i]) + k4[i]) * dt * 0.125f;
@@ -241,132 +248,10 @@ __global__ __launch_bounds__(256) void rollout_kernel(const float* __restrict__ 
   }
 }
 
-// ----------------------------------------------------------------------------------------------
-// 4-wave TEAM mapping (few trajectories: batch <~ 2048).
-// One 256-thread workgroup = one trajectory at a time.  Wave w owns RFF lane-groups j = w, w+4, ...
-// and the inducing work unit u = w (u = 2 j + half: record j, output-dim half), so its parameter slice
-// is a quarter of the pack (cfg1: 60 floats per lane, cfg2: 108) and lives in VGPRs for the whole
-// launch -- no spills, no LDS/L2 re-reads.  Per evaluation each wave reduces its partial f over its 64
-// lanes (transposing reduction -> wave-uniform), lane 0 drops it in an LDS slot, ONE s_barrier, and all
-// four waves sum the four slots in fixed order (deterministic).  Slots are double-buffered by
-// evaluation parity: a wave can run at most one evaluation ahead of the slowest one.
-// ----------------------------------------------------------------------------------------------
-constexpr int TEAM = 4;
-
-template <int DO> struct TeamCombine {
-  static constexpr int DP = (DO + 3) / 4 * 4;
-  float* slots;  // [2][TEAM][DP] in LDS
-  int wave, lane, parity;
-  __device__ __forceinline__ void init(float* s, int w, int l) { slots = s; wave = w; lane = l; parity = 0; }
-  __device__ __forceinline__ void run(const float (&part)[DO], float (&f)[DO]) {
-    float* mine = slots + (parity * TEAM + wave) * DP;
-    if (lane == 0) {
-#pragma unroll
-      for (int d = 0; d < DO; ++d) mine[d] = part[d];
-    }
-    __syncthreads();
-    const float* base = slots + parity * TEAM * DP;
-#pragma unroll
-    for (int d = 0; d < DO; ++d) {
-      float v = base[d];
-#pragma unroll
-      for (int w = 1; w < TEAM; ++w) v += base[w * DP + d];
-      f[d] = v;
-    }
-    parity ^= 1;
-  }
-};
-
-template <int DI, int DO, int NJ> struct RbfTeamEval {
-  using L = RbfLayout<DI, DO>;
-  float4 rff[NJ * DO][L::RQ];
-  float4 ind[L::RQ2];
-  const float* wl;
-  int half;
-  TeamCombine<DO> comb;
-  static __host__ bool fits(int M, int S) { return cdiv(S, 64) <= TEAM * NJ && cdiv(M, 64) * 2 <= TEAM; }
-  __device__ __forceinline__ void init(const float* pack, int M, int S, float* lds, int wave, int lane) {
-    const float4* p4 = reinterpret_cast<const float4*>(pack);
-    const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int jn = 0; jn < NJ; ++jn) {
-      const int j = wave + TEAM * jn;
-#pragma unroll
-      for (int d = 0; d < DO; ++d)
-#pragma unroll
-        for (int q = 0; q < L::RQ; ++q) rff[jn * DO + d][q] = j < SJ ? p4[((j * DO + d) * L::RQ + q) * 64 + lane] : z;
-    }
-    const float4* i4 = p4 + L::rff_f4(S);
-    const int j = wave >> 1;
-    half = wave & 1;
-#pragma unroll
-    for (int q = 0; q < L::RQ2; ++q) ind[q] = j < MJ ? i4[(j * L::RQ2 + q) * 64 + lane] : z;
-    wl = pack + 4 * (L::rff_f4(S) + L::ind_f4(M));
-    comb.init(lds, wave, lane);
-  }
-  template <int MODE> __device__ __forceinline__ void eval(const float (&x)[DI], float (&f)[DO]) {
-    float acc[DO];
-#pragma unroll
-    for (int d = 0; d < DO; ++d) acc[d] = 0.f;
-    if (MODE != 2) {
-#pragma unroll
-      for (int r = 0; r < NJ * DO; ++r) rbf_rff_record<DI, DO>(rff[r], x, acc[r % DO]);
-    }
-    if (MODE != 1) rbf_ind_record_half<DI, DO>(ind, x, wl, half, acc);
-    float part[DO];
-    wave_sum_all<DO>(acc, part);
-    comb.run(part, f);
-  }
-};
-
-template <int D, int NJ> struct DfTeamEval {
-  using L = DfLayout<D>;
-  float4 rff[NJ * D][L::RQ];
-  float4 ind[L::RQ2];
-  const float* uni;
-  int half;
-  TeamCombine<D> comb;
-  static __host__ bool fits(int M, int S) { return cdiv(S, 64) <= TEAM * NJ && cdiv(M, 64) * 2 <= TEAM; }
-  __device__ __forceinline__ void init(const float* pack, int M, int S, float* lds, int wave, int lane) {
-    const float4* p4 = reinterpret_cast<const float4*>(pack);
-    const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int jn = 0; jn < NJ; ++jn) {
-      const int j = wave + TEAM * jn;
-#pragma unroll
-      for (int i = 0; i < D; ++i)
-#pragma unroll
-        for (int q = 0; q < L::RQ; ++q) rff[jn * D + i][q] = j < SJ ? p4[((j * D + i) * L::RQ + q) * 64 + lane] : z;
-    }
-    const float4* i4 = p4 + L::rff_f4(S);
-    const int j = wave >> 1;
-    half = wave & 1;
-#pragma unroll
-    for (int q = 0; q < L::RQ2; ++q) ind[q] = j < MJ ? i4[(j * L::RQ2 + q) * 64 + lane] : z;
-    uni = pack + 4 * (L::rff_f4(S) + L::ind_f4(M));
-    comb.init(lds, wave, lane);
-  }
-  template <int MODE> __device__ __forceinline__ void eval(const float (&x)[D], float (&f)[D]) {
-    float acc[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) acc[d] = 0.f;
-    if (MODE != 2) {
-#pragma unroll
-      for (int r = 0; r < NJ * D; ++r) df_rff_record<D>(rff[r], x, acc);
-    }
-    if (MODE != 1) df_ind_record_half<D>(ind, x, uni, half, acc);
-    float part[D];
-    wave_sum_all<D>(acc, part);
-    comb.run(part, f);
-  }
-};
-
 template <class EV, int DI, int DO>
 __global__ __launch_bounds__(256) void rhs_team_kernel(const float* __restrict__ pack, int M, int S,
                                                         const float* __restrict__ x, int N, float* __restrict__ f, int mode) {
-  __shared__ float slots[2 * TEAM * 16];
+  __shared__ float slots[2 * TEAM * TeamCombine::DP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   EV ev;
   ev.init(pack, M, S, slots, wave, lane);
@@ -402,9 +287,10 @@ __device__ __forceinline__ void ode_rhs_mut(EV& ev, const float (&y)[DI], float 
 template <class EV, int DI, int DO, int ORDER, int METHOD>
 __global__ __launch_bounds__(256) void rollout_team_kernel(const float* __restrict__ pack, int M, int S,
                                                             const float* __restrict__ z0, const float* __restrict__ ts,
-                                                            int N, int T, float* __restrict__ zt) {
+                                                            int N, int T, float* __restrict__ zt, float* __restrict__ xstage) {
   static_assert(DI == ORDER * DO, "state dim = order * D_out");
-  __shared__ float slots[2 * TEAM * 16];
+  constexpr int NS = METHOD == 0 ? 1 : 4;
+  __shared__ float slots[2 * TEAM * TeamCombine::DP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   EV ev;
   ev.init(pack, M, S, slots, wave, lane);
@@ -414,10 +300,12 @@ __global__ __launch_bounds__(256) void rollout_team_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < DI; ++i) y[i] = z0[(size_t)n * DI + i];
     float* out = zt + (size_t)n * T * DI;
+    float* xs_out = (xstage && wave == 0) ? xstage + (size_t)n * (T - 1) * NS * DI : nullptr;
     if (wave == 0) store_state<DI>(out, y, lane);
     for (int t = 0; t + 1 < T; ++t) {
       const float dt = ts[t + 1] - ts[t];
       float k1[DI];
+      if (xs_out) store_state<DI>(xs_out + (size_t)(t * NS) * DI, y, lane);
       ode_rhs_mut<EV, DI, DO, ORDER>(ev, y, k1);
       if (METHOD == 0) {
 #pragma unroll
@@ -426,12 +314,15 @@ __global__ __launch_bounds__(256) void rollout_team_kernel(const float* __restri
         float k2[DI], k3[DI], k4[DI], xs[DI];
 #pragma unroll
         for (int i = 0; i < DI; ++i) xs[i] = y[i] + dt * k1[i] * third;
+        if (xs_out) store_state<DI>(xs_out + (size_t)(t * NS + 1) * DI, xs, lane);
         ode_rhs_mut<EV, DI, DO, ORDER>(ev, xs, k2);
 #pragma unroll
         for (int i = 0; i < DI; ++i) xs[i] = y[i] + dt * (k2[i] - k1[i] * third);
+        if (xs_out) store_state<DI>(xs_out + (size_t)(t * NS + 2) * DI, xs, lane);
         ode_rhs_mut<EV, DI, DO, ORDER>(ev, xs, k3);
 #pragma unroll
         for (int i = 0; i < DI; ++i) xs[i] = y[i] + dt * (k1[i] - k2[i] + k3[i]);
+        if (xs_out) store_state<DI>(xs_out + (size_t)(t * NS + 3) * DI, xs, lane);
         ode_rhs_mut<EV, DI, DO, ORDER>(ev, xs, k4);
 #pragma unroll
         for (int i = 0; i < DI; ++i) y[i] = y[i] + (k1[i] + 3.f * (k2[i] + k3[i]) + k4[i]) * dt * 0.125f;
@@ -513,41 +404,41 @@ static int launch_rhs_df(const float* pack, int M, int S, const float* x, int N,
 }
 
 template <int DI, int DO, int ORDER, int METHOD>
-static int launch_rollout_rbf(const float* pack, int M, int S, const float* z0, const float* ts, int N, int T, float* zt, hipStream_t st) {
+static int launch_rollout_rbf(const float* pack, int M, int S, const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st) {
   int grid, block;
   grid_for(N, grid, block);
   if (N <= kTeamMaxRows && DO <= 16) {
     if (RbfTeamEval<DI, DO, 1>::fits(M, S)) {
-      hipLaunchKernelGGL((rollout_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO, ORDER, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt);
+      hipLaunchKernelGGL((rollout_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO, ORDER, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
       return check_launch("rollout_rbf_team");
     }
   }
   const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
   if constexpr (rbf_reg_fits<DI, DO, 4, 2>()) {
     if (SJ == 4 && MJ == 2) {
-      hipLaunchKernelGGL((rollout_kernel<RbfRegEval<DI, DO, 4, 2>, DI, DO, ORDER, METHOD, false>), grid, block, 0, st, pack, M, S, (size_t)0, z0, ts, N, T, zt);
+      hipLaunchKernelGGL((rollout_kernel<RbfRegEval<DI, DO, 4, 2>, DI, DO, ORDER, METHOD, false>), grid, block, 0, st, pack, M, S, (size_t)0, z0, ts, N, T, zt, xstage);
       return check_launch("rollout_rbf");
     }
   }
   if constexpr (rbf_reg_fits<DI, DO, 1, 1>()) {
     if (SJ == 1 && MJ == 1) {
-      hipLaunchKernelGGL((rollout_kernel<RbfRegEval<DI, DO, 1, 1>, DI, DO, ORDER, METHOD, false>), grid, block, 0, st, pack, M, S, (size_t)0, z0, ts, N, T, zt);
+      hipLaunchKernelGGL((rollout_kernel<RbfRegEval<DI, DO, 1, 1>, DI, DO, ORDER, METHOD, false>), grid, block, 0, st, pack, M, S, (size_t)0, z0, ts, N, T, zt, xstage);
       return check_launch("rollout_rbf");
     }
   }
-  hipLaunchKernelGGL((rollout_kernel<RbfStreamEval<DI, DO>, DI, DO, ORDER, METHOD, false>), grid, block, 0, st, pack, M, S, (size_t)0, z0, ts, N, T, zt);
+  hipLaunchKernelGGL((rollout_kernel<RbfStreamEval<DI, DO>, DI, DO, ORDER, METHOD, false>), grid, block, 0, st, pack, M, S, (size_t)0, z0, ts, N, T, zt, xstage);
   return check_launch("rollout_rbf");
 }
 
 template <int D, int METHOD>
-static int launch_rollout_df(const float* pack, int M, int S, const float* z0, const float* ts, int N, int T, float* zt, hipStream_t st) {
+static int launch_rollout_df(const float* pack, int M, int S, const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st) {
   using L = DfLayout<D>;
   const size_t f4 = L::rff_f4(S) + L::ind_f4(M);
   int grid, block;
   grid_for(N, grid, block);
   if constexpr (D <= 8) {
     if (N <= kTeamMaxRows && DfTeamEval<D, 1>::fits(M, S)) {
-      hipLaunchKernelGGL((rollout_team_kernel<DfTeamEval<D, 1>, D, D, 1, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt);
+      hipLaunchKernelGGL((rollout_team_kernel<DfTeamEval<D, 1>, D, D, 1, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
       return check_launch("rollout_df_team");
     }
   }
@@ -556,9 +447,9 @@ static int launch_rollout_df(const float* pack, int M, int S, const float* z0, c
     else { block = 256; grid = 256; }
     auto kern = rollout_kernel<DfEval<D, true>, D, D, 1, METHOD, true>;
     if (set_max_lds((const void*)kern, f4 * 16)) return 1;
-    hipLaunchKernelGGL(kern, grid, block, f4 * 16, st, pack, M, S, f4, z0, ts, N, T, zt);
+    hipLaunchKernelGGL(kern, grid, block, f4 * 16, st, pack, M, S, f4, z0, ts, N, T, zt, xstage);
   } else {
-    hipLaunchKernelGGL((rollout_kernel<DfEval<D, false>, D, D, 1, METHOD, false>), grid, block, 0, st, pack, M, S, (size_t)0, z0, ts, N, T, zt);
+    hipLaunchKernelGGL((rollout_kernel<DfEval<D, false>, D, D, 1, METHOD, false>), grid, block, 0, st, pack, M, S, (size_t)0, z0, ts, N, T, zt, xstage);
   }
   return check_launch("rollout_df");
 }
@@ -581,29 +472,29 @@ int rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack, const f
 }
 
 template <int DI, int DO>
-static int rollout_rbf_dispatch(int order, int method, const float* pack, int M, int S, const float* z0, const float* ts, int N, int T, float* zt, hipStream_t st) {
+static int rollout_rbf_dispatch(int order, int method, const float* pack, int M, int S, const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st) {
   if constexpr (DI == DO) {
-    if (order == 1 && method == 0) return launch_rollout_rbf<DI, DO, 1, 0>(pack, M, S, z0, ts, N, T, zt, st);
-    if (order == 1 && method == 1) return launch_rollout_rbf<DI, DO, 1, 1>(pack, M, S, z0, ts, N, T, zt, st);
+    if (order == 1 && method == 0) return launch_rollout_rbf<DI, DO, 1, 0>(pack, M, S, z0, ts, N, T, zt, xstage, st);
+    if (order == 1 && method == 1) return launch_rollout_rbf<DI, DO, 1, 1>(pack, M, S, z0, ts, N, T, zt, xstage, st);
   }
   if constexpr (DI == 2 * DO) {
-    if (order == 2 && method == 0) return launch_rollout_rbf<DI, DO, 2, 0>(pack, M, S, z0, ts, N, T, zt, st);
-    if (order == 2 && method == 1) return launch_rollout_rbf<DI, DO, 2, 1>(pack, M, S, z0, ts, N, T, zt, st);
+    if (order == 2 && method == 0) return launch_rollout_rbf<DI, DO, 2, 0>(pack, M, S, z0, ts, N, T, zt, xstage, st);
+    if (order == 2 && method == 1) return launch_rollout_rbf<DI, DO, 2, 1>(pack, M, S, z0, ts, N, T, zt, xstage, st);
   }
   return set_error("gpode_rollout_fwd: order=%d needs Di == order*Do (Di=%d Do=%d)", order, DI, DO);
 }
 
 int rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, int S, const float* pack,
-                const float* z0, const float* ts, int N, int T, float* zt, hipStream_t st) {
+                const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st) {
   if (method != 0 && method != 1) return set_error("gpode_rollout_fwd: method %d (0 euler, 1 rk4)", method);
   if (kernel == 0) {
-#define X(a, b) if (Di == a && Do == b) return rollout_rbf_dispatch<a, b>(order, method, pack, M, S, z0, ts, N, T, zt, st);
+#define X(a, b) if (Di == a && Do == b) return rollout_rbf_dispatch<a, b>(order, method, pack, M, S, z0, ts, N, T, zt, xstage, st);
     GP_RBF_DIMS(X)
 #undef X
   } else {
     if (order != 1) return set_error("gpode_rollout_fwd: DF kernel is first-order only (kernels.py:259-262)");
-#define X(a) if (Di == a && Do == a) return method == 0 ? launch_rollout_df<a, 0>(pack, M, S, z0, ts, N, T, zt, st) \
-                                                          : launch_rollout_df<a, 1>(pack, M, S, z0, ts, N, T, zt, st);
+#define X(a) if (Di == a && Do == a) return method == 0 ? launch_rollout_df<a, 0>(pack, M, S, z0, ts, N, T, zt, xstage, st) \
+                                                          : launch_rollout_df<a, 1>(pack, M, S, z0, ts, N, T, zt, xstage, st);
     GP_DF_DIMS(X)
 #undef X
   }

@@ -33,7 +33,12 @@ inline int set_max_lds(const void* kern, size_t bytes) {
 int dims_supported(int kernel, int Di, int Do);
 int rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, int N, float* f, int mode, hipStream_t st);
 int rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, int S, const float* pack,
-                const float* z0, const float* ts, int N, int T, float* zt, hipStream_t st);
+                const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st);
+int rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S, const float* pack, const float* xstage,
+                const float* gzt, const float* ts, int N, int T, float* gz0, float* astage, hipStream_t st);
+int rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, const float* a, int R, float* gx, hipStream_t st);
+int param_grad(int kernel, int Di, int Do, int M, int S, const float* pack, const float* xr, const float* ar, int R,
+               float* slab, int nchunk, float* gpack, int accumulate, hipStream_t st);
 int cache_sizes(int kernel, int Di, int Do, int M, int S, size_t* pack_floats, size_t* ws_floats);
 int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
                     const float* raw_ell, const float* raw_var, const float* Z, const float* Um, const float* Us_packed,

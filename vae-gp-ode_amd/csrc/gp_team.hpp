@@ -1,0 +1,211 @@
+// gp_team.hpp -- 4-wave TEAM evaluators shared by the forward (gp_forward.hip) and backward
+// (gp_backward.hip) kernels: value f(x), vector-Jacobian product J(x)^T a, and per-row parameter
+// gradients, all on the same register-resident quarter of the pack.
+#pragma once
+#include "gp_eval.hpp"
+
+namespace gp {
+
+// ----------------------------------------------------------------------------------------------
+// 4-wave TEAM mapping (few trajectories: batch <~ 2048).
+// One 256-thread workgroup = one trajectory at a time.  Wave w owns RFF lane-groups j = w, w+4, ...
+// and the inducing work unit u = w (u = 2 j + half: record j, output-dim half), so its parameter slice
+// is a quarter of the pack (cfg1: 60 floats per lane, cfg2: 108) and lives in VGPRs for the whole
+// launch -- no spills, no LDS/L2 re-reads.  Per evaluation each wave reduces its partial f over its 64
+// lanes (transposing reduction -> wave-uniform), lane 0 drops it in an LDS slot, ONE s_barrier, and all
+// four waves sum the four slots in fixed order (deterministic).  Slots are double-buffered by
+// evaluation parity: a wave can run at most one evaluation ahead of the slowest one.
+// ----------------------------------------------------------------------------------------------
+constexpr int TEAM = 4;
+
+struct TeamCombine {
+  static constexpr int DP = 16;  // floats per wave slot (D <= 16 for every compiled specialisation)
+  float* slots;                  // [2][TEAM][DP] in LDS
+  int wave, lane, parity;
+  __device__ __forceinline__ void init(float* s, int w, int l) { slots = s; wave = w; lane = l; parity = 0; }
+  template <int NV> __device__ __forceinline__ void run(const float (&part)[NV], float (&f)[NV]) {
+    static_assert(NV <= DP, "slot too small");
+    float* mine = slots + (parity * TEAM + wave) * DP;
+    if (lane == 0) {
+#pragma unroll
+      for (int d = 0; d < NV; ++d) mine[d] = part[d];
+    }
+    __syncthreads();
+    const float* base = slots + parity * TEAM * DP;
+#pragma unroll
+    for (int d = 0; d < NV; ++d) {
+      float v = base[d];
+#pragma unroll
+      for (int w = 1; w < TEAM; ++w) v += base[w * DP + d];
+      f[d] = v;
+    }
+    parity ^= 1;
+  }
+};
+
+template <int DI, int DO, int NJ> struct RbfTeamEval {
+  using L = RbfLayout<DI, DO>;
+  float4 rff[NJ * DO][L::RQ];
+  float4 ind[L::RQ2];
+  const float* wl;
+  int half;
+  TeamCombine comb;
+  static __host__ bool fits(int M, int S) { return cdiv(S, 64) <= TEAM * NJ && cdiv(M, 64) * 2 <= TEAM; }
+  __device__ __forceinline__ void init(const float* pack, int M, int S, float* lds, int wave, int lane) {
+    const float4* p4 = reinterpret_cast<const float4*>(pack);
+    const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int jn = 0; jn < NJ; ++jn) {
+      const int j = wave + TEAM * jn;
+#pragma unroll
+      for (int d = 0; d < DO; ++d)
+#pragma unroll
+        for (int q = 0; q < L::RQ; ++q) rff[jn * DO + d][q] = j < SJ ? p4[((j * DO + d) * L::RQ + q) * 64 + lane] : z;
+    }
+    const float4* i4 = p4 + L::rff_f4(S);
+    const int j = wave >> 1;
+    half = wave & 1;
+#pragma unroll
+    for (int q = 0; q < L::RQ2; ++q) ind[q] = j < MJ ? i4[(j * L::RQ2 + q) * 64 + lane] : z;
+    wl = pack + 4 * (L::rff_f4(S) + L::ind_f4(M));
+    comb.init(lds, wave, lane);
+  }
+  template <int MODE> __device__ __forceinline__ void eval(const float (&x)[DI], float (&f)[DO]) {
+    float acc[DO];
+#pragma unroll
+    for (int d = 0; d < DO; ++d) acc[d] = 0.f;
+    if (MODE != 2) {
+#pragma unroll
+      for (int r = 0; r < NJ * DO; ++r) rbf_rff_record<DI, DO>(rff[r], x, acc[r % DO]);
+    }
+    if (MODE != 1) rbf_ind_record_half<DI, DO>(ind, x, wl, half, acc);
+    float part[DO];
+    wave_sum_all<DO>(acc, part);
+    comb.run<DO>(part, f);
+  }
+  // gx = J_f(x)^T a, combined over the team
+  __device__ __forceinline__ void vjp(const float (&x)[DI], const float (&a)[DO], float (&gx)[DI]) {
+    float acc[DI];
+#pragma unroll
+    for (int i = 0; i < DI; ++i) acc[i] = 0.f;
+    float g0[4 * L::RQ], g1[4 * L::RQ2], g2[(DO + 1) / 2][DI];
+#pragma unroll
+    for (int r = 0; r < NJ * DO; ++r) rbf_rff_bwd<DI, DO, false>(rff[r], x, a[r % DO], acc, g0);
+    rbf_ind_half_bwd<DI, DO, false>(ind, x, wl, half, a, acc, g1, g2);
+    float part[DI];
+    wave_sum_all<DI>(acc, part);
+    comb.run<DI>(part, gx);
+  }
+  // per-row parameter gradients of this wave's slice (no cross-wave traffic)
+  struct Grads {
+    float rff[NJ * DO][4 * L::RQ];
+    float ind[4 * L::RQ2];
+    float gwl[(DO + 1) / 2][DI];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+      for (int r = 0; r < NJ * DO; ++r)
+#pragma unroll
+        for (int q = 0; q < 4 * L::RQ; ++q) rff[r][q] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4 * L::RQ2; ++q) ind[q] = 0.f;
+#pragma unroll
+      for (int d = 0; d < (DO + 1) / 2; ++d)
+#pragma unroll
+        for (int i = 0; i < DI; ++i) gwl[d][i] = 0.f;
+    }
+  };
+  __device__ __forceinline__ void grad_row(const float (&x)[DI], const float (&a)[DO], Grads& G) const {
+    float gx[DI];
+#pragma unroll
+    for (int i = 0; i < DI; ++i) gx[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < NJ * DO; ++r) rbf_rff_bwd<DI, DO, true>(rff[r], x, a[r % DO], gx, G.rff[r]);
+    rbf_ind_half_bwd<DI, DO, true>(ind, x, wl, half, a, gx, G.ind, G.gwl);
+  }
+};
+
+template <int D, int NJ> struct DfTeamEval {
+  using L = DfLayout<D>;
+  float4 rff[NJ * D][L::RQ];
+  float4 ind[L::RQ2];
+  const float* uni;
+  int half;
+  TeamCombine comb;
+  static __host__ bool fits(int M, int S) { return cdiv(S, 64) <= TEAM * NJ && cdiv(M, 64) * 2 <= TEAM; }
+  __device__ __forceinline__ void init(const float* pack, int M, int S, float* lds, int wave, int lane) {
+    const float4* p4 = reinterpret_cast<const float4*>(pack);
+    const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int jn = 0; jn < NJ; ++jn) {
+      const int j = wave + TEAM * jn;
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int q = 0; q < L::RQ; ++q) rff[jn * D + i][q] = j < SJ ? p4[((j * D + i) * L::RQ + q) * 64 + lane] : z;
+    }
+    const float4* i4 = p4 + L::rff_f4(S);
+    const int j = wave >> 1;
+    half = wave & 1;
+#pragma unroll
+    for (int q = 0; q < L::RQ2; ++q) ind[q] = j < MJ ? i4[(j * L::RQ2 + q) * 64 + lane] : z;
+    uni = pack + 4 * (L::rff_f4(S) + L::ind_f4(M));
+    comb.init(lds, wave, lane);
+  }
+  template <int MODE> __device__ __forceinline__ void eval(const float (&x)[D], float (&f)[D]) {
+    float acc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = 0.f;
+    if (MODE != 2) {
+#pragma unroll
+      for (int r = 0; r < NJ * D; ++r) df_rff_record<D>(rff[r], x, acc);
+    }
+    if (MODE != 1) df_ind_record_half<D>(ind, x, uni, half, acc);
+    float part[D];
+    wave_sum_all<D>(acc, part);
+    comb.run<D>(part, f);
+  }
+  __device__ __forceinline__ void vjp(const float (&x)[D], const float (&a)[D], float (&gx)[D]) {
+    float acc[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) acc[i] = 0.f;
+    float g0[4 * L::RQ], g1[4 * L::RQ2], g2[D][(D + 1) / 2], g3[D][(D + 1) / 2], g4[(D + 1) / 2];
+#pragma unroll
+    for (int r = 0; r < NJ * D; ++r) df_rff_bwd<D, false>(rff[r], x, a, acc, g0);
+    df_ind_half_bwd<D, false>(ind, x, uni, half, a, acc, g1, g2, g3, g4);
+    float part[D];
+    wave_sum_all<D>(acc, part);
+    comb.run<D>(part, gx);
+  }
+  struct Grads {
+    float rff[NJ * D][4 * L::RQ];
+    float ind[4 * L::RQ2];
+    float gwab[D][(D + 1) / 2], gil2[D][(D + 1) / 2], gvar[(D + 1) / 2];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+      for (int r = 0; r < NJ * D; ++r)
+#pragma unroll
+        for (int q = 0; q < 4 * L::RQ; ++q) rff[r][q] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4 * L::RQ2; ++q) ind[q] = 0.f;
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < (D + 1) / 2; ++b) { gwab[a][b] = 0.f; gil2[a][b] = 0.f; }
+#pragma unroll
+      for (int b = 0; b < (D + 1) / 2; ++b) gvar[b] = 0.f;
+    }
+  };
+  __device__ __forceinline__ void grad_row(const float (&x)[D], const float (&a)[D], Grads& G) const {
+    float gx[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) gx[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < NJ * D; ++r) df_rff_bwd<D, true>(rff[r], x, a, gx, G.rff[r]);
+    df_ind_half_bwd<D, true>(ind, x, uni, half, a, gx, G.ind, G.gwab, G.gil2, G.gvar);
+  }
+};
+
+
+}  // namespace gp

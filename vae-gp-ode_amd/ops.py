@@ -97,8 +97,12 @@ def rhs(cache, x, mode=0):
     return f
 
 
-def rollout(cache, z0, ts, order, method):
-    """Flow.forward (flow.py:68-86) for a built cache: z0 (N,D), ts (T,) -> zt (N,T,D)."""
+NSTAGE = {'euler': 1, 'rk4': 4}
+
+
+def rollout(cache, z0, ts, order, method, save_stages=False):
+    """Flow.forward (flow.py:68-86) for a built cache: z0 (N,D), ts (T,) -> zt (N,T,D).
+    save_stages=True also returns the inputs of all RHS evaluations (N,T-1,NS,D) for the reverse sweep."""
     if method not in METHOD_ID:
         raise _lib.GpodeError("solver '%s' is not a fixed-grid method of this build (euler, rk4)" % method)
     z0 = _chk(z0, 'z0'); ts = _chk(ts, 'ts')
@@ -107,9 +111,45 @@ def rollout(cache, z0, ts, order, method):
         raise _lib.GpodeError('state dim %d must equal D_in=%d = order*D_out=%d' % (D, cache.Di, order * cache.Do))
     T = ts.shape[0]
     zt = torch.empty((N, T, D), dtype=torch.float32, device=z0.device)
+    xs = torch.empty((N, max(T - 1, 0), NSTAGE[method], D), dtype=torch.float32, device=z0.device) if save_stages else None
     _lib.call('gpode_rollout_fwd', KERNEL_ID[cache.kernel], order, METHOD_ID[method], cache.Di, cache.Do, cache.M,
-              cache.S, _ptr(cache.pack), _ptr(z0), _ptr(ts), N, T, _ptr(zt), _stream())
-    return zt
+              cache.S, _ptr(cache.pack), _ptr(z0), _ptr(ts), N, T, _ptr(zt), _ptr(xs), _stream())
+    return (zt, xs) if save_stages else zt
+
+
+def rollout_bwd(cache, xstage, gzt, ts, order, method):
+    """Reverse sweep: gzt (N,T,D) -> gz0 (N,D), astage (N,T-1,NS,Do)."""
+    gzt = _chk(gzt, 'gzt'); xstage = _chk(xstage, 'xstage'); ts = _chk(ts, 'ts')
+    N, T, D = gzt.shape
+    gz0 = torch.empty((N, D), dtype=torch.float32, device=gzt.device)
+    ast = torch.empty((N, T - 1, NSTAGE[method], cache.Do), dtype=torch.float32, device=gzt.device)
+    _lib.call('gpode_rollout_bwd', KERNEL_ID[cache.kernel], order, METHOD_ID[method], cache.Di, cache.Do, cache.M,
+              cache.S, _ptr(cache.pack), _ptr(xstage), _ptr(gzt), _ptr(ts), N, T, _ptr(gz0), _ptr(ast), _stream())
+    return gz0, ast
+
+
+def rhs_vjp(cache, x, a):
+    """gx = J_f(x)^T a for rows x (R,Di), a (R,Do)."""
+    x = _chk(x, 'x'); a = _chk(a, 'a')
+    gx = torch.empty_like(x)
+    _lib.call('gpode_rhs_vjp', KERNEL_ID[cache.kernel], cache.Di, cache.Do, cache.M, cache.S, _ptr(cache.pack),
+              _ptr(x), _ptr(a), x.shape[0], _ptr(gx), _stream())
+    return gx
+
+
+def param_grad(cache, x, a, gpack=None, nchunk=256):
+    """Gradient of sum_r <a_r, f(x_r)> w.r.t. every field of the pack, in pack layout."""
+    x = _chk(x, 'x'); a = _chk(a, 'a')
+    R = x.shape[0]
+    nchunk = max(1, min(nchunk, R))
+    pf = cache.pack.numel()
+    slab = torch.empty(nchunk * pf, dtype=torch.float32, device=x.device)
+    acc = 1 if gpack is not None else 0
+    if gpack is None:
+        gpack = torch.zeros(pf, dtype=torch.float32, device=x.device)
+    _lib.call('gpode_param_grad', KERNEL_ID[cache.kernel], cache.Di, cache.Do, cache.M, cache.S, _ptr(cache.pack),
+              _ptr(x), _ptr(a), R, _ptr(slab), nchunk, _ptr(gpack), acc, _stream())
+    return gpack
 
 
 def kernel_matrix(kernel, raw_ell, raw_var, X, X2=None):
