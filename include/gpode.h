@@ -86,6 +86,17 @@ int gpode_param_grad(int kernel, int Di, int Do, int M, int S, const float* pack
                      const float* x, const float* a, int R, float* slab, int nchunk, float* gpack, int accumulate,
                      void* stream);
 
+/* Backward of gpode_cache_build_fwd: what autograd does behind SVGP_Layer.build_cache in the reference
+ * (nu = L^-T(u - L^-1 f_prior(Z)), cholesky, K(Z), omega = eps/ell, softplus ...).
+ *   gpack : in/out, pack-layout gradient from gpode_param_grad (the f_prior(Z) path is added to it);
+ *   ws    : the workspace the forward of THIS draw wrote;  bws: gpode_cache_bwd_sizes() floats of scratch;
+ *   outputs: gradients w.r.t. the five raw parameter tensors, in their state_dict layouts. */
+int gpode_cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, size_t* bws_floats);
+int gpode_cache_build_bwd(int kernel, int Di, int Do, int M, int S,
+                          const float* raw_ell, const float* raw_var, const float* Z, const float* eps_u,
+                          const float* pack, const float* ws, float* gpack, float* bws,
+                          float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, void* stream);
+
 /* Factorisation status of the last gpode_cache_build_fwd on `ws` (bit 0: K_uu + jitter I not positive
  * definite -- torch.linalg.cholesky raises there, kernels.py:163/:384).  Copies one int to the host and
  * synchronises `stream`. */

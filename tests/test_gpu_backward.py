@@ -96,3 +96,47 @@ def test_param_grads_in_pack_layout(name, kernel, order):
         bs = O.df_B_omega(c64['omega'])[:S] * sc
         g_var = gvar + (rff[:, :, D + 3:2 * D + 3] * bs / (2 * var)).sum((0, 1))
         assert relerr(g_var, tw['var']) < tol
+
+
+def make_layer(g, kernel, order, method):
+    """The mirror API on the GPU, loaded with the fixture's state_dict and primed with its noise."""
+    from vae_gp_ode_amd.model.core.flow import Flow
+    from vae_gp_ode_amd.model.core.svpy import SVGP_Layer
+    sd = sub(g, 'sd.flow.odefunc.diffeq.')
+    Do, Di = sd['kern.unconstrained_lengthscales'].shape
+    M = sd['inducing_loc.optvar'].shape[0]
+    S = g['noise.rff_eps'].shape[1]
+    gp = SVGP_Layer(Di, Do, M, S, kernel=kernel).cuda()
+    gp.load_state_dict(sd)
+    flow = Flow(gp, order=order, solver=method).cuda()
+    gp.set_noise({k: v.cuda() for k, v in sub(g, 'noise.').items()})
+    return flow, gp
+
+
+@pytest.mark.parametrize('name,kernel,order', GP_CASES)
+@pytest.mark.parametrize('method', ['euler', 'rk4'])
+def test_flow_autograd_matches_reference(name, kernel, order, method):
+    """loss.backward() through the mirror's Flow.forward: every GP parameter gradient against the
+    reference's autograd (golden) with the fp64-calibrated tolerance."""
+    g = load_golden(name)
+    flow, gp = make_layer(g, kernel, order, method)
+    z0 = g['z0'].cuda().requires_grad_(True)
+    zt = flow(z0, g['ts'].cuda())
+    (zt * g['gw'].cuda()).sum().backward()
+    # fp64 twin of the full gradient
+    p64 = {k: v.double().clone().requires_grad_(True) for k, v in O.gp_params_from_state_dict(sub(g, 'sd.')).items()}
+    c64 = O.build_cache(p64, O.to_dtype(sub(g, 'noise.'), torch.float64), kernel)
+    z64 = g['z0'].double().clone().requires_grad_(True)
+    (O.flow_forward(z64, g['ts'].double(), c64, order, method) * g['gw'].double()).sum().backward()
+    gr = sub(g, 'grad_%s.' % method)
+    got = {'raw_ell': gp.kern.unconstrained_lengthscales.grad, 'raw_var': gp.kern.unconstrained_variance.grad,
+           'Z': gp.inducing_loc.optvar.grad, 'Um': gp.Um.optvar.grad, 'Us': gp.Us_sqrt.optvar.grad}
+    worst = {}
+    for short, key in O.GP_KEYS.items():
+        ref = gr[key[len('flow.'):]]
+        tol = 1e-3 + 3 * relerr(ref, p64[short].grad)
+        err = relerr(got[short], ref)
+        worst[short] = (err, tol)
+        assert err < tol, (short, err, tol)
+    assert relerr(z0.grad, gr['z0']) < 5e-4 + 3 * relerr(gr['z0'], z64.grad)
+    print(name, method, {k: '%.1e/%.1e' % v for k, v in worst.items()})

@@ -70,14 +70,14 @@ int gpode_rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, 
 int gpode_rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack,
                   const float* x, const float* a, int R, float* gx, void* stream) {
   if (!pack || !x || !a || !gx) return gp::set_error("gpode_rhs_vjp: null pointer");
-  return gp::rhs_vjp(kernel, Di, Do, M, S, pack, x, a, R, gx, (hipStream_t)stream);
+  return gp::rhs_vjp(kernel, Di, Do, M, S, pack, x, a, R, gx, 0, (hipStream_t)stream);
 }
 
 int gpode_param_grad(int kernel, int Di, int Do, int M, int S, const float* pack,
                      const float* x, const float* a, int R, float* slab, int nchunk, float* gpack, int accumulate,
                      void* stream) {
   if (!pack || !x || !a || !slab || !gpack) return gp::set_error("gpode_param_grad: null pointer");
-  return gp::param_grad(kernel, Di, Do, M, S, pack, x, a, R, slab, nchunk, gpack, accumulate, (hipStream_t)stream);
+  return gp::param_grad(kernel, Di, Do, M, S, pack, x, a, R, slab, nchunk, gpack, accumulate, 0, (hipStream_t)stream);
 }
 
 int gpode_kernel_matrix(int kernel, int Di, int Do, const float* raw_ell, const float* raw_var,
@@ -95,6 +95,21 @@ int gpode_svgp_kl_bwd(int M, int Do, const float* Um, const float* Us_packed, co
                       float* dUm, float* dUs, void* stream) {
   if (!Um || !Us_packed || !g || !dUm || !dUs) return gp::set_error("gpode_svgp_kl_bwd: null pointer");
   return gp::svgp_kl_bwd(M, Do, Um, Us_packed, g, dUm, dUs, (hipStream_t)stream);
+}
+
+int gpode_cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, size_t* bws_floats) {
+  if (!bws_floats) return gp::set_error("gpode_cache_bwd_sizes: null pointer");
+  return gp::cache_bwd_sizes(kernel, Di, Do, M, S, bws_floats);
+}
+
+int gpode_cache_build_bwd(int kernel, int Di, int Do, int M, int S,
+                          const float* raw_ell, const float* raw_var, const float* Z, const float* eps_u,
+                          const float* pack, const float* ws, float* gpack, float* bws,
+                          float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, void* stream) {
+  if (!raw_ell || !raw_var || !Z || !eps_u || !pack || !ws || !gpack || !bws || !g_raw_ell || !g_raw_var || !g_Z || !g_Um || !g_Us)
+    return gp::set_error("gpode_cache_build_bwd: null pointer");
+  return gp::cache_build_bwd(kernel, Di, Do, M, S, raw_ell, raw_var, Z, eps_u, pack, ws, gpack, bws,
+                             g_raw_ell, g_raw_var, g_Z, g_Um, g_Us, (hipStream_t)stream);
 }
 
 }  // extern "C"

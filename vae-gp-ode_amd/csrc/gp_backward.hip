@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void rollout_bwd_team_kernel(const float* __re
 template <class EV, int DI, int DO>
 __global__ __launch_bounds__(256) void rhs_vjp_team_kernel(const float* __restrict__ pack, int M, int S,
                                                             const float* __restrict__ x, const float* __restrict__ a, int R,
-                                                            float* __restrict__ gx) {
+                                                            float* __restrict__ gx, int prior_only) {
   __shared__ float slots[2 * TEAM * TeamCombine::DP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   EV ev;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void rhs_vjp_team_kernel(const float* __restri
     for (int i = 0; i < DI; ++i) xv[i] = x[(size_t)n * DI + i];
 #pragma unroll
     for (int i = 0; i < DO; ++i) av[i] = a[(size_t)n * DO + i];
-    ev.vjp(xv, av, g);
+    ev.vjp(xv, av, g, prior_only != 0);
     if (wave == 0) store_vec<DI>(gx + (size_t)n * DI, g, lane);
   }
 }
@@ -148,7 +148,7 @@ template <int DI, int DO, int NJ>
 __global__ __launch_bounds__(256) void param_grad_rbf_kernel(const float* __restrict__ pack, int M, int S,
                                                               const float* __restrict__ xr, const float* __restrict__ ar,
                                                               int R, int rows_per_chunk, float* __restrict__ slab,
-                                                              size_t pack_floats) {
+                                                              size_t pack_floats, int prior_only) {
   using EV = RbfTeamEval<DI, DO, NJ>;
   using L = RbfLayout<DI, DO>;
   constexpr int DH = (DO + 1) / 2;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void param_grad_rbf_kernel(const float* __rest
     for (int i = 0; i < DI; ++i) x[i] = xr[(size_t)r * DI + i];
 #pragma unroll
     for (int i = 0; i < DO; ++i) a[i] = ar[(size_t)r * DO + i];
-    ev.grad_row(x, a, G);
+    ev.grad_row(x, a, G, prior_only != 0);
   }
   float* out = slab + (size_t)blockIdx.x * pack_floats;
   const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
@@ -220,7 +220,7 @@ template <int D, int NJ>
 __global__ __launch_bounds__(256) void param_grad_df_kernel(const float* __restrict__ pack, int M, int S,
                                                              const float* __restrict__ xr, const float* __restrict__ ar,
                                                              int R, int rows_per_chunk, float* __restrict__ slab,
-                                                             size_t pack_floats) {
+                                                             size_t pack_floats, int prior_only) {
   using EV = DfTeamEval<D, NJ>;
   using L = DfLayout<D>;
   constexpr int DH = (D + 1) / 2;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void param_grad_df_kernel(const float* __restr
     float x[D], a[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) { x[i] = xr[(size_t)r * D + i]; a[i] = ar[(size_t)r * D + i]; }
-    ev.grad_row(x, a, G);
+    ev.grad_row(x, a, G, prior_only != 0);
   }
   float* out = slab + (size_t)blockIdx.x * pack_floats;
   const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
@@ -369,13 +369,14 @@ int rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S,
   return set_error("gpode_rollout_bwd: no specialisation for kernel=%d Di=%d Do=%d", kernel, Di, Do);
 }
 
-int rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, const float* a, int R, float* gx, hipStream_t st) {
+int rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, const float* a, int R, float* gx,
+            int prior_only, hipStream_t st) {
   if (R <= 0) return 0;
   if (kernel == 0) {
 #define X(p, q)                                                                                                              \
   if (Di == p && Do == q) {                                                                                                  \
     if (!RbfTeamEval<p, q, 1>::fits(M, S)) return set_error("gpode_rhs_vjp: S=%d M=%d too large for the team mapping", S, M); \
-    hipLaunchKernelGGL((rhs_vjp_team_kernel<RbfTeamEval<p, q, 1>, p, q>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx); \
+    hipLaunchKernelGGL((rhs_vjp_team_kernel<RbfTeamEval<p, q, 1>, p, q>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only); \
     return check_launch("rhs_vjp_rbf");                                                                                      \
   }
     GP_BWD_RBF_DIMS(X)
@@ -384,7 +385,7 @@ int rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack, const f
 #define X(p)                                                                                                                 \
   if (Di == p && Do == p) {                                                                                                  \
     if (!DfTeamEval<p, 1>::fits(M, S)) return set_error("gpode_rhs_vjp: S=%d M=%d too large for the team mapping", S, M);     \
-    hipLaunchKernelGGL((rhs_vjp_team_kernel<DfTeamEval<p, 1>, p, p>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx);   \
+    hipLaunchKernelGGL((rhs_vjp_team_kernel<DfTeamEval<p, 1>, p, p>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);   \
     return check_launch("rhs_vjp_df");                                                                                       \
   }
     GP_BWD_DF_DIMS(X)
@@ -395,7 +396,7 @@ int rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack, const f
 
 // rows (R,Di) x adjoints (R,Do) -> gpack (pack layout).  slab: nchunk * pack_floats floats of scratch.
 int param_grad(int kernel, int Di, int Do, int M, int S, const float* pack, const float* xr, const float* ar, int R,
-               float* slab, int nchunk, float* gpack, int accumulate, hipStream_t st) {
+               float* slab, int nchunk, float* gpack, int accumulate, int prior_only, hipStream_t st) {
   size_t pf = 0;
   if (cache_sizes(kernel, Di, Do, M, S, &pf, nullptr)) return 1;
   if (R <= 0 || nchunk <= 0) return set_error("gpode_param_grad: R=%d nchunk=%d", R, nchunk);
@@ -405,7 +406,7 @@ int param_grad(int kernel, int Di, int Do, int M, int S, const float* pack, cons
 #define X(p, q)                                                                                                              \
   if (Di == p && Do == q) {                                                                                                  \
     if (!RbfTeamEval<p, q, 1>::fits(M, S)) return set_error("gpode_param_grad: S=%d M=%d too large for the team mapping", S, M); \
-    hipLaunchKernelGGL((param_grad_rbf_kernel<p, q, 1>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf);           \
+    hipLaunchKernelGGL((param_grad_rbf_kernel<p, q, 1>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only); \
     if (check_launch("param_grad_rbf")) return 1;                                                                           \
     hipLaunchKernelGGL(reduce_slab_kernel, cdiv((int)pf, 256), 256, 0, st, slab, used, pf, gpack, accumulate);              \
     return check_launch("reduce_slab");                                                                                      \
@@ -416,7 +417,7 @@ int param_grad(int kernel, int Di, int Do, int M, int S, const float* pack, cons
 #define X(p)                                                                                                                 \
   if (Di == p && Do == p) {                                                                                                  \
     if (!DfTeamEval<p, 1>::fits(M, S)) return set_error("gpode_param_grad: S=%d M=%d too large for the team mapping", S, M);  \
-    hipLaunchKernelGGL((param_grad_df_kernel<p, 1>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf);               \
+    hipLaunchKernelGGL((param_grad_df_kernel<p, 1>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only);   \
     if (check_launch("param_grad_df")) return 1;                                                                            \
     hipLaunchKernelGGL(reduce_slab_kernel, cdiv((int)pf, 256), 256, 0, st, slab, used, pf, gpack, accumulate);              \
     return check_launch("reduce_slab");                                                                                      \

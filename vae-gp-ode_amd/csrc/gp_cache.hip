@@ -17,10 +17,10 @@
 // panel solves for free (row n of the factor); only the transposed solve runs as its own kernel.
 #include "gp_eval.hpp"
 #include "gp_launch.hpp"
+#include "gp_ws.hpp"
 
 namespace gp {
 
-static constexpr int NB = 32;
 static constexpr float kJitter = 1e-5f;  // kernels.py:11
 
 __device__ __forceinline__ float softplus_lower(float x) {
@@ -485,35 +485,6 @@ __global__ void k_copy_L(const float* __restrict__ Aall, const float* __restrict
   Lu[((size_t)b * n + r) * n + c] = v;
 }
 
-// ---------------------------------------------------------------------------------------------
-// workspace layout (floats)
-// ---------------------------------------------------------------------------------------------
-struct WsLayout {
-  size_t info, ell, var, u, u_prior, nu, A, Lmat, Dfac, total;
-  int n, np, nblk, batch;
-};
-
-static WsLayout ws_layout(int kernel, int Di, int Do, int M, int S) {
-  WsLayout w;
-  w.n = kernel == 0 ? M : M * Do;
-  w.batch = kernel == 0 ? Do : 1;
-  w.nblk = cdiv(w.n + 1, NB);
-  w.np = w.nblk * NB;
-  size_t o = 0;
-  auto take = [&](size_t nfl) { size_t at = o; o += (nfl + 3) / 4 * 4; return at; };
-  w.info = take(4);
-  w.ell = take((size_t)Do * Di);
-  w.var = take(Do);
-  w.u = take((size_t)M * Do);
-  w.u_prior = take((size_t)M * Do);
-  w.nu = take((size_t)w.batch * w.n);
-  w.A = take((size_t)w.batch * w.np * w.np);
-  w.Lmat = take((size_t)w.batch * w.np * w.np);
-  w.Dfac = take((size_t)w.batch * w.nblk * NB * NB);
-  w.total = o;
-  return w;
-}
-
 static size_t pack_floats_for(int kernel, int Di, int Do, int M, int S) {
   const size_t SJ = cdiv(S, 64), MJ = cdiv(M, 64);
   if (kernel == 0) return 256 * (SJ * Do * cdiv(Di + 2, 4) + MJ * cdiv(Di + Do, 4)) + (size_t)cdiv(Do * Di, 4) * 4;
@@ -562,8 +533,12 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
   }
 
   // u_prior = f_prior(Z): the rhs kernel in prior-only mode on the M inducing locations
-  float* up = u_prior ? u_prior : ws + w.u_prior;
+  float* up = ws + w.u_prior;
   if (rhs_fwd(kernel, Di, Do, M, S, pack, Z, M, up, 1, st)) return 1;
+  if (u_prior) {
+    e = hipMemcpyAsync(u_prior, up, sizeof(float) * M * Do, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return set_error("memcpy: %s", hipGetErrorString(e));
+  }
 
   float* A = ws + w.A;
   float* Lmat = ws + w.Lmat;

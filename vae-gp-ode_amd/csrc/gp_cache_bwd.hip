@@ -1,0 +1,631 @@
+// gp_cache_bwd.hip -- backward of the per-draw cache build: pack-layout gradients -> raw parameters.
+//
+// What autograd does in the reference behind SVGP_Layer.build_cache (svpy.py:103-121) when
+// loss.backward() runs (main.py:210): gradients flow from every use of omega / variance / nu / Z / ell
+// inside the 4(T-1) RHS evaluations back through  nu = L^-T (u - L^-1 f_prior(Z)),  L = chol(K(Z)+jitter I),
+// u = tril(Us) eps + Um,  omega = eps/ell,  softplus.  Here:
+//
+//   g_nu  <- coefficient fields of the pack gradient (gp_backward.hip, kernel B)
+//   q = L^-1 g_nu,  a = L^-T q (= K^-1 g_nu),  v = L^-1 p,  r = u - v          (matvecs with L^-1)
+//   g_u = q   -> g_Um, g_Us ;   g_p = -a  -> f_prior(Z) path: VJP w.r.t. Z + parameter gradients (prior only)
+//   g_L = -tril(nu q^T) + tril(a v^T)  =>  Phi = tril_half(L^T g_L) = tril_half(-r q^T + q v^T)
+//   g_K = sym(L^-T Phi L^-1)            (torch's cholesky_backward convention: symmetrised, both triangles)
+//   g_K -> g_Z, g_ell, g_var through the kernel-matrix formula (kernels.py:98-110 / :289-303)
+//   pack chain: om = eps/(2 pi ell), aw = sqrt(var/S) w, cc = var nu, wl = -log2e/(2 ell^2), B(omega) ...
+//   raw chain: softplus' = sigmoid.
+//
+// L^-1 is formed explicitly (all block columns in parallel, one launch) so that everything after it is
+// plain tiled FMAs with no sequential chain; cond(L) = sqrt(cond(K)) ~ 1e2, harmless in fp32.
+#include "gp_eval.hpp"
+#include "gp_launch.hpp"
+#include "gp_ws.hpp"
+
+namespace gp {
+
+__device__ __forceinline__ float sigmoid_raw(float x) { return x > 20.f ? 1.f : 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float softplus_l(float x) { return (x > 20.f ? x : log1pf(expf(x))) + 1e-12f; }
+
+struct BwsLayout {
+  size_t Dinv, Linv, X, S, vec, gp_rows, vjpZ, slab, gZpart, kpart, gom, total;
+  int n, np, nbn, batch, nchunkZ, kpart_stride;
+};
+
+static BwsLayout bws_layout(int kernel, int Di, int Do, int M, int S, size_t pack_floats) {
+  BwsLayout b;
+  const WsLayout w = ws_layout(kernel, Di, Do, M, S);
+  b.n = w.n; b.np = w.np; b.batch = w.batch; b.nbn = cdiv(w.n, NB);
+  b.nchunkZ = M < 16 ? M : 16;
+  size_t o = 0;
+  auto take = [&](size_t nfl) { size_t at = o; o += (nfl + 3) / 4 * 4; return at; };
+  b.Dinv = take((size_t)b.batch * b.nbn * NB * NB);
+  b.Linv = take((size_t)b.batch * b.np * b.np);
+  b.X = take((size_t)b.batch * b.np * b.np);
+  b.S = take((size_t)b.batch * b.np * b.np);
+  b.vec = take((size_t)6 * b.batch * b.np);
+  b.gp_rows = take((size_t)M * Do);
+  b.vjpZ = take((size_t)M * Di);
+  b.slab = take((size_t)b.nchunkZ * pack_floats);
+  b.gZpart = take((size_t)(kernel == 0 ? Do : 1) * M * Di);
+  b.kpart_stride = kernel == 0 ? (1 + Di) : (Do + Do * Do);
+  b.kpart = take((size_t)(kernel == 0 ? Do * cdiv(M, 64) : M) * b.kpart_stride);
+  b.gom = take(kernel == 1 ? (size_t)S * Do * Do : 4);
+  b.total = o;
+  return b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// g_nu from the coefficient fields of the pack gradient
+// ---------------------------------------------------------------------------------------------
+__global__ void k_gnu(int kernel, int Di, int Do, int M, int n, int np, const float* __restrict__ gpack_ind,
+                      const float* __restrict__ var, float* __restrict__ gnu) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= np) return;
+  float v = 0.f;
+  if (j < n) {
+    const int RQ2 = cdiv(Di + Do, 4);
+    int m, d;
+    if (kernel == 0) { m = j; d = b; } else { m = j / Do; d = j % Do; }
+    const int field = Di + d;
+    const float gc = gpack_ind[(((size_t)(m >> 6) * RQ2 + (field >> 2)) * 64 + (m & 63)) * 4 + (field & 3)];
+    v = kernel == 0 ? gc * var[d] : gc;
+  }
+  gnu[(size_t)b * np + j] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// inverse of every 32x32 diagonal block of L (rows/cols >= n treated as identity)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_trinv_diag(const float* __restrict__ Dfac_all, size_t dfac_stride, int n,
+                                                    float* __restrict__ Dinv_all, size_t dinv_stride) {
+  __shared__ float sL[NB][NB + 1];
+  const int k = blockIdx.x, b = blockIdx.y, c0 = k * NB;
+  const float* Lk = Dfac_all + (size_t)b * dfac_stride + (size_t)k * NB * NB;
+  float* out = Dinv_all + (size_t)b * dinv_stride + (size_t)k * NB * NB;
+  for (int e = threadIdx.x; e < NB * NB; e += 64) {
+    const int r = e / NB, c = e % NB;
+    sL[r][c] = (c0 + r < n && c0 + c < n) ? Lk[e] : (r == c ? 1.f : 0.f);
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c < NB) {
+    float x[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      float acc = (r == c) ? 1.f : 0.f;
+#pragma unroll
+      for (int p = 0; p < r; ++p) acc = fmaf(-sL[r][p], x[p], acc);
+      x[r] = acc / sL[r][r];
+    }
+#pragma unroll
+    for (int r = 0; r < NB; ++r) out[r * NB + c] = x[r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// L^-1, one workgroup per block column k (forward substitution down the block rows)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_linv_cols(const float* __restrict__ Lall, size_t batch_stride, int n, int np, int nbn,
+                                                    const float* __restrict__ Dinv_all, size_t dinv_stride,
+                                                    float* __restrict__ Linv_all) {
+  __shared__ float sA[NB][NB + 1], sB[NB][NB + 1];
+  const int k = blockIdx.x, b = blockIdx.y;
+  const float* Lm = Lall + (size_t)b * batch_stride;
+  const float* Dinv = Dinv_all + (size_t)b * dinv_stride;
+  float* Li = Linv_all + (size_t)b * batch_stride;
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  const int c0 = k * NB;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = ty + 8 * q;
+    for (int j = 0; j < k; ++j) Li[(size_t)(j * NB + r) * np + c0 + tx] = 0.f;  // above the diagonal block
+    Li[(size_t)(c0 + r) * np + c0 + tx] = Dinv[(size_t)k * NB * NB + r * NB + tx];
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int i = k + 1; i < nbn; ++i) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = k; j < i; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = ty + 8 * q;
+        sA[r][tx] = (i * NB + r < n) ? Lm[(size_t)(i * NB + r) * np + j * NB + tx] : 0.f;
+        sB[r][tx] = Li[(size_t)(j * NB + r) * np + c0 + tx];
+      }
+      __syncthreads();
+#pragma unroll 8
+      for (int p = 0; p < NB; ++p) {
+        const float bv = sB[p][tx];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = fmaf(sA[ty + 8 * q][p], bv, acc[q]);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = ty + 8 * q;
+      sB[r][tx] = acc[q];
+      sA[r][tx] = Dinv[(size_t)i * NB * NB + r * NB + tx];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = ty + 8 * q;
+      float v = 0.f;
+#pragma unroll 8
+      for (int p = 0; p < NB; ++p) v = fmaf(sA[r][p], sB[p][tx], v);
+      Li[(size_t)(i * NB + r) * np + c0 + tx] = -v;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// vectors: q = L^-1 g_nu, a = L^-T q, v = L^-1 p (row n of the factor), r = u - v ; g_Um ; g_p rows
+//   vec layout per batch: [gnu | q | a | r | v | -] each np floats
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vecs(int kernel, int Do, int n, int np, const float* __restrict__ Lall,
+                                              size_t batch_stride, const float* __restrict__ Dfac_all, size_t dfac_stride,
+                                              const float* __restrict__ Linv_all, const float* __restrict__ u,
+                                              float* __restrict__ vec_all, float* __restrict__ g_Um, float* __restrict__ gp_rows) {
+  extern __shared__ float sm[];  // gnu[np], q[np]
+  float* sg = sm;
+  float* sq = sm + np;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* Lm = Lall + (size_t)b * batch_stride;
+  const float* Li = Linv_all + (size_t)b * batch_stride;
+  const float* Dfac = Dfac_all + (size_t)b * dfac_stride;
+  const int nb = gridDim.x;
+  float* vec = vec_all;
+  float* vg = vec + (size_t)(0 * nb + b) * np;
+  float* vq = vec + (size_t)(1 * nb + b) * np;
+  float* va = vec + (size_t)(2 * nb + b) * np;
+  float* vr = vec + (size_t)(3 * nb + b) * np;
+  float* vv = vec + (size_t)(4 * nb + b) * np;
+  for (int j = tid; j < np; j += 256) sg[j] = vg[j];
+  __syncthreads();
+  for (int i = tid; i < np; i += 256) {
+    float acc = 0.f;
+    if (i < n) for (int j = 0; j <= i; ++j) acc = fmaf(Li[(size_t)i * np + j], sg[j], acc);
+    sq[i] = acc;
+    vq[i] = acc;
+  }
+  __syncthreads();
+  const int kl = n / NB, cl = kl * NB;
+  const int u_stride = kernel == 0 ? Do : 1, u_b = kernel == 0 ? b : 0;
+  for (int j = tid; j < np; j += 256) {
+    float acc = 0.f, y = 0.f, rr = 0.f;
+    if (j < n) {
+      for (int i = j; i < n; ++i) acc = fmaf(Li[(size_t)i * np + j], sq[i], acc);
+      y = (j < cl) ? Lm[(size_t)n * np + j] : Dfac[(size_t)kl * NB * NB + (n - cl) * NB + (j - cl)];
+      rr = u[(size_t)j * u_stride + u_b] - y;
+      // g_u = q (u element j of batch b lives at u[j*u_stride + u_b]); g_p = -a in the same (M,Do) layout
+      g_Um[(size_t)j * u_stride + u_b] = sq[j];
+      gp_rows[(size_t)j * u_stride + u_b] = -acc;
+    }
+    va[j] = acc; vv[j] = y; vr[j] = rr;
+  }
+}
+
+// g_Us[d, n(n+1)/2 + m] = g_u[n,d] eps_u[m,d]   (svpy.py:94-100 backward)
+__global__ void k_gUs(int M, int Do, const float* __restrict__ g_u, const float* __restrict__ eps_u, float* __restrict__ g_Us) {
+  const size_t P = (size_t)M * (M + 1) / 2;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P * Do) return;
+  const int d = (int)(e / P);
+  const size_t k = e % P;
+  int nn = (int)((sqrtf(8.f * (float)k + 1.f) - 1.f) * 0.5f);
+  while ((size_t)(nn + 1) * (nn + 2) / 2 <= k) ++nn;
+  while ((size_t)nn * (nn + 1) / 2 > k) --nn;
+  const int m = (int)(k - (size_t)nn * (nn + 1) / 2);
+  g_Us[e] = g_u[(size_t)nn * Do + d] * eps_u[(size_t)m * Do + d];
+}
+
+// ---------------------------------------------------------------------------------------------
+// X = L^-T Phi,  Phi[i][j] = -r_i q_j + q_i v_j (i > j), half of that on the diagonal, 0 above
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gemm_phiX(const float* __restrict__ Linv_all, size_t batch_stride, int np, int nbn,
+                                                    const float* __restrict__ vec_all, float* __restrict__ X_all) {
+  __shared__ float sA[NB][NB + 1], sP[NB][NB + 1];
+  __shared__ float sri[NB], sqi[NB], sqj[NB], svj[NB];
+  const int ab = blockIdx.x, jb = blockIdx.y, b = blockIdx.z, nb = gridDim.z;
+  const float* Li = Linv_all + (size_t)b * batch_stride;
+  float* X = X_all + (size_t)b * batch_stride;
+  const float* vq = vec_all + (size_t)(1 * nb + b) * np;
+  const float* vr = vec_all + (size_t)(3 * nb + b) * np;
+  const float* vv = vec_all + (size_t)(4 * nb + b) * np;
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  if (tid < NB) { sqj[tid] = vq[jb * NB + tid]; svj[tid] = vv[jb * NB + tid]; }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int ib = (ab > jb ? ab : jb); ib < nbn; ++ib) {
+    __syncthreads();
+    if (tid < NB) { sri[tid] = vr[ib * NB + tid]; sqi[tid] = vq[ib * NB + tid]; }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = ty + 8 * q;
+      sA[p][tx] = Li[(size_t)(ib * NB + p) * np + ab * NB + tx];  // Linv[i][a]
+      const int gi = ib * NB + p, gj = jb * NB + tx;
+      const float ph = -sri[p] * sqj[tx] + sqi[p] * svj[tx];
+      sP[p][tx] = gi > gj ? ph : (gi == gj ? 0.5f * ph : 0.f);
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int p = 0; p < NB; ++p) {
+      const float pv = sP[p][tx];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = fmaf(sA[p][ty + 8 * q], pv, acc[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) X[(size_t)(ab * NB + ty + 8 * q) * np + jb * NB + tx] = acc[q];
+}
+
+// S = X L^-1
+__global__ __launch_bounds__(256) void k_gemm_S(const float* __restrict__ X_all, const float* __restrict__ Linv_all,
+                                                 size_t batch_stride, int np, int nbn, float* __restrict__ S_all) {
+  __shared__ float sA[NB][NB + 1], sB[NB][NB + 1];
+  const int ab = blockIdx.x, cb = blockIdx.y, b = blockIdx.z;
+  const float* X = X_all + (size_t)b * batch_stride;
+  const float* Li = Linv_all + (size_t)b * batch_stride;
+  float* Sm = S_all + (size_t)b * batch_stride;
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int jb = cb; jb < nbn; ++jb) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = ty + 8 * q;
+      sA[r][tx] = X[(size_t)(ab * NB + r) * np + jb * NB + tx];
+      sB[r][tx] = Li[(size_t)(jb * NB + r) * np + cb * NB + tx];
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int p = 0; p < NB; ++p) {
+      const float bv = sB[p][tx];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = fmaf(sA[ty + 8 * q][p], bv, acc[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) Sm[(size_t)(ab * NB + ty + 8 * q) * np + cb * NB + tx] = acc[q];
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel-matrix backward.  G = (S + S^T)/2 multiplies BOTH triangles of K(Z) (torch's cholesky_backward).
+// ---------------------------------------------------------------------------------------------
+// RBF: grid (ceil(M/64), Do), block 64: thread = row point n.
+__global__ __launch_bounds__(64) void k_Kbwd_rbf(int Di, int Do, int M, int np, const float* __restrict__ Z,
+                                                  const float* __restrict__ ell, const float* __restrict__ var,
+                                                  const float* __restrict__ S_all, float* __restrict__ gZpart,
+                                                  float* __restrict__ kpart) {
+  const int d = blockIdx.y, lane = threadIdx.x, n = blockIdx.x * 64 + lane;
+  const float* Sm = S_all + (size_t)d * np * np;
+  float gz[16], gl[16], zn[16], il[16];
+  float gv = 0.f;
+  const bool ok = n < M;
+  for (int i = 0; i < Di; ++i) { gz[i] = 0.f; gl[i] = 0.f; zn[i] = ok ? Z[n * Di + i] : 0.f; il[i] = 1.f / ell[d * Di + i]; }
+  const float vd = var[d];
+  if (ok) {
+    for (int m = 0; m < M; ++m) {
+      float qd = 0.f, dl[16];
+      for (int i = 0; i < Di; ++i) { dl[i] = zn[i] - Z[m * Di + i]; const float t = dl[i] * il[i]; qd = fmaf(t, t, qd); }
+      const float K = vd * expf(-0.5f * qd);
+      const float G = 0.5f * (Sm[(size_t)n * np + m] + Sm[(size_t)m * np + n]);
+      const float GK = G * K;
+      gv = fmaf(G, K / vd, gv);
+      for (int i = 0; i < Di; ++i) {
+        gz[i] = fmaf(-2.f * GK, dl[i] * il[i] * il[i], gz[i]);
+        gl[i] = fmaf(GK, dl[i] * dl[i] * il[i] * il[i] * il[i], gl[i]);
+      }
+    }
+    for (int i = 0; i < Di; ++i) gZpart[((size_t)d * M + n) * Di + i] = gz[i];
+  }
+  gv = wave_allreduce_sum(gv);
+  float* kp = kpart + (size_t)(d * gridDim.x + blockIdx.x) * (1 + Di);
+  if (lane == 0) kp[0] = gv;
+  for (int i = 0; i < Di; ++i) {
+    const float s = wave_allreduce_sum(gl[i]);
+    if (lane == 0) kp[1 + i] = s;
+  }
+}
+
+// DF: grid M, block 64: one wave per point n; lanes stride over the other point m.
+//   kpart[n]: [gvar(D) | gell(D*D)],  gZpart[n][c]
+template <int D>
+__global__ __launch_bounds__(64) void k_Kbwd_df(int M, int np, const float* __restrict__ Z, const float* __restrict__ ell,
+                                                 const float* __restrict__ var, const float* __restrict__ Sm,
+                                                 float* __restrict__ gZpart, float* __restrict__ kpart) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  float gz[D], gvar[D], gell[D][D], zn[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    gz[a] = 0.f; gvar[a] = 0.f; zn[a] = Z[n * D + a];
+#pragma unroll
+    for (int b = 0; b < D; ++b) gell[a][b] = 0.f;
+  }
+  for (int m = lane; m < M; m += 64) {
+    float dl[D];
+    float r2 = 0.f;
+#pragma unroll
+    for (int a = 0; a < D; ++a) { dl[a] = Z[m * D + a] - zn[a]; r2 = fmaf(dl[a], dl[a], r2); }  // delta = z_m - z_n
+    float gd[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) gd[a] = 0.f;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+#pragma unroll
+      for (int b = 0; b < D; ++b) {
+        const float l = ell[a * D + b];
+        const float il = 1.f / (l * l), il3 = il / l;  // 1/l^2, 1/l^3
+        const float E = expf(-0.5f * r2 * il);
+        const bool diag = a == b;
+        const float term = dl[a] * dl[b] * il + (diag ? ((float)(D - 1) - r2 * il) : 0.f);
+        const float vb = var[b];
+        // entry (n,a),(m,b) and its point-transposed twin (m,a),(n,b): same value, same d/d z_n
+        const size_t r1 = (size_t)(n * D + a), c1 = (size_t)(m * D + b);
+        const size_t r2i = (size_t)(m * D + a), c2 = (size_t)(n * D + b);
+        const float G1 = 0.5f * (Sm[r1 * np + c1] + Sm[c1 * np + r1]);
+        const float G2 = 0.5f * (Sm[r2i * np + c2] + Sm[c2 * np + r2i]);
+        const float base = vb * E * il;
+        // dT/d delta_c = base * [ -il delta_c term + il (d_ca delta_b + d_cb delta_a) - diag 2 il delta_c ]
+        const float Gs = (G1 + G2) * base;
+        const float common = -il * term - (diag ? 2.f * il : 0.f);
+#pragma unroll
+        for (int c = 0; c < D; ++c) gd[c] = fmaf(Gs, common * dl[c], gd[c]);
+        gd[a] = fmaf(Gs, il * dl[b], gd[a]);
+        gd[b] = fmaf(Gs, il * dl[a], gd[b]);
+        // parameters: entry 1 only
+        gvar[b] = fmaf(G1, E * il * term, gvar[b]);
+        // dT/dl = vb E / l^3 [ r2 il term - 2 term - 2 il (delta_a delta_b - diag r2) ]
+        const float dT = vb * E * il3 * (r2 * il * term - 2.f * term - 2.f * il * (dl[a] * dl[b] - (diag ? r2 : 0.f)));
+        gell[a][b] = fmaf(G1, dT, gell[a][b]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) gz[c] -= gd[c];  // d/d z_n = - d/d delta
+  }
+  float red[D], tmp[D];
+  wave_sum_all<D>(gz, red);
+  if (lane == 0)
+#pragma unroll
+    for (int c = 0; c < D; ++c) gZpart[(size_t)n * D + c] = red[c];
+  float* kp = kpart + (size_t)n * (D + D * D);
+  wave_sum_all<D>(gvar, red);
+  if (lane == 0)
+#pragma unroll
+    for (int c = 0; c < D; ++c) kp[c] = red[c];
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+#pragma unroll
+    for (int b = 0; b < D; ++b) tmp[b] = gell[a][b];
+    wave_sum_all<D>(tmp, red);
+    if (lane == 0)
+#pragma unroll
+      for (int b = 0; b < D; ++b) kp[D + a * D + b] = red[b];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// final chains
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rec_field(const float* __restrict__ base, size_t rec_f4_base, int lane, int field) {
+  return base[((rec_f4_base + (size_t)(field >> 2)) * 64 + lane) * 4 + (field & 3)];
+}
+
+// RBF: one block.  g_ell[d,i], g_var[d] -> raw; g_Z.
+__global__ __launch_bounds__(256) void k_chain_rbf(int Di, int Do, int M, int S, const float* __restrict__ pack,
+                                                    const float* __restrict__ gpack, const float* __restrict__ raw_ell,
+                                                    const float* __restrict__ raw_var, const float* __restrict__ nu,
+                                                    const float* __restrict__ vjpZ, const float* __restrict__ gZpart,
+                                                    const float* __restrict__ kpart, int nbx,
+                                                    float* __restrict__ g_raw_ell, float* __restrict__ g_raw_var,
+                                                    float* __restrict__ g_Z) {
+  const int RQ = cdiv(Di + 2, 4), RQ2 = cdiv(Di + Do, 4), SJ = cdiv(S, 64), MJ = cdiv(M, 64);
+  const size_t rff_f4 = (size_t)SJ * Do * RQ * 64, ind_f4 = (size_t)MJ * RQ2 * 64;
+  const float* gind = gpack + 4 * rff_f4;
+  const float* guni = gpack + 4 * (rff_f4 + ind_f4);
+  const int tid = threadIdx.x;
+  for (int e = tid; e < Do * Di; e += 256) {
+    const int d = e / Di, i = e % Di;
+    const float l = softplus_l(raw_ell[e]);
+    float g = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const size_t base = (size_t)((s >> 6) * Do + d) * RQ;
+      g = fmaf(rec_field(gpack, base, s & 63, i), -rec_field(pack, base, s & 63, i) / l, g);  // om = eps/(2 pi l)
+    }
+    g = fmaf(guni[e], GP_LOG2E / (l * l * l), g);                                             // wl = -log2e/(2 l^2)
+    for (int bx = 0; bx < nbx; ++bx) g += kpart[(size_t)(d * nbx + bx) * (1 + Di) + 1 + i];
+    g_raw_ell[e] = g * sigmoid_raw(raw_ell[e]);
+  }
+  for (int d = tid; d < Do; d += 256) {
+    const float v = softplus_l(raw_var[d]);
+    float g = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const size_t base = (size_t)((s >> 6) * Do + d) * RQ;
+      g = fmaf(rec_field(gpack, base, s & 63, Di + 1), rec_field(pack, base, s & 63, Di + 1) / (2.f * v), g);  // aw = sqrt(v/S) w
+    }
+    for (int m = 0; m < M; ++m) g = fmaf(rec_field(gind, (size_t)(m >> 6) * RQ2, m & 63, Di + d), nu[(size_t)d * M + m], g);  // cc = v nu
+    for (int bx = 0; bx < nbx; ++bx) g += kpart[(size_t)(d * nbx + bx) * (1 + Di)];
+    g_raw_var[d] = g * sigmoid_raw(raw_var[d]);
+  }
+  for (int e = tid; e < M * Di; e += 256) {
+    const int m = e / Di, i = e % Di;
+    float g = rec_field(gind, (size_t)(m >> 6) * RQ2, m & 63, i) + vjpZ[e];
+    for (int d = 0; d < Do; ++d) g += gZpart[((size_t)d * M + m) * Di + i];
+    g_Z[e] = g;
+  }
+}
+
+// DF step 1: per feature s, gradient w.r.t. omega[p,s,q] from the om fields and through B(omega):
+//   gom[s][p*D+q]
+template <int D>
+__global__ void k_df_gomega(int S, const float* __restrict__ pack, const float* __restrict__ gpack,
+                            const float* __restrict__ var, float* __restrict__ gom) {
+  constexpr int RQ = cdiv(2 * D + 3, 4);
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const int lane = s & 63, j0 = s >> 6;
+  float om[D][D], gB[D][D], nrm[D], G[D][D], go[D][D];  // om[p][q] = omega[p,s,q]
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    const size_t base = (size_t)(j0 * D + i) * RQ;  // record (s,i): fields om_k = omega[k,s,i]/(2 pi), bs_j
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      om[k][i] = rec_field(pack, base, lane, k) * GP_2PI;
+      go[k][i] = rec_field(gpack, base, lane, k) * GP_INV2PI;
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) gB[i][j] = rec_field(gpack, base, lane, D + 3 + j) * sqrtf(var[j] / (float)S);
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    float n2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < D; ++k) n2 = fmaf(om[k][j], om[k][j], n2);
+    nrm[j] = sqrtf(n2);
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float g = 0.f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) g = fmaf(om[i][k], om[j][k], g);
+      G[i][j] = g;
+    }
+  // B[i][j] = nrm_j d_ij - G[i][j]/nrm_j
+#pragma unroll
+  for (int p = 0; p < D; ++p)
+#pragma unroll
+    for (int q = 0; q < D; ++q) {
+      float t1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < D; ++i) t1 = fmaf(gB[i][q], ((i == q) ? 1.f : 0.f) + G[i][q] / (nrm[q] * nrm[q]), t1);
+      float g = t1 * om[p][q] / nrm[q];
+#pragma unroll
+      for (int j = 0; j < D; ++j) g = fmaf(-gB[p][j] / nrm[j], om[j][q], g);
+#pragma unroll
+      for (int i = 0; i < D; ++i) g = fmaf(-gB[i][p] / nrm[p], om[i][q], g);
+      gom[(size_t)s * D * D + p * D + q] = go[p][q] + g;
+    }
+}
+
+// DF step 2: one block.
+template <int D>
+__global__ __launch_bounds__(256) void k_chain_df(int M, int S, const float* __restrict__ pack, const float* __restrict__ gpack,
+                                                   const float* __restrict__ raw_ell, const float* __restrict__ raw_var,
+                                                   const float* __restrict__ gom, const float* __restrict__ vjpZ,
+                                                   const float* __restrict__ gZpart, const float* __restrict__ kpart,
+                                                   float* __restrict__ g_raw_ell, float* __restrict__ g_raw_var,
+                                                   float* __restrict__ g_Z) {
+  constexpr int RQ = cdiv(2 * D + 3, 4), RQ2 = cdiv(2 * D, 4);
+  const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
+  const size_t rff_f4 = (size_t)SJ * D * RQ * 64, ind_f4 = (size_t)MJ * RQ2 * 64;
+  const float* gind = gpack + 4 * rff_f4;
+  const float* guni = gpack + 4 * (rff_f4 + ind_f4);
+  const int tid = threadIdx.x;
+  for (int e = tid; e < D * D; e += 256) {
+    const int a = e / D, b = e % D;  // ell[a][b]; omega[k,s,i] = eps/ell[i][k] -> entry (a,b) <- omega[b,s,a]
+    const float l = softplus_l(raw_ell[e]);
+    float g = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const size_t base = (size_t)((s >> 6) * D + a) * RQ;                // record (s, i=a), field k=b
+      const float om = rec_field(pack, base, s & 63, b) * GP_2PI;         // omega[b,s,a]
+      g = fmaf(gom[(size_t)s * D * D + b * D + a], -om / l, g);
+    }
+    const float l3 = l * l * l;
+    g = fmaf(guni[e], GP_LOG2E / l3, g);             // wab = -log2e/(2 l^2)
+    g = fmaf(guni[D * D + e], -2.f / l3, g);         // il2 = 1/l^2
+    for (int n = 0; n < M; ++n) g += kpart[(size_t)n * (D + D * D) + D + e];
+    g_raw_ell[e] = g * sigmoid_raw(raw_ell[e]);
+  }
+  for (int j = tid; j < D; j += 256) {
+    const float v = softplus_l(raw_var[j]);
+    float g = guni[2 * D * D + j];
+    for (int s = 0; s < S; ++s)
+      for (int i = 0; i < D; ++i) {
+        const size_t base = (size_t)((s >> 6) * D + i) * RQ;
+        g = fmaf(rec_field(gpack, base, s & 63, D + 3 + j), rec_field(pack, base, s & 63, D + 3 + j) / (2.f * v), g);  // bs = B sqrt(v/S)
+      }
+    for (int n = 0; n < M; ++n) g += kpart[(size_t)n * (D + D * D) + j];
+    g_raw_var[j] = g * sigmoid_raw(raw_var[j]);
+  }
+  for (int e = tid; e < M * D; e += 256) {
+    const int m = e / D, i = e % D;
+    g_Z[e] = rec_field(gind, (size_t)(m >> 6) * RQ2, m & 63, i) + vjpZ[e] + gZpart[e];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+int cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, size_t* bws_floats) {
+  size_t pf = 0;
+  if (cache_sizes(kernel, Di, Do, M, S, &pf, nullptr)) return 1;
+  *bws_floats = bws_layout(kernel, Di, Do, M, S, pf).total;
+  return 0;
+}
+
+int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_ell, const float* raw_var, const float* Z,
+                    const float* eps_u, const float* pack, const float* ws, float* gpack, float* bws,
+                    float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, hipStream_t st) {
+  size_t pf = 0;
+  if (cache_sizes(kernel, Di, Do, M, S, &pf, nullptr)) return 1;
+  if (Di > 16 || Do > 16) return set_error("gpode_cache_build_bwd: D <= 16");
+  const WsLayout w = ws_layout(kernel, Di, Do, M, S);
+  const BwsLayout b = bws_layout(kernel, Di, Do, M, S, pf);
+  const size_t SJ = cdiv(S, 64), MJ = cdiv(M, 64);
+  const size_t rff_f4 = (kernel == 0 ? SJ * Do * cdiv(Di + 2, 4) : SJ * Do * cdiv(2 * Do + 3, 4)) * 64;
+  const float* gpack_ind = gpack + 4 * rff_f4;
+  const float* Lmat = ws + w.Lmat;
+  const float* Dfac = ws + w.Dfac;
+  const size_t bstride = (size_t)w.np * w.np, dstride = (size_t)w.nblk * NB * NB, dinv_stride = (size_t)b.nbn * NB * NB;
+  float* vec = bws + b.vec;
+  (void)MJ;
+
+  hipLaunchKernelGGL(k_gnu, dim3(cdiv(b.np, 128), b.batch), 128, 0, st, kernel, Di, Do, M, b.n, b.np, gpack_ind, ws + w.var, vec);
+  hipLaunchKernelGGL(k_trinv_diag, dim3(b.nbn, b.batch), 64, 0, st, Dfac, dstride, b.n, bws + b.Dinv, dinv_stride);
+  hipLaunchKernelGGL(k_linv_cols, dim3(b.nbn, b.batch), 256, 0, st, Lmat, bstride, b.n, b.np, b.nbn, bws + b.Dinv, dinv_stride, bws + b.Linv);
+  {
+    const size_t lds = 2 * sizeof(float) * b.np;
+    if (set_max_lds((const void*)k_vecs, lds)) return 1;
+    hipLaunchKernelGGL(k_vecs, b.batch, 256, lds, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, bws + b.Linv,
+                       ws + w.u, vec, g_Um, bws + b.gp_rows);
+  }
+  if (check_launch("cache bwd: solves")) return 1;
+  {
+    const size_t P = (size_t)M * (M + 1) / 2 * Do;
+    hipLaunchKernelGGL(k_gUs, (unsigned)((P + 255) / 256), 256, 0, st, M, Do, g_Um, eps_u, g_Us);
+  }
+  // f_prior(Z) path: d/dZ and parameter gradients (prior only), added to the pack gradient
+  if (rhs_vjp(kernel, Di, Do, M, S, pack, Z, bws + b.gp_rows, M, bws + b.vjpZ, 1, st)) return 1;
+  if (param_grad(kernel, Di, Do, M, S, pack, Z, bws + b.gp_rows, M, bws + b.slab, b.nchunkZ, gpack, 1, 1, st)) return 1;
+  // g_K = sym(L^-T Phi L^-1)
+  hipLaunchKernelGGL(k_gemm_phiX, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, bws + b.Linv, bstride, b.np, b.nbn, vec, bws + b.X);
+  hipLaunchKernelGGL(k_gemm_S, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, bws + b.X, bws + b.Linv, bstride, b.np, b.nbn, bws + b.S);
+  if (check_launch("cache bwd: gK")) return 1;
+  if (kernel == 0) {
+    const int nbx = cdiv(M, 64);
+    hipLaunchKernelGGL(k_Kbwd_rbf, dim3(nbx, Do), 64, 0, st, Di, Do, M, b.np, Z, ws + w.ell, ws + w.var, bws + b.S,
+                       bws + b.gZpart, bws + b.kpart);
+    hipLaunchKernelGGL(k_chain_rbf, 1, 256, 0, st, Di, Do, M, S, pack, gpack, raw_ell, raw_var, ws + w.nu, bws + b.vjpZ,
+                       bws + b.gZpart, bws + b.kpart, nbx, g_raw_ell, g_raw_var, g_Z);
+    return check_launch("cache bwd: chain");
+  }
+#define X(D_)                                                                                                              \
+  if (Do == D_) {                                                                                                          \
+    hipLaunchKernelGGL(k_Kbwd_df<D_>, M, 64, 0, st, M, b.np, Z, ws + w.ell, ws + w.var, bws + b.S, bws + b.gZpart,         \
+                       bws + b.kpart);                                                                                     \
+    hipLaunchKernelGGL(k_df_gomega<D_>, cdiv(S, 64), 64, 0, st, S, pack, gpack, ws + w.var, bws + b.gom);                  \
+    hipLaunchKernelGGL(k_chain_df<D_>, 1, 256, 0, st, M, S, pack, gpack, raw_ell, raw_var, bws + b.gom, bws + b.vjpZ,      \
+                       bws + b.gZpart, bws + b.kpart, g_raw_ell, g_raw_var, g_Z);                                          \
+    return check_launch("cache bwd: chain df");                                                                            \
+  }
+  X(6) X(4) X(2) X(3) X(8)
+#undef X
+  return set_error("gpode_cache_build_bwd: DF backward is built for D in {2,3,4,6,8}");
+}
+
+}  // namespace gp

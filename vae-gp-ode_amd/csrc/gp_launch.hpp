@@ -36,9 +36,10 @@ int rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, int S,
                 const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st);
 int rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S, const float* pack, const float* xstage,
                 const float* gzt, const float* ts, int N, int T, float* gz0, float* astage, hipStream_t st);
-int rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, const float* a, int R, float* gx, hipStream_t st);
+int rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, const float* a, int R, float* gx,
+            int prior_only, hipStream_t st);
 int param_grad(int kernel, int Di, int Do, int M, int S, const float* pack, const float* xr, const float* ar, int R,
-               float* slab, int nchunk, float* gpack, int accumulate, hipStream_t st);
+               float* slab, int nchunk, float* gpack, int accumulate, int prior_only, hipStream_t st);
 int cache_sizes(int kernel, int Di, int Do, int M, int S, size_t* pack_floats, size_t* ws_floats);
 int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
                     const float* raw_ell, const float* raw_var, const float* Z, const float* Um, const float* Us_packed,
@@ -50,5 +51,10 @@ int kernel_matrix(int kernel, int Di, int Do, const float* raw_ell, const float*
                   const float* X2, int M2, float* out, hipStream_t st);
 int svgp_kl_fwd(int M, int Do, const float* Um, const float* Us, float* kl, hipStream_t st);
 int svgp_kl_bwd(int M, int Do, const float* Um, const float* Us, const float* g, float* dUm, float* dUs, hipStream_t st);
+
+int cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, size_t* bws_floats);
+int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_ell, const float* raw_var, const float* Z,
+                    const float* eps_u, const float* pack, const float* ws, float* gpack, float* bws,
+                    float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, hipStream_t st);
 
 }  // namespace gp

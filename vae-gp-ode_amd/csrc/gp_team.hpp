@@ -85,14 +85,15 @@ template <int DI, int DO, int NJ> struct RbfTeamEval {
     comb.run<DO>(part, f);
   }
   // gx = J_f(x)^T a, combined over the team
-  __device__ __forceinline__ void vjp(const float (&x)[DI], const float (&a)[DO], float (&gx)[DI]) {
+  // prior_only: differentiate f_prior alone (the f_prior(Z) path of the cache build)
+  __device__ __forceinline__ void vjp(const float (&x)[DI], const float (&a)[DO], float (&gx)[DI], bool prior_only = false) {
     float acc[DI];
 #pragma unroll
     for (int i = 0; i < DI; ++i) acc[i] = 0.f;
     float g0[4 * L::RQ], g1[4 * L::RQ2], g2[(DO + 1) / 2][DI];
 #pragma unroll
     for (int r = 0; r < NJ * DO; ++r) rbf_rff_bwd<DI, DO, false>(rff[r], x, a[r % DO], acc, g0);
-    rbf_ind_half_bwd<DI, DO, false>(ind, x, wl, half, a, acc, g1, g2);
+    if (!prior_only) rbf_ind_half_bwd<DI, DO, false>(ind, x, wl, half, a, acc, g1, g2);
     float part[DI];
     wave_sum_all<DI>(acc, part);
     comb.run<DI>(part, gx);
@@ -115,13 +116,13 @@ template <int DI, int DO, int NJ> struct RbfTeamEval {
         for (int i = 0; i < DI; ++i) gwl[d][i] = 0.f;
     }
   };
-  __device__ __forceinline__ void grad_row(const float (&x)[DI], const float (&a)[DO], Grads& G) const {
+  __device__ __forceinline__ void grad_row(const float (&x)[DI], const float (&a)[DO], Grads& G, bool prior_only) const {
     float gx[DI];
 #pragma unroll
     for (int i = 0; i < DI; ++i) gx[i] = 0.f;
 #pragma unroll
     for (int r = 0; r < NJ * DO; ++r) rbf_rff_bwd<DI, DO, true>(rff[r], x, a[r % DO], gx, G.rff[r]);
-    rbf_ind_half_bwd<DI, DO, true>(ind, x, wl, half, a, gx, G.ind, G.gwl);
+    if (!prior_only) rbf_ind_half_bwd<DI, DO, true>(ind, x, wl, half, a, gx, G.ind, G.gwl);
   }
 };
 
@@ -166,14 +167,14 @@ template <int D, int NJ> struct DfTeamEval {
     wave_sum_all<D>(acc, part);
     comb.run<D>(part, f);
   }
-  __device__ __forceinline__ void vjp(const float (&x)[D], const float (&a)[D], float (&gx)[D]) {
+  __device__ __forceinline__ void vjp(const float (&x)[D], const float (&a)[D], float (&gx)[D], bool prior_only = false) {
     float acc[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) acc[i] = 0.f;
     float g0[4 * L::RQ], g1[4 * L::RQ2], g2[D][(D + 1) / 2], g3[D][(D + 1) / 2], g4[(D + 1) / 2];
 #pragma unroll
     for (int r = 0; r < NJ * D; ++r) df_rff_bwd<D, false>(rff[r], x, a, acc, g0);
-    df_ind_half_bwd<D, false>(ind, x, uni, half, a, acc, g1, g2, g3, g4);
+    if (!prior_only) df_ind_half_bwd<D, false>(ind, x, uni, half, a, acc, g1, g2, g3, g4);
     float part[D];
     wave_sum_all<D>(acc, part);
     comb.run<D>(part, gx);
@@ -197,13 +198,13 @@ template <int D, int NJ> struct DfTeamEval {
       for (int b = 0; b < (D + 1) / 2; ++b) gvar[b] = 0.f;
     }
   };
-  __device__ __forceinline__ void grad_row(const float (&x)[D], const float (&a)[D], Grads& G) const {
+  __device__ __forceinline__ void grad_row(const float (&x)[D], const float (&a)[D], Grads& G, bool prior_only) const {
     float gx[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) gx[i] = 0.f;
 #pragma unroll
     for (int r = 0; r < NJ * D; ++r) df_rff_bwd<D, true>(rff[r], x, a, gx, G.rff[r]);
-    df_ind_half_bwd<D, true>(ind, x, uni, half, a, gx, G.ind, G.gwab, G.gil2, G.gvar);
+    if (!prior_only) df_ind_half_bwd<D, true>(ind, x, uni, half, a, gx, G.ind, G.gwab, G.gil2, G.gvar);
   }
 };
 

@@ -191,22 +191,31 @@ def svgp_kl(Um, Us_packed, M):
 
 class _Flow(torch.autograd.Function):
     """One GP function draw + fixed-grid integration (flow.py:68-86), differentiable w.r.t. z0 and the five
-    GP parameter tensors.  Forward: gpode_cache_build_fwd + gpode_rollout_fwd.  Backward: reverse sweep
-    kernels (gpode_rollout_bwd / gpode_cache_build_bwd)."""
+    GP parameter tensors.  Forward: gpode_cache_build_fwd + gpode_rollout_fwd.  Backward: gpode_rollout_bwd
+    (reverse sweep), gpode_param_grad (pack-layout parameter gradients), gpode_cache_build_bwd."""
 
     @staticmethod
     def forward(ctx, z0, ts, raw_ell, raw_var, Z, Um, Us, gp, order, method):
         cache = gp.build_cache()
-        zt = rollout(cache, z0, ts, order, method)
-        ctx.gp, ctx.cache, ctx.order, ctx.method = gp, cache, order, method
-        ctx.save_for_backward(z0, ts, zt)
+        need = any(ctx.needs_input_grad)
+        if need:
+            zt, xs = rollout(cache, z0, ts, order, method, save_stages=True)
+        else:
+            zt, xs = rollout(cache, z0, ts, order, method), None
+        ctx.cache, ctx.order, ctx.method = cache, order, method
+        ctx.save_for_backward(ts, xs, raw_ell.detach(), raw_var.detach(), Z.detach())
         return zt
 
     @staticmethod
     def backward(ctx, gzt):
-        z0, ts, zt = ctx.saved_tensors
-        grads = flow_backward(ctx.cache, z0, ts, zt, gzt.contiguous(), ctx.order, ctx.method, ctx.needs_input_grad)
-        return (grads['z0'], None, grads['raw_ell'], grads['raw_var'], grads['Z'], grads['Um'], grads['Us'], None, None, None)
+        ts, xs, raw_ell, raw_var, Z = ctx.saved_tensors
+        c = ctx.cache
+        gz0, ast = rollout_bwd(c, xs, gzt.contiguous(), ts, ctx.order, ctx.method)
+        if not any(ctx.needs_input_grad[2:7]):
+            return (gz0,) + (None,) * 9
+        gpack = param_grad(c, xs.reshape(-1, c.Di), ast.reshape(-1, c.Do))
+        g = cache_build_bwd(c, raw_ell, raw_var, Z, gpack)
+        return (gz0, None, g['raw_ell'], g['raw_var'], g['Z'], g['Um'], g['Us'], None, None, None)
 
 
 def flow(gp, z0, ts, order, method):
@@ -215,6 +224,18 @@ def flow(gp, z0, ts, order, method):
                        gp.Um.optvar, gp.Us_sqrt.optvar, gp, order, method)
 
 
-def flow_backward(cache, z0, ts, zt, gzt, order, method, needs):
-    raise _lib.GpodeError('the HIP reverse sweep (gpode_rollout_bwd) is not built in this version; '
-                          'there is no autograd/CPU fallback')
+def cache_build_bwd(cache, raw_ell, raw_var, Z, gpack):
+    """Pack-layout gradient -> gradients of the five raw GP parameter tensors (state_dict layouts)."""
+    c = cache
+    bw = ctypes.c_size_t(0)
+    _lib.call('gpode_cache_bwd_sizes', KERNEL_ID[c.kernel], c.Di, c.Do, c.M, c.S, ctypes.byref(bw))
+    dev = gpack.device
+    new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    bws = new(bw.value)
+    out = dict(raw_ell=new(c.Do, c.Di), raw_var=new(c.Do), Z=new(c.M, c.Di), Um=new(c.M, c.Do),
+               Us=new(c.Do, c.M * (c.M + 1) // 2))
+    _lib.call('gpode_cache_build_bwd', KERNEL_ID[c.kernel], c.Di, c.Do, c.M, c.S,
+              _ptr(_chk(raw_ell, 'raw_ell')), _ptr(_chk(raw_var, 'raw_var')), _ptr(_chk(Z, 'Z')), _ptr(c.noise['eps_u']),
+              _ptr(c.pack), _ptr(c.ws), _ptr(gpack), _ptr(bws),
+              _ptr(out['raw_ell']), _ptr(out['raw_var']), _ptr(out['Z']), _ptr(out['Um']), _ptr(out['Us']), _stream())
+    return out
