@@ -113,6 +113,47 @@ int gpode_svgp_kl_fwd(int M, int Do, const float* Um, const float* Us_packed, fl
 int gpode_svgp_kl_bwd(int M, int Do, const float* Um, const float* Us_packed, const float* g,
                       float* dUm, float* dUs, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * conv VAE blocks (model/core/vae.py), NCHW fp32.  Conv geometry: x (B,Ci,H,W), w (Co,Ci,K,K), stride S,
+ * padding P, y (B,Co,Ho,Wo).  nn.ConvTranspose2d(Cin_T,Cout_T) with weight (Cin_T,Cout_T,K,K) is the adjoint
+ * of the convolution with Co=Cin_T, Ci=Cout_T on the SAME weight buffer:
+ *   ConvTranspose2d forward   = gpode_conv2d_bwd_data(gy := its input, bias := its bias)
+ *   ConvTranspose2d d/d input = gpode_conv2d_fwd(x := grad_output, bias := NULL)
+ *   ConvTranspose2d d/d weight= gpode_conv2d_bwd_weight(x := grad_output, gy := its input)
+ * Conv2d (vae.py:53-61) uses them under their own names. */
+int gpode_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co,
+                     int K, int S, int P, int Ho, int Wo, void* stream);
+int gpode_conv2d_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co,
+                          int K, int S, int P, int Ho, int Wo, void* stream);
+size_t gpode_conv_wgrad_scratch(int B, int Ci, int Co, int K);
+int gpode_conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci, int H, int W,
+                            int Co, int K, int S, int P, int Ho, int Wo, void* stream);
+/* nn.BatchNorm2d in TRAINING mode (batch statistics), optional fused ReLU (vae.py:55-59,113-120).
+ * running_* may be NULL (no update). */
+size_t gpode_bn_scratch(int B, int C);
+int gpode_bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
+                 float* running_mean, float* running_var, float momentum, float eps, int B, int C, int HW, int relu,
+                 float* scratch, void* stream);
+int gpode_bn_bwd(const float* x, const float* y, const float* gy, const float* gamma, const float* save_mean,
+                 const float* save_invstd, float* gx, float* ggamma, float* gbeta, int B, int C, int HW, int relu,
+                 float* scratch, void* stream);
+/* out[c] = sum_{b,hw} v[b,c,hw] (bias gradients); scratch: gpode_bn_scratch(B,C) floats. */
+int gpode_chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, void* stream);
+/* mode 0: ReLU, 1: sigmoid (vae.py:60,121).  Backward takes the forward OUTPUT y. */
+int gpode_act_fwd(const float* x, float* y, size_t n, int mode, void* stream);
+int gpode_act_bwd(const float* y, const float* gy, float* gx, size_t n, int mode, void* stream);
+/* nn.Linear (vae.py:64,107): x (B,In), w (Out,In). */
+int gpode_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, void* stream);
+int gpode_linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out,
+                     void* stream);
+/* Decoder.log_prob (vae.py:136-153): ll = log(z) X + log(1-z)(1-X), X broadcast over the leading L copies
+ * (nX = numel(X)).  rowsum: the sum([2,3,4,5]) of create_model.py:52-53 fused, rows = L*N, inner = T*C*H*W. */
+int gpode_loglik_fwd(const float* X, const float* z, float* ll, size_t n, size_t nX, void* stream);
+int gpode_loglik_bwd(const float* X, const float* z, const float* g, float* gz, size_t n, size_t nX, void* stream);
+int gpode_loglik_rowsum_fwd(const float* X, const float* z, float* out, size_t rows, size_t inner, size_t nX, void* stream);
+int gpode_loglik_rowsum_bwd(const float* X, const float* z, const float* grow, float* gz, size_t rows, size_t inner, size_t nX,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,88 @@
+"""GPU parity of the full path: encoder -> GP-ODE flow -> decoder -> ELBO -> backward, through the mirror of
+the reference API, against fixtures captured from the reference's own ODEGPVAE / compute_loss / autograd."""
+import types
+
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from test_gpu_forward import relerr
+
+pytestmark = pytest.mark.gpu
+
+CASES = [('model_rbf1_tiny', dict(), 2), ('model_rbf2_tiny', dict(ode=2, D_in=6, D_out=3, latent_dim=3, solver='euler'), 1),
+         ('model_df1_tiny', dict(kernel='DF'), 1)]
+
+
+def make_model(name, kw, L):
+    from vae_gp_ode_amd.model.create_model import build_model
+    a = dict(D_in=6, D_out=6, num_inducing=16, num_features=32, dimwise=True, q_diag=False, device='cuda', kernel='RBF',
+             ode=1, solver='rk4', use_adjoint=False, frames=5, n_filt=8, latent_dim=6, Ndata=360, dt=0.1)
+    a.update(kw)
+    g = load_golden(name)
+    m = build_model(types.SimpleNamespace(**a)).cuda()
+    m.load_state_dict(sub(g, 'sd.'))
+    gp = m.flow.odefunc.diffeq
+    gp.set_noise(*[{k: v.cuda() for k, v in sub(g, 'noise%d.' % l).items()} for l in range(L)])
+    m.vae.encoder.next_eps = g['eps_s'].cuda()
+    if a['ode'] == 2:
+        m.vae.encoder_v.next_eps = g['eps_v'].cuda()
+    return m, g
+
+
+@pytest.mark.parametrize('name,kw,L', CASES)
+def test_forward_matches_reference(name, kw, L):
+    m, g = make_model(name, kw, L)
+    f = load_golden(name + '_fwd')
+    with torch.no_grad():
+        Xrec, (s_mu, s_logv), (v_mu, v_logv) = m(g['X'].cuda(), L)
+    assert relerr(s_mu, f['s_mu']) < 2e-5 and relerr(s_logv, f['s_logv']) < 2e-5
+    if v_mu is not None:
+        assert relerr(v_mu, f['v_mu']) < 2e-5 and relerr(v_logv, f['v_logv']) < 2e-5
+    assert relerr(Xrec, f['Xrec']) < 2e-4
+    # BatchNorm running statistics were updated exactly once, like the reference's forward
+    for k, v in sub(g, 'sd_after.').items():
+        if 'num_batches' in k:
+            continue
+        assert relerr(m.state_dict()[k], v) < 1e-4, k
+
+
+@pytest.mark.parametrize('name,kw,L', CASES)
+def test_loss_and_gradients_match_reference(name, kw, L):
+    from vae_gp_ode_amd.model.create_model import compute_loss
+    m, g = make_model(name, kw, L)
+    loss, nlhood, kl_reg, kl_u = compute_loss(m, g['X'].cuda(), L)
+    for got, key in ((loss, 'loss'), (nlhood, 'nlhood'), (kl_reg, 'kl_reg'), (kl_u, 'kl_u')):
+        assert relerr(got, g[key]) < 1e-4, key
+    loss.backward()
+    gr = sub(g, 'grad.')
+    # fp64 twin of the reference's gradients (oracle), to calibrate the tolerance of the ill-conditioned cases
+    from oracle import gpode_oracle as O
+    sd64 = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v)
+            for k, v in sub(g, 'sd.').items()}
+    a = dict(kernel='RBF', ode=1, solver='rk4'); a.update(kw)
+    r64 = O.compute_loss(g['X'].double(), sd64, [O.to_dtype(sub(g, 'noise%d.' % l), torch.float64) for l in range(L)],
+                         g['eps_s'].double(), g['eps_v'].double() if 'eps_v' in g else None, kernel=a['kernel'],
+                         order=a['ode'], method=a['solver'], dt=0.1, Ndata=360)
+    r64['loss'].backward()
+    dead_bias = {'cnn.0.bias', 'cnn.3.bias', 'decnn.1.bias', 'decnn.4.bias', 'decnn.7.bias'}  # feed a BatchNorm: true gradient 0
+    params = dict(m.named_parameters())
+    errs, worst = {}, 0.0
+    for k, ref in gr.items():
+        got = params[k].grad
+        if any(k.endswith(d) for d in dead_bias):
+            wscale = gr[k[:-4] + 'weight'].abs().max().item()
+            assert got.abs().max().item() <= 2e-3 * wscale + 1e-5, k
+            continue
+        tol = 5e-3 + 3 * relerr(ref, sd64[k].grad)
+        errs[k] = relerr(got, ref)
+        worst = max(worst, errs[k] / tol)
+    print(name, {k.split('.', 2)[-1]: '%.1e' % v for k, v in errs.items() if v > 2e-4})
+    # model_rbf1_tiny holds ONE decoder BatchNorm+ReLU output that is 3.1e-7 in the reference (and in fp64) and
+    # exactly 0 on the HIP path (fp32 round-off on either side of the ReLU kink; tools/debug_kink.py finds it).
+    # The gradient of a piecewise-linear net jumps there, so every gradient of this fixture moves by 0.1-0.7 %;
+    # with that unit masked the same way all gradients agree to 1e-6.  Hence the wider bound for this one case.
+    base = 1e-2 if name == 'model_rbf1_tiny' else 5e-3
+    for k, ref in gr.items():
+        if k in errs:
+            assert errs[k] < base + 3 * relerr(ref, sd64[k].grad), (k, errs[k])

@@ -34,6 +34,28 @@ SIGNATURES = {
     'gpode_param_grad': (_i, [_i] * 5 + [_c_float_p, _c_float_p, _c_float_p, _i, _c_float_p, _i, _c_float_p, _i, ctypes.c_void_p]),
 }
 
+_sz = ctypes.c_size_t
+_f = ctypes.c_float
+_vp = ctypes.c_void_p
+SIGNATURES.update({
+    'gpode_conv2d_fwd': (_i, [_c_float_p] * 4 + [_i] * 10 + [_vp]),
+    'gpode_conv2d_bwd_data': (_i, [_c_float_p] * 4 + [_i] * 10 + [_vp]),
+    'gpode_conv_wgrad_scratch': (_sz, [_i, _i, _i, _i]),
+    'gpode_conv2d_bwd_weight': (_i, [_c_float_p] * 5 + [_i] * 10 + [_vp]),
+    'gpode_bn_scratch': (_sz, [_i, _i]),
+    'gpode_bn_fwd': (_i, [_c_float_p] * 8 + [_f, _f, _i, _i, _i, _i, _c_float_p, _vp]),
+    'gpode_bn_bwd': (_i, [_c_float_p] * 9 + [_i, _i, _i, _i, _c_float_p, _vp]),
+    'gpode_chan_sum': (_i, [_c_float_p, _c_float_p, _i, _i, _i, _c_float_p, _vp]),
+    'gpode_act_fwd': (_i, [_c_float_p, _c_float_p, _sz, _i, _vp]),
+    'gpode_act_bwd': (_i, [_c_float_p, _c_float_p, _c_float_p, _sz, _i, _vp]),
+    'gpode_linear_fwd': (_i, [_c_float_p] * 4 + [_i, _i, _i, _vp]),
+    'gpode_linear_bwd': (_i, [_c_float_p] * 6 + [_i, _i, _i, _vp]),
+    'gpode_loglik_fwd': (_i, [_c_float_p] * 3 + [_sz, _sz, _vp]),
+    'gpode_loglik_bwd': (_i, [_c_float_p] * 4 + [_sz, _sz, _vp]),
+    'gpode_loglik_rowsum_fwd': (_i, [_c_float_p] * 3 + [_sz, _sz, _sz, _vp]),
+    'gpode_loglik_rowsum_bwd': (_i, [_c_float_p] * 4 + [_sz, _sz, _sz, _vp]),
+})
+
 _lib = None
 
 

@@ -112,4 +112,64 @@ int gpode_cache_build_bwd(int kernel, int Di, int Do, int M, int S,
                              g_raw_ell, g_raw_var, g_Z, g_Um, g_Us, (hipStream_t)stream);
 }
 
+// ---- conv VAE blocks -----------------------------------------------------------------------
+#define GP_ST ((hipStream_t)stream)
+int gpode_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co,
+                     int K, int S, int P, int Ho, int Wo, void* stream) {
+  if (!x || !w || !y) return gp::set_error("gpode_conv2d_fwd: null pointer");
+  return gp::conv2d_fwd(x, w, bias, y, B, Ci, H, W, Co, K, S, P, Ho, Wo, GP_ST);
+}
+int gpode_conv2d_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co,
+                          int K, int S, int P, int Ho, int Wo, void* stream) {
+  if (!gy || !w || !gx) return gp::set_error("gpode_conv2d_bwd_data: null pointer");
+  return gp::conv2d_bwd_data(gy, w, bias, gx, B, Ci, H, W, Co, K, S, P, Ho, Wo, GP_ST);
+}
+size_t gpode_conv_wgrad_scratch(int B, int Ci, int Co, int K) { return gp::conv_wgrad_scratch(B, Ci, Co, K); }
+int gpode_conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci, int H, int W,
+                            int Co, int K, int S, int P, int Ho, int Wo, void* stream) {
+  if (!x || !gy || !gw || !scratch) return gp::set_error("gpode_conv2d_bwd_weight: null pointer");
+  return gp::conv2d_bwd_weight(x, gy, gw, gbias, scratch, B, Ci, H, W, Co, K, S, P, Ho, Wo, GP_ST);
+}
+size_t gpode_bn_scratch(int B, int C) { return gp::bn_scratch(B, C); }
+int gpode_bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
+                 float* running_mean, float* running_var, float momentum, float eps, int B, int C, int HW, int relu,
+                 float* scratch, void* stream) {
+  if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !scratch) return gp::set_error("gpode_bn_fwd: null pointer");
+  return gp::bn_fwd(x, gamma, beta, y, save_mean, save_invstd, running_mean, running_var, momentum, eps, B, C, HW, relu, scratch, GP_ST);
+}
+int gpode_bn_bwd(const float* x, const float* y, const float* gy, const float* gamma, const float* save_mean,
+                 const float* save_invstd, float* gx, float* ggamma, float* gbeta, int B, int C, int HW, int relu,
+                 float* scratch, void* stream) {
+  if (!x || !y || !gy || !gamma || !save_mean || !save_invstd || !gx || !ggamma || !gbeta || !scratch)
+    return gp::set_error("gpode_bn_bwd: null pointer");
+  return gp::bn_bwd(x, y, gy, gamma, save_mean, save_invstd, gx, ggamma, gbeta, B, C, HW, relu, scratch, GP_ST);
+}
+int gpode_chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, void* stream) {
+  if (!v || !out || !scratch) return gp::set_error("gpode_chan_sum: null pointer");
+  return gp::chan_sum(v, out, B, C, HW, scratch, GP_ST);
+}
+int gpode_act_fwd(const float* x, float* y, size_t n, int mode, void* stream) { return gp::act_fwd(x, y, n, mode, GP_ST); }
+int gpode_act_bwd(const float* y, const float* gy, float* gx, size_t n, int mode, void* stream) { return gp::act_bwd(y, gy, gx, n, mode, GP_ST); }
+int gpode_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, void* stream) {
+  if (!x || !w || !y) return gp::set_error("gpode_linear_fwd: null pointer");
+  return gp::linear_fwd(x, w, bias, y, B, In, Out, GP_ST);
+}
+int gpode_linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out,
+                     void* stream) {
+  if (!x || !w || !gy) return gp::set_error("gpode_linear_bwd: null pointer");
+  return gp::linear_bwd(x, w, gy, gx, gw, gb, B, In, Out, GP_ST);
+}
+int gpode_loglik_fwd(const float* X, const float* z, float* ll, size_t n, size_t nX, void* stream) { return gp::loglik_fwd(X, z, ll, n, nX, GP_ST); }
+int gpode_loglik_bwd(const float* X, const float* z, const float* g, float* gz, size_t n, size_t nX, void* stream) {
+  return gp::loglik_bwd(X, z, g, gz, n, nX, GP_ST);
+}
+int gpode_loglik_rowsum_fwd(const float* X, const float* z, float* out, size_t rows, size_t inner, size_t nX, void* stream) {
+  return gp::loglik_rowsum_fwd(X, z, out, rows, inner, nX, GP_ST);
+}
+int gpode_loglik_rowsum_bwd(const float* X, const float* z, const float* grow, float* gz, size_t rows, size_t inner, size_t nX,
+                            void* stream) {
+  return gp::loglik_rowsum_bwd(X, z, grow, gz, rows, inner, nX, GP_ST);
+}
+#undef GP_ST
+
 }  // extern "C"

@@ -164,12 +164,14 @@ __device__ __forceinline__ void rbf_ind_record_half(const float4 (&r)[RbfLayout<
   float t2[DI];
 #pragma unroll
   for (int i = 0; i < DI; ++i) { float d = x[i] - f[i]; t2[i] = d * d; }
-  const float* wlh = wl + half * DH * DI;  // wave-uniform base -> scalar loads
 #pragma unroll
   for (int dd = 0; dd < DH; ++dd) {
+    // wave-uniform row of wl (scalar loads); the upper half of an odd DO has one row less: clamp, its
+    // coefficient is zero anyway but the exponent must stay finite (0 * inf = NaN)
+    const float* wlh = wl + ((half * DH + dd < DO) ? half * DH + dd : 0) * DI;
     float e = 0.f;
 #pragma unroll
-    for (int i = 0; i < DI; ++i) e = fmaf(wlh[dd * DI + i], t2[i], e);
+    for (int i = 0; i < DI; ++i) e = fmaf(wlh[i], t2[i], e);
     const float c_lo = f[DI + dd];
     const float c_hi = (DH + dd < DO) ? f[DI + (DH + dd < DO ? DH + dd : 0)] : 0.f;
     const float v = (half ? c_hi : c_lo) * exp2_fast(e);
@@ -254,16 +256,16 @@ __device__ __forceinline__ void rbf_ind_half_bwd(const float4 (&r)[RbfLayout<DI,
   float dl[DI], t2[DI];
 #pragma unroll
   for (int i = 0; i < DI; ++i) { dl[i] = x[i] - f[i]; t2[i] = dl[i] * dl[i]; }
-  const float* wlh = wl + half * DH * DI;
   float gxi[DI];
 #pragma unroll
   for (int i = 0; i < DI; ++i) gxi[i] = 0.f;
 #pragma unroll
   for (int dd = 0; dd < DH; ++dd) {
     const bool hi_ok = DH + dd < DO;
+    const float* wlh = wl + ((half * DH + dd < DO) ? half * DH + dd : 0) * DI;  // clamped, see rbf_ind_record_half
     float e = 0.f;
 #pragma unroll
-    for (int i = 0; i < DI; ++i) e = fmaf(wlh[dd * DI + i], t2[i], e);
+    for (int i = 0; i < DI; ++i) e = fmaf(wlh[i], t2[i], e);
     const float E = exp2_fast(e);
     const float c_lo = f[DI + dd], c_hi = hi_ok ? f[DI + (hi_ok ? DH + dd : 0)] : 0.f;
     const float a_lo = a[dd], a_hi = hi_ok ? a[hi_ok ? DH + dd : 0] : 0.f;
@@ -271,7 +273,7 @@ __device__ __forceinline__ void rbf_ind_half_bwd(const float4 (&r)[RbfLayout<DI,
     const float aE = ad * E;           // d L / d cc
     const float w = aE * cc * GP_LN2;  // d L / d e
 #pragma unroll
-    for (int i = 0; i < DI; ++i) gxi[i] = fmaf(w * wlh[dd * DI + i], 2.f * dl[i], gxi[i]);
+    for (int i = 0; i < DI; ++i) gxi[i] = fmaf(w * wlh[i], 2.f * dl[i], gxi[i]);
     if (WITH_G) {
       g[DI + dd] += half ? 0.f : aE;
       if (hi_ok) g[DI + (hi_ok ? DH + dd : 0)] += half ? aE : 0.f;

@@ -57,4 +57,28 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
                     const float* eps_u, const float* pack, const float* ws, float* gpack, float* bws,
                     float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, hipStream_t st);
 
+// conv VAE blocks (vae_conv.hip)
+int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S,
+               int P, int Ho, int Wo, hipStream_t st);
+int conv2d_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co, int K, int S,
+                    int P, int Ho, int Wo, hipStream_t st);
+size_t conv_wgrad_scratch(int B, int Ci, int Co, int K);
+int conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci, int H, int W, int Co,
+                      int K, int S, int P, int Ho, int Wo, hipStream_t st);
+size_t bn_scratch(int B, int C);
+int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
+           float* running_mean, float* running_var, float momentum, float eps, int B, int C, int HW, int relu,
+           float* scratch, hipStream_t st);
+int bn_bwd(const float* x, const float* y, const float* gy, const float* gamma, const float* save_mean, const float* save_invstd,
+           float* gx, float* ggamma, float* gbeta, int B, int C, int HW, int relu, float* scratch, hipStream_t st);
+int chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, hipStream_t st);
+int act_fwd(const float* x, float* y, size_t n, int mode, hipStream_t st);
+int act_bwd(const float* y, const float* gy, float* gx, size_t n, int mode, hipStream_t st);
+int linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, hipStream_t st);
+int linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out, hipStream_t st);
+int loglik_fwd(const float* X, const float* z, float* ll, size_t n, size_t nX, hipStream_t st);
+int loglik_bwd(const float* X, const float* z, const float* g, float* gz, size_t n, size_t nX, hipStream_t st);
+int loglik_rowsum_fwd(const float* X, const float* z, float* out, size_t rows, size_t inner, size_t nX, hipStream_t st);
+int loglik_rowsum_bwd(const float* X, const float* z, const float* grow, float* gz, size_t rows, size_t inner, size_t nX, hipStream_t st);
+
 }  // namespace gp

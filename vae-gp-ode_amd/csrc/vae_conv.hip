@@ -1,0 +1,492 @@
+// vae_conv.hip -- conv VAE building blocks (encoder vae.py:47-98, decoder vae.py:101-153), NCHW fp32.
+//
+// Three convolution kernels cover all seven layers, forward and backward:
+//   conv_fwd        y  = conv(x, w) + b                          Conv2d forward;  ConvTranspose2d d/d input
+//   conv_bwd_data   gx = sum_co sum_taps gy * w  (+ b)           Conv2d d/d input; ConvTranspose2d FORWARD
+//   conv_bwd_weight gw = sum_{b,oy,ox} gy * x                    both (roles of x / gy swap for ConvTranspose2d)
+// nn.ConvTranspose2d stores its weight as (C_in, C_out, k, k), which is exactly the (Co, Ci, k, k) weight of
+// the convolution it is the adjoint of -- the same buffer serves both directions.
+// K (kernel size) and STRIDE are template parameters so the tap loops unroll and the stride test of the
+// transposed direction folds into the loop bounds (only contributing taps are visited).
+//
+// Round-1 status: direct (gather) form, one thread per output element, weights/inputs through L1/L2.
+// This is the correctness baseline of the decoder; the LDS-resident implicit-GEMM MFMA version of the two
+// FLOP-dominant layers (decnn.4, decnn.7) is the next optimisation step.
+#include <hip/hip_runtime.h>
+#include "gp_launch.hpp"
+#include "wave_reduce.hpp"
+
+namespace gp {
+
+struct ConvDims { int B, Ci, H, W, Co, P, Ho, Wo; };
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void k_conv_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ y, ConvDims d) {
+  const size_t total = (size_t)d.B * d.Co * d.Ho * d.Wo;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(e % d.Wo), oy = (int)((e / d.Wo) % d.Ho), co = (int)((e / ((size_t)d.Wo * d.Ho)) % d.Co);
+    const int b = (int)(e / ((size_t)d.Wo * d.Ho * d.Co));
+    float acc = bias ? bias[co] : 0.f;
+    const int iy0 = oy * S - d.P, ix0 = ox * S - d.P;
+    const float* xb = x + (size_t)b * d.Ci * d.H * d.W;
+    const float* wc = w + (size_t)co * d.Ci * K * K;
+    for (int ci = 0; ci < d.Ci; ++ci) {
+      const float* xc = xb + (size_t)ci * d.H * d.W;
+      const float* wk = wc + ci * K * K;
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const int iy = iy0 + ky;
+        if (iy < 0 || iy >= d.H) continue;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const int ix = ix0 + kx;
+          if (ix < 0 || ix >= d.W) continue;
+          acc = fmaf(xc[iy * d.W + ix], wk[ky * K + kx], acc);
+        }
+      }
+    }
+    y[e] = acc;
+  }
+}
+
+// gx[b,ci,iy,ix] = bias[ci] + sum_{co,ky,kx} gy[b,co,oy,ox] w[co,ci,ky,kx],  oy = (iy + P - ky)/S when divisible
+template <int K, int S>
+__global__ __launch_bounds__(256) void k_conv_bwd_data(const float* __restrict__ gy, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ gx, ConvDims d) {
+  const size_t total = (size_t)d.B * d.Ci * d.H * d.W;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int ix = (int)(e % d.W), iy = (int)((e / d.W) % d.H), ci = (int)((e / ((size_t)d.W * d.H)) % d.Ci);
+    const int b = (int)(e / ((size_t)d.W * d.H * d.Ci));
+    float acc = bias ? bias[ci] : 0.f;
+    const float* gb = gy + (size_t)b * d.Co * d.Ho * d.Wo;
+    const int ky0 = (iy + d.P) % S, kx0 = (ix + d.P) % S;  // only taps with (iy + P - ky) % S == 0 contribute
+    for (int co = 0; co < d.Co; ++co) {
+      const float* gc = gb + (size_t)co * d.Ho * d.Wo;
+      const float* wk = w + ((size_t)co * d.Ci + ci) * K * K;
+#pragma unroll
+      for (int t = 0; t < (K + S - 1) / S; ++t) {
+        const int ky = ky0 + t * S;
+        if (ky >= K) continue;
+        const int oy = (iy + d.P - ky) / S;
+        if (iy + d.P - ky < 0 || oy >= d.Ho) continue;
+#pragma unroll
+        for (int u = 0; u < (K + S - 1) / S; ++u) {
+          const int kx = kx0 + u * S;
+          if (kx >= K) continue;
+          const int ox = (ix + d.P - kx) / S;
+          if (ix + d.P - kx < 0 || ox >= d.Wo) continue;
+          acc = fmaf(gc[oy * d.Wo + ox], wk[ky * K + kx], acc);
+        }
+      }
+    }
+    gx[e] = acc;
+  }
+}
+
+// gw[co,ci,ky,kx] = sum_{b,oy,ox} gy[b,co,oy,ox] x[b,ci,oy*S-P+ky,ox*S-P+kx].  grid (Co*Ci, nsplit): each workgroup
+// sums a slice of the batch for one (co,ci) pair into part[split][co][ci][K*K]; a second kernel adds the splits.
+template <int K, int S>
+__global__ __launch_bounds__(256) void k_conv_bwd_weight(const float* __restrict__ x, const float* __restrict__ gy,
+                                                          float* __restrict__ part, ConvDims d, int b_per_split) {
+  __shared__ float red[4][K * K];
+  const int co = blockIdx.x / d.Ci, ci = blockIdx.x % d.Ci;
+  const int b0 = blockIdx.y * b_per_split, b1 = min(d.B, b0 + b_per_split);
+  float acc[K * K];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) acc[t] = 0.f;
+  const int npix = d.Ho * d.Wo;
+  const size_t work = (size_t)(b1 - b0) * npix;
+  for (size_t e = threadIdx.x; e < work; e += 256) {
+    const int b = b0 + (int)(e / npix), p = (int)(e % npix);
+    const int oy = p / d.Wo, ox = p % d.Wo;
+    const float g = gy[((size_t)b * d.Co + co) * npix + p];
+    const float* xc = x + ((size_t)b * d.Ci + ci) * d.H * d.W;
+    const int iy0 = oy * S - d.P, ix0 = ox * S - d.P;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = iy0 + ky;
+      const bool oky = iy >= 0 && iy < d.H;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const int ix = ix0 + kx;
+        const float xv = (oky && ix >= 0 && ix < d.W) ? xc[iy * d.W + ix] : 0.f;
+        acc[ky * K + kx] = fmaf(g, xv, acc[ky * K + kx]);
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) {
+    const float s = row_allreduce16(acc[t]);  // 16-lane rows; the four rows are added below
+    float tot = GP_LANE(s, 0) + GP_LANE(s, 16) + GP_LANE(s, 32) + GP_LANE(s, 48);
+    if (lane == 0) red[wv][t] = tot;
+  }
+  __syncthreads();
+  if (threadIdx.x < K * K)
+    part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (K * K) + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void k_sum_splits(const float* __restrict__ part, int nsplit, size_t n, float* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float acc = 0.f;
+  for (int s = 0; s < nsplit; ++s) acc += part[(size_t)s * n + e];
+  out[e] = acc;
+}
+
+// per-channel sum over (B, HW) of v (and optionally of v*u): part[split][c][2]; grid (C, nsplit)
+__global__ __launch_bounds__(256) void k_chan_sums(const float* __restrict__ v, const float* __restrict__ u, int B, int C, int HW,
+                                                    int b_per_split, float* __restrict__ part) {
+  __shared__ float red[4][2];
+  const int c = blockIdx.x;
+  const int b0 = blockIdx.y * b_per_split, b1 = min(B, b0 + b_per_split);
+  float s0 = 0.f, s1 = 0.f;
+  const size_t work = (size_t)(b1 - b0) * HW;
+  for (size_t e = threadIdx.x; e < work; e += 256) {
+    const int b = b0 + (int)(e / HW), p = (int)(e % HW);
+    const size_t idx = ((size_t)b * C + c) * HW + p;
+    const float a = v[idx];
+    s0 += a;
+    s1 = fmaf(a, u ? u[idx] : a, s1);
+  }
+  float in2[2] = {s0, s1}, out2[2];
+  wave_sum_multi<2>(in2, out2);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = out2[0]; red[threadIdx.x >> 6][1] = out2[1]; }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    part[((size_t)blockIdx.y * C + c) * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// part[split][c][0] = sum (v - mean[c])^2 over the split (second pass of the variance: no E[x^2]-E[x]^2 cancellation)
+__global__ __launch_bounds__(256) void k_chan_sqdev(const float* __restrict__ v, const float* __restrict__ mean, int B, int C, int HW,
+                                                     int b_per_split, float* __restrict__ part) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  const int b0 = blockIdx.y * b_per_split, b1 = min(B, b0 + b_per_split);
+  const float m = mean[c];
+  float s0 = 0.f;
+  const size_t work = (size_t)(b1 - b0) * HW;
+  for (size_t e = threadIdx.x; e < work; e += 256) {
+    const int b = b0 + (int)(e / HW), p = (int)(e % HW);
+    const float a = v[((size_t)b * C + c) * HW + p] - m;
+    s0 = fmaf(a, a, s0);
+  }
+  float in1[1] = {s0}, out1[1];
+  wave_sum_multi<1>(in1, out1);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = out1[0];
+  __syncthreads();
+  if (threadIdx.x == 0) part[((size_t)blockIdx.y * C + c) * 2] = red[0] + red[1] + red[2] + red[3];
+}
+
+// out[c] = sum_s part[s][c][comp]
+__global__ void k_reduce_chan(const float* __restrict__ part, int nsplit, int C, int comp, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int s = 0; s < nsplit; ++s) a += part[((size_t)s * C + c) * 2 + comp];
+  out[c] = a;
+}
+
+// BatchNorm2d, training mode (vae.py:55,58,113,116,119): batch statistics, biased variance for the
+// normalisation, unbiased for the running estimate, momentum 0.1.
+// pass 1: mean ; pass 2: biased variance -> invstd, running statistics (unbiased variance, momentum)
+__global__ void k_bn_mean(const float* __restrict__ part, int nsplit, int C, float count, float* __restrict__ save_mean) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s0 = 0.f;
+  for (int s = 0; s < nsplit; ++s) s0 += part[((size_t)s * C + c) * 2];
+  save_mean[c] = s0 / count;
+}
+__global__ void k_bn_finalize(const float* __restrict__ part, int nsplit, int C, float count, float eps, float momentum,
+                              const float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                              float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f;
+  for (int s = 0; s < nsplit; ++s) s1 += part[((size_t)s * C + c) * 2];
+  const float var = s1 / count;
+  save_invstd[c] = rsqrtf(var + eps);
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * save_mean[c];
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count / (count - 1.f));
+  }
+}
+
+__global__ void k_bn_apply(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                           const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ y,
+                           size_t total, int C, int HW, int relu) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((e / HW) % C);
+    float v = (x[e] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+    y[e] = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
+// dy -> (masked by relu) -> g ; channel sums of g and g*xhat
+__global__ __launch_bounds__(256) void k_bn_bwd_sums(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      int B, int C, int HW, int relu, int b_per_split, float* __restrict__ part) {
+  __shared__ float red[4][2];
+  const int c = blockIdx.x;
+  const int b0 = blockIdx.y * b_per_split, b1 = min(B, b0 + b_per_split);
+  float s0 = 0.f, s1 = 0.f;
+  const float m = mean[c], is = invstd[c];
+  const size_t work = (size_t)(b1 - b0) * HW;
+  for (size_t e = threadIdx.x; e < work; e += 256) {
+    const int b = b0 + (int)(e / HW), p = (int)(e % HW);
+    const size_t idx = ((size_t)b * C + c) * HW + p;
+    float g = gy[idx];
+    if (relu && !(y[idx] > 0.f)) g = 0.f;
+    s0 += g;
+    s1 = fmaf(g, (x[idx] - m) * is, s1);
+  }
+  float in2[2] = {s0, s1}, out2[2];
+  wave_sum_multi<2>(in2, out2);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = out2[0]; red[threadIdx.x >> 6][1] = out2[1]; }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    part[((size_t)blockIdx.y * C + c) * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
+                               const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+                               const float* __restrict__ part, int nsplit, float count, float* __restrict__ gx,
+                               float* __restrict__ ggamma, float* __restrict__ gbeta, size_t total, int C, int HW, int relu) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((e / HW) % C);
+    float sg = 0.f, sgx = 0.f;
+    for (int s = 0; s < nsplit; ++s) { sg += part[((size_t)s * C + c) * 2]; sgx += part[((size_t)s * C + c) * 2 + 1]; }
+    float g = gy[e];
+    if (relu && !(y[e] > 0.f)) g = 0.f;
+    const float xh = (x[e] - mean[c]) * invstd[c];
+    gx[e] = gamma[c] * invstd[c] * (g - sg / count - xh * sgx / count);
+    if (e < (size_t)C) {  // one thread per channel also publishes the affine gradients
+      float a = 0.f, bq = 0.f;
+      for (int s = 0; s < nsplit; ++s) { a += part[((size_t)s * C + e) * 2]; bq += part[((size_t)s * C + e) * 2 + 1]; }
+      gbeta[e] = a;
+      ggamma[e] = bq;
+    }
+  }
+}
+
+// elementwise activations: mode 0 relu, 1 sigmoid
+__global__ void k_act_fwd(const float* __restrict__ x, float* __restrict__ y, size_t n, int mode) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float v = x[e];
+    y[e] = mode == 0 ? fmaxf(v, 0.f) : 1.f / (1.f + expf(-v));
+  }
+}
+__global__ void k_act_bwd(const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gx, size_t n, int mode) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float v = y[e];
+    gx[e] = mode == 0 ? (v > 0.f ? gy[e] : 0.f) : gy[e] * v * (1.f - v);
+  }
+}
+
+// Linear: y[b,o] = bias[o] + sum_i x[b,i] w[o,i]
+__global__ void k_linear_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                             float* __restrict__ y, int B, int In, int Out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)B * Out) return;
+  const int b = (int)(e / Out), o = (int)(e % Out);
+  float acc = bias ? bias[o] : 0.f;
+  const float* xr = x + (size_t)b * In;
+  const float* wr = w + (size_t)o * In;
+  for (int i = 0; i < In; ++i) acc = fmaf(xr[i], wr[i], acc);
+  y[e] = acc;
+}
+__global__ void k_linear_bwd_x(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx, int B, int In, int Out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)B * In) return;
+  const int b = (int)(e / In), i = (int)(e % In);
+  float acc = 0.f;
+  for (int o = 0; o < Out; ++o) acc = fmaf(gy[(size_t)b * Out + o], w[(size_t)o * In + i], acc);
+  gx[e] = acc;
+}
+// gw[o,i] = sum_b gy[b,o] x[b,i]; gb[o] = sum_b gy[b,o].  One wave per (o,i) (i == In -> bias).
+__global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gw,
+                                                       float* __restrict__ gb, int B, int In, int Out) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= Out * (In + 1)) return;
+  const int o = wave / (In + 1), i = wave % (In + 1);
+  float acc = 0.f;
+  for (int b = lane; b < B; b += 64) acc = fmaf(gy[(size_t)b * Out + o], i < In ? x[(size_t)b * In + i] : 1.f, acc);
+  float in1[1] = {acc}, out1[1];
+  wave_sum_multi<1>(in1, out1);
+  if (lane == 0) { if (i < In) gw[(size_t)o * In + i] = out1[0]; else if (gb) gb[o] = out1[0]; }
+}
+
+// Bernoulli log-likelihood (vae.py:136-153, no epsilon -- SURVEY F9): ll = log(z) X + log(1-z) (1-X).
+// z has `reps` copies of X's extent (X.repeat([L,...])): X index = e % nX.
+__global__ void k_loglik_fwd(const float* __restrict__ X, const float* __restrict__ z, float* __restrict__ ll, size_t n, size_t nX) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float xv = X[e % nX], zv = z[e];
+    ll[e] = logf(zv) * xv + logf(1.f - zv) * (1.f - xv);
+  }
+}
+__global__ void k_loglik_bwd(const float* __restrict__ X, const float* __restrict__ z, const float* __restrict__ g,
+                             float* __restrict__ gz, size_t n, size_t nX) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float xv = X[e % nX], zv = z[e];
+    gz[e] = g[e] * (xv / zv - (1.f - xv) / (1.f - zv));
+  }
+}
+// fused reduction used by the ELBO (create_model.py:52-53): out[row] = sum over `inner` of ll; row = (l,n)
+__global__ __launch_bounds__(256) void k_loglik_rowsum(const float* __restrict__ X, const float* __restrict__ z, float* __restrict__ out,
+                                                        size_t inner, size_t nX) {
+  __shared__ float red[4];
+  const size_t row = blockIdx.x;
+  float acc = 0.f;
+  for (size_t p = threadIdx.x; p < inner; p += 256) {
+    const size_t e = row * inner + p;
+    const float xv = X[e % nX], zv = z[e];
+    acc += logf(zv) * xv + logf(1.f - zv) * (1.f - xv);
+  }
+  float in1[1] = {acc}, out1[1];
+  wave_sum_multi<1>(in1, out1);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = out1[0];
+  __syncthreads();
+  if (threadIdx.x == 0) out[row] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void k_loglik_rowsum_bwd(const float* __restrict__ X, const float* __restrict__ z, const float* __restrict__ grow,
+                                    float* __restrict__ gz, size_t n, size_t inner, size_t nX) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float xv = X[e % nX], zv = z[e];
+    gz[e] = grow[e / inner] * (xv / zv - (1.f - xv) / (1.f - zv));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+static inline int ew_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g < 8192 ? (g ? g : 1) : 8192); }
+
+#define GP_CONV_KS(X) X(5, 2) X(5, 1) X(3, 1) X(3, 2)
+
+int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S,
+               int P, int Ho, int Wo, hipStream_t st) {
+  ConvDims d{B, Ci, H, W, Co, P, Ho, Wo};
+  const size_t total = (size_t)B * Co * Ho * Wo;
+#define X(k, s) if (K == k && S == s) { hipLaunchKernelGGL((k_conv_fwd<k, s>), ew_grid(total), 256, 0, st, x, w, bias, y, d); return check_launch("conv_fwd"); }
+  GP_CONV_KS(X)
+#undef X
+  return set_error("gpode_conv2d_fwd: kernel %d stride %d not built", K, S);
+}
+
+int conv2d_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co, int K, int S,
+                    int P, int Ho, int Wo, hipStream_t st) {
+  ConvDims d{B, Ci, H, W, Co, P, Ho, Wo};
+  const size_t total = (size_t)B * Ci * H * W;
+#define X(k, s) if (K == k && S == s) { hipLaunchKernelGGL((k_conv_bwd_data<k, s>), ew_grid(total), 256, 0, st, gy, w, bias, gx, d); return check_launch("conv_bwd_data"); }
+  GP_CONV_KS(X)
+#undef X
+  return set_error("gpode_conv2d_bwd_data: kernel %d stride %d not built", K, S);
+}
+
+static inline int pick_split(int B, int nblocks_per_split) {
+  int s = 1024 / (nblocks_per_split > 0 ? nblocks_per_split : 1);  // aim for ~1024 workgroups
+  if (s < 1) s = 1;
+  if (s > B) s = B;
+  if (s > 64) s = 64;
+  return s;
+}
+
+// scratch: conv_wgrad_scratch_floats(...) floats
+size_t conv_wgrad_scratch(int B, int Ci, int Co, int K) { return (size_t)pick_split(B, Co * Ci) * Co * Ci * K * K + (size_t)64 * Co * 2; }
+
+int conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci, int H, int W, int Co,
+                      int K, int S, int P, int Ho, int Wo, hipStream_t st) {
+  ConvDims d{B, Ci, H, W, Co, P, Ho, Wo};
+  const int nsplit = pick_split(B, Co * Ci);
+  const int bps = (B + nsplit - 1) / nsplit;
+  const int used = (B + bps - 1) / bps;
+  const size_t n = (size_t)Co * Ci * K * K;
+  bool ok = false;
+#define X(k, s) if (K == k && S == s) { hipLaunchKernelGGL((k_conv_bwd_weight<k, s>), dim3(Co * Ci, used), 256, 0, st, x, gy, scratch, d, bps); ok = true; }
+  GP_CONV_KS(X)
+#undef X
+  if (!ok) return set_error("gpode_conv2d_bwd_weight: kernel %d stride %d not built", K, S);
+  hipLaunchKernelGGL(k_sum_splits, (unsigned)((n + 255) / 256), 256, 0, st, scratch, used, n, gw);
+  if (gbias) {
+    float* part = scratch + (size_t)nsplit * n;
+    const int ns2 = B < 64 ? B : 64, bps2 = (B + ns2 - 1) / ns2, used2 = (B + bps2 - 1) / bps2;
+    hipLaunchKernelGGL(k_chan_sums, dim3(Co, used2), 256, 0, st, gy, (const float*)nullptr, B, Co, Ho * Wo, bps2, part);
+    hipLaunchKernelGGL(k_reduce_chan, (Co + 63) / 64, 64, 0, st, part, used2, Co, 0, gbias);
+  }
+  return check_launch("conv_bwd_weight");
+}
+
+size_t bn_scratch(int B, int C) { return (size_t)(B < 64 ? B : 64) * C * 2; }
+
+int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
+           float* running_mean, float* running_var, float momentum, float eps, int B, int C, int HW, int relu,
+           float* scratch, hipStream_t st) {
+  const int ns = B < 64 ? B : 64, bps = (B + ns - 1) / ns, used = (B + bps - 1) / bps;
+  hipLaunchKernelGGL(k_chan_sums, dim3(C, used), 256, 0, st, x, (const float*)nullptr, B, C, HW, bps, scratch);
+  hipLaunchKernelGGL(k_bn_mean, (C + 63) / 64, 64, 0, st, scratch, used, C, (float)B * HW, save_mean);
+  hipLaunchKernelGGL(k_chan_sqdev, dim3(C, used), 256, 0, st, x, save_mean, B, C, HW, bps, scratch);
+  hipLaunchKernelGGL(k_bn_finalize, (C + 63) / 64, 64, 0, st, scratch, used, C, (float)B * HW, eps, momentum, save_mean, save_invstd,
+                     running_mean, running_var);
+  const size_t total = (size_t)B * C * HW;
+  hipLaunchKernelGGL(k_bn_apply, ew_grid(total), 256, 0, st, x, gamma, beta, save_mean, save_invstd, y, total, C, HW, relu);
+  return check_launch("bn_fwd");
+}
+
+int bn_bwd(const float* x, const float* y, const float* gy, const float* gamma, const float* save_mean, const float* save_invstd,
+           float* gx, float* ggamma, float* gbeta, int B, int C, int HW, int relu, float* scratch, hipStream_t st) {
+  const int ns = B < 64 ? B : 64, bps = (B + ns - 1) / ns, used = (B + bps - 1) / bps;
+  hipLaunchKernelGGL(k_bn_bwd_sums, dim3(C, used), 256, 0, st, x, y, gy, save_mean, save_invstd, B, C, HW, relu, bps, scratch);
+  const size_t total = (size_t)B * C * HW;
+  hipLaunchKernelGGL(k_bn_bwd_apply, ew_grid(total), 256, 0, st, x, y, gy, gamma, save_mean, save_invstd, scratch, used,
+                     (float)B * HW, gx, ggamma, gbeta, total, C, HW, relu);
+  return check_launch("bn_bwd");
+}
+
+// out[c] = sum over (b, hw) of v[b,c,hw]   (bias gradient of ConvTranspose2d / Conv2d)
+int chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, hipStream_t st) {
+  const int ns = B < 64 ? B : 64, bps = (B + ns - 1) / ns, used = (B + bps - 1) / bps;
+  hipLaunchKernelGGL(k_chan_sums, dim3(C, used), 256, 0, st, v, (const float*)nullptr, B, C, HW, bps, scratch);
+  hipLaunchKernelGGL(k_reduce_chan, (C + 63) / 64, 64, 0, st, scratch, used, C, 0, out);
+  return check_launch("chan_sum");
+}
+
+int act_fwd(const float* x, float* y, size_t n, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(k_act_fwd, ew_grid(n), 256, 0, st, x, y, n, mode);
+  return check_launch("act_fwd");
+}
+int act_bwd(const float* y, const float* gy, float* gx, size_t n, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(k_act_bwd, ew_grid(n), 256, 0, st, y, gy, gx, n, mode);
+  return check_launch("act_bwd");
+}
+
+int linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, hipStream_t st) {
+  hipLaunchKernelGGL(k_linear_fwd, (unsigned)(((size_t)B * Out + 255) / 256), 256, 0, st, x, w, bias, y, B, In, Out);
+  return check_launch("linear_fwd");
+}
+int linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out, hipStream_t st) {
+  if (gx) hipLaunchKernelGGL(k_linear_bwd_x, (unsigned)(((size_t)B * In + 255) / 256), 256, 0, st, gy, w, gx, B, In, Out);
+  if (gw) hipLaunchKernelGGL(k_linear_bwd_w, (unsigned)(((size_t)Out * (In + 1) * 64 + 255) / 256), 256, 0, st, x, gy, gw, gb, B, In, Out);
+  return check_launch("linear_bwd");
+}
+
+int loglik_fwd(const float* X, const float* z, float* ll, size_t n, size_t nX, hipStream_t st) {
+  hipLaunchKernelGGL(k_loglik_fwd, ew_grid(n), 256, 0, st, X, z, ll, n, nX);
+  return check_launch("loglik_fwd");
+}
+int loglik_bwd(const float* X, const float* z, const float* g, float* gz, size_t n, size_t nX, hipStream_t st) {
+  hipLaunchKernelGGL(k_loglik_bwd, ew_grid(n), 256, 0, st, X, z, g, gz, n, nX);
+  return check_launch("loglik_bwd");
+}
+int loglik_rowsum_fwd(const float* X, const float* z, float* out, size_t rows, size_t inner, size_t nX, hipStream_t st) {
+  hipLaunchKernelGGL(k_loglik_rowsum, (unsigned)rows, 256, 0, st, X, z, out, inner, nX);
+  return check_launch("loglik_rowsum");
+}
+int loglik_rowsum_bwd(const float* X, const float* z, const float* grow, float* gz, size_t rows, size_t inner, size_t nX, hipStream_t st) {
+  const size_t n = rows * inner;
+  hipLaunchKernelGGL(k_loglik_rowsum_bwd, ew_grid(n), 256, 0, st, X, z, grow, gz, n, inner, nX);
+  return check_launch("loglik_rowsum_bwd");
+}
+
+}  // namespace gp

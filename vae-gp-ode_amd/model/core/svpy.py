@@ -40,18 +40,18 @@ class SVGP_Layer(torch.nn.Module):
                              transform=transforms.LowerTriangular(M, D_out, device=self.device),
                              name='Inducing distribution (scale)')
         self.noise_source = NumpyNoise()
-        self._next_noise = None
+        self._next_noise = []
         self.cache = None
 
     # -- randomness ---------------------------------------------------------------------------
-    def set_noise(self, noise):
-        """Use this dict (see core/noise.py) for the next build_cache() instead of drawing."""
-        self._next_noise = noise
+    def set_noise(self, *noises):
+        """Queue explicit draws (dicts, see core/noise.py): each build_cache() consumes one instead of drawing."""
+        self._next_noise.extend(noises)
 
     def _take_noise(self):
         dev = self.inducing_loc.optvar.device
-        if self._next_noise is not None:
-            nz, self._next_noise = self._next_noise, None
+        if self._next_noise:
+            nz = self._next_noise.pop(0)
             return {k: v.to(dev) for k, v in nz.items()}
         return self.noise_source.draw(self.kernel_n, self.D_in, self.D_out, self.M, self.S, dev)
 
@@ -64,7 +64,7 @@ class SVGP_Layer(torch.nn.Module):
     def build_cache(self, noise=None, want_Lu=False):
         """Fix one function draw: Fourier features, inducing sample, nu (svpy.py:103-121)."""
         if noise is not None:
-            self._next_noise = noise
+            self._next_noise.insert(0, noise)
         nz = self._take_noise()
         k = self.kern
         self.cache = ops.cache_build(self.kernel_n, k.unconstrained_lengthscales.detach(), k.unconstrained_variance.detach(),

@@ -1,9 +1,12 @@
 """Conv VAE (operator API and state_dict layout of experiments/model/core/vae.py).
 
-ROUND-1 STATUS: the encoder/decoder modules below keep the reference's parameter names and shapes
-(``cnn.{0,3,6}``, ``fc``, ``decnn.{1,4,7,10}`` ...) so checkpoints interchange, but their arithmetic is
-still dispatched by torch.nn (MIOpen/rocBLAS on the GPU) -- the hand-written implicit-GEMM conv + BN +
-Bernoulli log-likelihood kernels are the next row of the build plan ("what comes next").
+The ``nn.Sequential`` containers below exist for their parameters, buffers and ``state_dict`` keys
+(``cnn.{0,3,6}``, ``fc``, ``decnn.{1,4,7,10}``, BatchNorm running statistics ...), which are the reference's,
+so checkpoints interchange.  The arithmetic -- convolutions, transposed convolutions, training-mode
+BatchNorm, ReLU/sigmoid, the linear layers and the Bernoulli log-likelihood, forward and backward -- runs in
+the hand-written HIP kernels of csrc/vae_conv.hip through ``vae_ops``; nothing is dispatched to torch.nn.
+BatchNorm runs on batch statistics exactly as the reference's training loop does (it never calls
+``.eval()``); eval-mode BatchNorm (only reached via ``--pretrained`` / ``VAE.test``) is not built.
 """
 import numpy as np
 import torch
@@ -11,6 +14,14 @@ import torch.nn as nn
 from torch.distributions import Normal
 
 from ..misc.torch_utils import UnFlatten
+from ... import vae_ops as V
+
+
+def _bn(x, bn, relu):
+    if not bn.training:
+        raise NotImplementedError('eval-mode BatchNorm is outside the accelerated path (the reference trains and '
+                                  'evaluates with batch statistics, SURVEY F11)')
+    return V.batch_norm_train(x, bn, relu)
 
 EPSILON = 1e-3
 
@@ -28,11 +39,24 @@ class Encoder(nn.Module):
         self.fc = nn.Linear(n_filt * 4 ** 3, 2 * latent_dim)
 
     def forward(self, x):
-        return self.fc(self.cnn(x)).chunk(2, dim=-1)
+        c = self.cnn
+        h = V.conv2d(x.contiguous(), c[0].weight, c[0].bias, 2, 2)
+        h = _bn(h, c[1], relu=True)
+        h = V.conv2d(h, c[3].weight, c[3].bias, 2, 2)
+        h = _bn(h, c[4], relu=True)
+        h = V.relu(V.conv2d(h, c[6].weight, c[6].bias, 2, 2))
+        z = V.linear(h.flatten(1), self.fc.weight, self.fc.bias)
+        return z.chunk(2, dim=-1)
 
     def sample(self, mu, logvar):
+        """Reparameterised draw (vae.py:75-78).  ``next_eps`` (if set) replaces the N(0,1) draw once --
+        used for parity tests and for data-parallel runs that must share the draw."""
         std = torch.exp(0.5 * logvar)
-        return mu + std * torch.randn_like(std)
+        eps = getattr(self, 'next_eps', None)
+        if eps is None:
+            eps = torch.randn_like(std)
+        self.next_eps = None
+        return mu + std * eps.to(std)
 
     def q_dist(self, mu_s, logvar_s, mu_v=None, logvar_v=None):
         if mu_v is not None:
@@ -63,7 +87,13 @@ class Decoder(nn.Module):
 
     def forward(self, x):
         flat = x.contiguous().view([int(np.prod(list(x.shape[:-1]))), x.shape[-1]])
-        return self.decnn(self.fc(flat))
+        d = self.decnn
+        h = V.linear(flat, self.fc.weight, self.fc.bias)
+        h = h.view(h.size(0), h[0].numel() // 16, 4, 4)                                   # UnFlatten(4)
+        h = _bn(V.conv_transpose2d(h, d[1].weight, d[1].bias, 1, 0), d[2], relu=True)     # 4 -> 6
+        h = _bn(V.conv_transpose2d(h, d[4].weight, d[4].bias, 2, 1), d[5], relu=True)     # 6 -> 13
+        h = _bn(V.conv_transpose2d(h, d[7].weight, d[7].bias, 2, 1, 1), d[8], relu=True)  # 13 -> 28
+        return V.sigmoid(V.conv_transpose2d(h, d[10].weight, d[10].bias, 1, 2))
 
     @property
     def device(self):
@@ -71,10 +101,14 @@ class Decoder(nn.Module):
 
     def log_prob(self, x, z, L=1, pretrain=False):
         """Bernoulli log-likelihood of targets x under reconstructions z (vae.py:136-153); no epsilon."""
-        XL = x if pretrain else x.repeat([L, 1, 1, 1, 1, 1])
         if self.distribution != 'bernoulli':
             raise ValueError('Currently only bernoulli dist implemented')
-        return torch.log(z) * XL + torch.log(1 - z) * (1 - XL)
+        return V.bernoulli_loglik(x, z)  # x is broadcast over the L leading copies of z inside the kernel
+
+    def log_prob_rowsum(self, x, z, L=1):
+        """sum over (T,c,h,w) of log_prob, shape (L,N): the reduction create_model.elbo applies, fused."""
+        N = x.shape[0]
+        return V.bernoulli_loglik_rowsum(x, z, L * N).view(L, N)
 
 
 class VAE(nn.Module):

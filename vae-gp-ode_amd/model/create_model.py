@@ -20,7 +20,7 @@ def elbo(model, X, Xrec, s0_mu, s0_logv, v0_mu, v0_logv, L):
     """-> (mean log-likelihood per sequence, mean KL(q(z0)||p), KL(q(u)||p)) (create_model.py:37-58)."""
     q = model.vae.encoder.q_dist(s0_mu, s0_logv, v0_mu, v0_logv)
     kl_reg = kl(q, model.vae.prior).sum(-1)
-    lhood = model.vae.decoder.log_prob(X, Xrec, L).sum([2, 3, 4, 5]).mean(0)
+    lhood = model.vae.decoder.log_prob_rowsum(X, Xrec, L).mean(0)  # == log_prob(...).sum([2,3,4,5]).mean(0)
     return lhood.mean(), kl_reg.mean(), model.flow.kl()
 
 

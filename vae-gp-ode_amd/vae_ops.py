@@ -1,0 +1,232 @@
+"""autograd bindings of the conv-VAE HIP kernels (csrc/vae_conv.hip).  Every forward AND backward is a
+call into libgpode_hip.so; torch only allocates the tensors and records the graph."""
+import ctypes
+
+import torch
+
+from . import _lib
+from .ops import _chk, _ptr, _stream
+
+
+def _new(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _scratch(n, like):
+    return torch.empty(max(int(n), 4), dtype=torch.float32, device=like.device)
+
+
+def _wgrad_scratch(B, Ci, Co, K, like):
+    return _scratch(_lib.load().gpode_conv_wgrad_scratch(B, Ci, Co, K), like)
+
+
+def _bn_scratch(B, C, like):
+    return _scratch(_lib.load().gpode_bn_scratch(B, C), like)
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad):
+        x, w = _chk(x, 'x'), _chk(w, 'weight')
+        B, Ci, H, W = x.shape
+        Co, _, K, _ = w.shape
+        Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+        y = _new((B, Co, Ho, Wo), x)
+        _lib.call('gpode_conv2d_fwd', _ptr(x), _ptr(w), _ptr(b), _ptr(y), B, Ci, H, W, Co, K, stride, pad, Ho, Wo, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.geom = (B, Ci, H, W, Co, K, stride, pad, Ho, Wo, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        B, Ci, H, W, Co, K, S, P, Ho, Wo, has_b = ctx.geom
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _new(x.shape, x)
+            _lib.call('gpode_conv2d_bwd_data', _ptr(gy), _ptr(w), _ptr(None), _ptr(gx), B, Ci, H, W, Co, K, S, P, Ho, Wo, _stream())
+        if ctx.needs_input_grad[1]:
+            gw = _new(w.shape, x)
+            gb = _new((Co,), x) if has_b else None
+            _lib.call('gpode_conv2d_bwd_weight', _ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), _ptr(_wgrad_scratch(B, Ci, Co, K, x)),
+                      B, Ci, H, W, Co, K, S, P, Ho, Wo, _stream())
+        return gx, gw, gb, None, None
+
+
+class _ConvT2d(torch.autograd.Function):
+    """nn.ConvTranspose2d as the adjoint of the convolution that shares its weight buffer."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, out_pad):
+        x, w = _chk(x, 'x'), _chk(w, 'weight')
+        B, Cin, Hi, Wi = x.shape
+        _, Cout, K, _ = w.shape
+        Ht, Wt = (Hi - 1) * stride - 2 * pad + K + out_pad, (Wi - 1) * stride - 2 * pad + K + out_pad
+        y = _new((B, Cout, Ht, Wt), x)
+        # conv geometry: "input" (B,Ci=Cout,H=Ht,W=Wt), "output" (B,Co=Cin,Ho=Hi,Wo=Wi)
+        _lib.call('gpode_conv2d_bwd_data', _ptr(x), _ptr(w), _ptr(b), _ptr(y), B, Cout, Ht, Wt, Cin, K, stride, pad, Hi, Wi, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.geom = (B, Cout, Ht, Wt, Cin, K, stride, pad, Hi, Wi, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, has_b = ctx.geom
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _new(x.shape, x)
+            _lib.call('gpode_conv2d_fwd', _ptr(gy), _ptr(w), _ptr(None), _ptr(gx), B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, _stream())
+        if ctx.needs_input_grad[1]:
+            gw = _new(w.shape, x)
+            _lib.call('gpode_conv2d_bwd_weight', _ptr(gy), _ptr(x), _ptr(gw), _ptr(None), _ptr(_wgrad_scratch(B, Cout, Cin, K, x)),
+                      B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, _stream())
+            if has_b:
+                gb = _new((Cout,), x)
+                _lib.call('gpode_chan_sum', _ptr(gy), _ptr(gb), B, Cout, Ht * Wt, _ptr(_bn_scratch(B, Cout, x)), _stream())
+        return gx, gw, gb, None, None, None
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+        x = _chk(x, 'x')
+        B, C = x.shape[0], x.shape[1]
+        HW = x[0, 0].numel()
+        y = _new(x.shape, x)
+        mean, invstd = _new((C,), x), _new((C,), x)
+        _lib.call('gpode_bn_fwd', _ptr(x), _ptr(_chk(gamma, 'gamma')), _ptr(_chk(beta, 'beta')), _ptr(y), _ptr(mean), _ptr(invstd),
+                  _ptr(running_mean), _ptr(running_var), ctypes.c_float(momentum), ctypes.c_float(eps), B, C, HW, int(relu),
+                  _ptr(_bn_scratch(B, C, x)), _stream())
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.relu = int(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        B, C = x.shape[0], x.shape[1]
+        HW = x[0, 0].numel()
+        gx, gg, gb = _new(x.shape, x), _new((C,), x), _new((C,), x)
+        _lib.call('gpode_bn_bwd', _ptr(x), _ptr(y), _ptr(gy.contiguous()), _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(gx), _ptr(gg),
+                  _ptr(gb), B, C, HW, ctx.relu, _ptr(_bn_scratch(B, C, x)), _stream())
+        return gx, gg, gb, None, None, None, None, None
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        x = _chk(x, 'x')
+        y = _new(x.shape, x)
+        _lib.call('gpode_act_fwd', _ptr(x), _ptr(y), x.numel(), mode, _stream())
+        ctx.save_for_backward(y)
+        ctx.mode = mode
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gx = _new(y.shape, y)
+        _lib.call('gpode_act_bwd', _ptr(y), _ptr(gy.contiguous()), _ptr(gx), y.numel(), ctx.mode, _stream())
+        return gx, None
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _chk(x, 'x'), _chk(w, 'weight')
+        B, In = x.shape
+        Out = w.shape[0]
+        y = _new((B, Out), x)
+        _lib.call('gpode_linear_fwd', _ptr(x), _ptr(w), _ptr(b), _ptr(y), B, In, Out, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        B, In = x.shape
+        Out = w.shape[0]
+        gx = _new(x.shape, x) if ctx.needs_input_grad[0] else None
+        gw = _new(w.shape, x) if ctx.needs_input_grad[1] else None
+        gb = _new((Out,), x) if (ctx.has_b and gw is not None) else None
+        _lib.call('gpode_linear_bwd', _ptr(x), _ptr(w), _ptr(gy.contiguous()), _ptr(gx), _ptr(gw), _ptr(gb), B, In, Out, _stream())
+        return gx, gw, gb
+
+
+class _LogLik(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, z):
+        X, z = _chk(X, 'X'), _chk(z, 'z')
+        ll = _new(z.shape, z)
+        _lib.call('gpode_loglik_fwd', _ptr(X), _ptr(z), _ptr(ll), z.numel(), X.numel(), _stream())
+        ctx.save_for_backward(X, z)
+        return ll
+
+    @staticmethod
+    def backward(ctx, g):
+        X, z = ctx.saved_tensors
+        gz = _new(z.shape, z)
+        _lib.call('gpode_loglik_bwd', _ptr(X), _ptr(z), _ptr(g.contiguous()), _ptr(gz), z.numel(), X.numel(), _stream())
+        return None, gz
+
+
+class _LogLikRowSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, z, rows):
+        X, z = _chk(X, 'X'), _chk(z, 'z')
+        inner = z.numel() // rows
+        out = _new((rows,), z)
+        _lib.call('gpode_loglik_rowsum_fwd', _ptr(X), _ptr(z), _ptr(out), rows, inner, X.numel(), _stream())
+        ctx.save_for_backward(X, z)
+        ctx.rows, ctx.inner = rows, inner
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X, z = ctx.saved_tensors
+        gz = _new(z.shape, z)
+        _lib.call('gpode_loglik_rowsum_bwd', _ptr(X), _ptr(z), _ptr(g.contiguous()), _ptr(gz), ctx.rows, ctx.inner, X.numel(), _stream())
+        return None, gz, None
+
+
+def conv2d(x, w, b, stride, pad):
+    return _Conv2d.apply(x, w, b, stride, pad)
+
+
+def conv_transpose2d(x, w, b, stride, pad, out_pad=0):
+    return _ConvT2d.apply(x, w, b, stride, pad, out_pad)
+
+
+def batch_norm_train(x, bn, relu):
+    """nn.BatchNorm2d in training mode on the module's own parameters/buffers (updates running stats)."""
+    if bn.training:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+    y = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean if bn.training else None,
+                              bn.running_var if bn.training else None, bn.momentum, bn.eps, relu)
+    return y
+
+
+def relu(x):
+    return _Act.apply(x, 0)
+
+
+def sigmoid(x):
+    return _Act.apply(x, 1)
+
+
+def linear(x, w, b):
+    return _Linear.apply(x, w, b)
+
+
+def bernoulli_loglik(X, z):
+    """log(z) X + log(1-z)(1-X), X broadcast over the leading copies of z (vae.py:136-153)."""
+    return _LogLik.apply(X, z)
+
+
+def bernoulli_loglik_rowsum(X, z, rows):
+    return _LogLikRowSum.apply(X, z, rows)
