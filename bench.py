@@ -3,14 +3,17 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload cfg2|cfg4|cfg3|cfg1]
 
-A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
-one GP function draw (cache build: K_uu, Cholesky, solves) + the fixed-grid RK4 rollout of the
-whole minibatch.  One process per GPU; for N>1 the minibatch axis is sharded (every rank integrates
-its own `batch` trajectories under the SAME GP draw), no data-path collective -> weak scaling.
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM.
+  --mode elbo (default): the full training step of main.py:199-211 -- encoder, GP draw (cache build), RK4
+      rollout, decoder, ELBO, loss.backward(), Adam -- every kernel hand-written HIP, L = 1.
+  --mode integrator: GP draw + RK4 rollout only (forward).
+One process per GPU; for N>1 the minibatch axis is sharded (every rank owns `batch` sequences, all ranks
+integrate under the SAME GP draw) and, in elbo mode, the gradient bucket is all-reduced over RCCL before the
+optimizer step -> weak scaling.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the rollout), timed live with
-HIP events on the launch stream; `cpu_baseline` times the CPU oracle (kind "port": the reference
-itself never travels to the GPU box) on a bounded sample of the same workload.
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, timed live with HIP events on the
+launch stream; `cpu_baseline` times the CPU oracle (kind "port": the reference itself never travels to the
+GPU box) on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -96,12 +99,73 @@ def cpu_baseline(w, p, nz, z0, ts, budget_s=12.0):
                 sample='%d full steps (GP draw + rk4 rollout, batch %d) of the torch-CPU oracle in %.1f s' % (n, N, el))
 
 
+def make_model_inputs(w, seed, dev, rank):
+    """Full model of the reference's shape (build_model under seed_everything, README hyper-parameters) and a
+    synthetic normalised minibatch X (N,T,1,28,28) (data/utils.py:8-15 on random frames)."""
+    import types
+    from vae_gp_ode_amd.model.core.initialization import initialize_and_fix_kernel_parameters
+    from vae_gp_ode_amd.model.core.noise import DeviceNoise
+    from vae_gp_ode_amd.model.create_model import build_model
+    from vae_gp_ode_amd.model.misc.torch_utils import seed_everything
+    q, order = w['q'], w['order']
+    args = types.SimpleNamespace(D_in=q * order, D_out=q, num_inducing=w['M'], num_features=w['S'], dimwise=True, q_diag=False,
+                                 device=dev, kernel=w['kernel'], ode=order, solver='rk4', use_adjoint=False, frames=5, n_filt=8,
+                                 latent_dim=q, Ndata=360, dt=0.1)
+    seed_everything(seed)
+    model = build_model(args).to(dev)
+    initialize_and_fix_kernel_parameters(model, lengthscale_value=2.0, variance_value=1.0)
+    model.flow.odefunc.diffeq.noise_source = DeviceNoise(seed + 1)  # same draw sequence on every rank
+    gx = torch.Generator().manual_seed(seed + 100 + rank)
+    X = ((torch.rand(w['batch'], w['T'], 1, 28, 28, generator=gx) - 0.1307) / 0.3081)
+    return model, X
+
+
+def cpu_baseline_elbo(w, model, X, budget_s=15.0):
+    """The same training step on the CPU: oracle compute_loss (torch CPU) + autograd + torch.optim.Adam."""
+    from oracle import gpode_oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get('BENCH_CPU_THREADS', '16'))))
+    torch.set_num_threads(cores)
+    sd = {k: (v.detach().cpu().clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k and '_num_evals' not in k
+              else v.detach().cpu().clone()) for k, v in model.state_dict().items()}
+    params = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    q, order = w['q'], w['order']
+    Di, Do, M, S, N = q * order, q, w['M'], w['S'], X.shape[0]
+    g = torch.Generator().manual_seed(7)
+
+    def step():
+        nz = dict(eps_u=torch.randn(M, Do, generator=g), rff_w=torch.randn(S if w['kernel'] == 'RBF' else 2 * S, Do, generator=g),
+                  rff_eps=torch.randn(Di, S, Do, generator=g), rff_u=torch.rand(1, S, Do, generator=g))
+        eps_s = torch.randn(N, q, generator=g)
+        eps_v = torch.randn(N, q, generator=g) if order == 2 else None
+        opt.zero_grad()
+        r = O.compute_loss(X, sd, [nz], eps_s, eps_v, kernel=w['kernel'], order=order, method='rk4', dt=0.1, Ndata=360)
+        r['loss'].backward()
+        opt.step()
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 200:
+            break
+    return dict(value=N * n / el, unit='trajectories/s', cores=cores, kind='port',
+                sample='%d full training steps (fwd + bwd + Adam, batch %d) of the torch-CPU oracle in %.1f s' % (n, N, el))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
+    ap.add_argument('--mode', default='elbo', choices=['elbo', 'integrator'])
     ap.add_argument('--seed', type=int, default=121)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     a = ap.parse_args()
@@ -118,9 +182,102 @@ def main():
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=dev)
     n_gpus = world
-
-    from vae_gp_ode_amd import ops
     w = WORKLOADS[a.workload]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if a.mode == 'integrator':
+        out = run_integrator(a, w, dev, rank, n_gpus, dist, barrier)
+    else:
+        out = run_elbo(a, w, dev, rank, n_gpus, dist, barrier)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
+    from vae_gp_ode_amd.model.create_model import compute_loss
+    from vae_gp_ode_amd.optim import HipAdam
+    from vae_gp_ode_amd.parallel import GradAllReduce
+    model, X = make_model_inputs(w, a.seed, dev, rank)
+    Xd = X.to(dev)
+    opt = HipAdam(model.parameters(), lr=1e-3)
+    sync = GradAllReduce(opt.flat_grads, dist) if dist is not None else None
+    last = {}
+
+    def step():
+        opt.zero_grad()
+        loss, nl, klr, klu = compute_loss(model, Xd, 1)
+        loss.backward()
+        if sync is not None:
+            sync.all_reduce_grads()
+        opt.step()
+        last['loss'] = loss
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    el = time.perf_counter() - t0
+    if not torch.isfinite(last['loss']).all():
+        raise SystemExit('non-finite loss')
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+    value = w['batch'] * n_gpus * a.steps / el
+    roof = dominant_kernel_roofline(w, dev)
+    out = {
+        'metric': 'latent_trajectories_per_sec', 'value': value, 'unit': 'trajectories/s',
+        'n_gpus': n_gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': el / a.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': w['desc'] + '; step = full ELBO training step (encoder, GP draw, rk4 rollout, decoder, ELBO, backward, Adam), L=1',
+                   'global_batch': w['batch'] * n_gpus, 'solver': 'rk4 (3/8 rule)', 'parallelism': 'dp%d' % n_gpus},
+        'elbo_step_ms': el / a.steps * 1e3,
+        'roofline': roof,
+    }
+    if rank == 0:
+        print('[bench] gpu leg done: %.1f traj/s, %.3f ms/step' % (value, el / a.steps * 1e3), file=sys.stderr, flush=True)
+        if not a.no_cpu_baseline and n_gpus == 1:
+            out['cpu_baseline'] = cpu_baseline_elbo(w, model, X)
+            out['gpu_over_cpu'] = value / out['cpu_baseline']['value']
+    return out
+
+
+def dominant_kernel_roofline(w, dev, reps=20):
+    """The FLOP-dominant kernel of the step is the decoder's 32->16, k5, s2 transposed convolution (decnn.7) on
+    batch*T images; time it alone with HIP events (torch's current stream is the launch stream)."""
+    from vae_gp_ode_amd import vae_ops as V
+    B = w['batch'] * w['T']
+    x = torch.randn(B, 32, 13, 13, device=dev)
+    wt = torch.randn(32, 16, 5, 5, device=dev) * 0.05
+    b = torch.zeros(16, device=dev)
+    with torch.no_grad():
+        for _ in range(3):
+            V.conv_transpose2d(x, wt, b, 2, 1, 1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            V.conv_transpose2d(x, wt, b, 2, 1, 1)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    macs = 169 * 32 * 16 * 25  # per image: every input pixel x Cin x Cout x taps (SURVEY 2.2 O16: 2.163 MMAC)
+    flops = 2.0 * macs * B
+    ach = flops / (ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'kernel': 'k_conv_bwd_data<5,2> (decoder decnn.7 forward)', 'achieved': ach, 'peak': PEAK_FP32_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_TFLOPS, 'traffic': None, 'ms_per_launch': ms,
+            'note': 'algorithmic flops = 2 x 2.163 MMAC/image x %d images; fp32, priced against the fp32 MFMA peak' % B}
+
+
+def run_integrator(a, w, dev, rank, n_gpus, dist, barrier):
+    from vae_gp_ode_amd import ops
     flow, p, nz, z0, ts, nzd, z0d, tsd = make_inputs(w, a.seed, dev, rank)
     gp = flow.odefunc.diffeq
     torch.set_grad_enabled(False)
@@ -143,10 +300,6 @@ def main():
         step()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
     for k in range(a.steps):
@@ -182,9 +335,7 @@ def main():
         if not a.no_cpu_baseline and n_gpus == 1:
             out['cpu_baseline'] = cpu_baseline(w, p, nz, z0, ts)
             out['gpu_over_cpu'] = value / out['cpu_baseline']['value']
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    return out
 
 
 if __name__ == '__main__':

@@ -154,6 +154,12 @@ int gpode_loglik_rowsum_fwd(const float* X, const float* z, float* out, size_t r
 int gpode_loglik_rowsum_bwd(const float* X, const float* z, const float* grow, float* gz, size_t rows, size_t inner, size_t nX,
                             void* stream);
 
+/* torch.optim.Adam step (main.py:194,211) over a whole parameter list in one launch.  params/grads/m1/m2:
+ * DEVICE arrays of `ntensors` device pointers; offs: DEVICE array of element prefix offsets (offs[0]=0);
+ * step: 1-based step count (bias correction). */
+int gpode_adam_multi(void* params, void* grads, void* m1, void* m2, const long long* offs, int ntensors, long long total,
+                     float lr, float beta1, float beta2, float eps, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,5 +80,7 @@ int loglik_fwd(const float* X, const float* z, float* ll, size_t n, size_t nX, h
 int loglik_bwd(const float* X, const float* z, const float* g, float* gz, size_t n, size_t nX, hipStream_t st);
 int loglik_rowsum_fwd(const float* X, const float* z, float* out, size_t rows, size_t inner, size_t nX, hipStream_t st);
 int loglik_rowsum_bwd(const float* X, const float* z, const float* grow, float* gz, size_t rows, size_t inner, size_t nX, hipStream_t st);
+int adam_multi(float* const* params, const float* const* grads, float* const* m1, float* const* m2, const long long* offs,
+               int ntensors, long long total, float lr, float beta1, float beta2, float eps, int step, hipStream_t st);
 
 }  // namespace gp

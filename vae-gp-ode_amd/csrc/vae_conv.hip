@@ -490,3 +490,34 @@ int loglik_rowsum_bwd(const float* X, const float* z, const float* grow, float* 
 }
 
 }  // namespace gp
+
+// ---------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam defaults as used at main.py:194: betas (0.9, 0.999), eps 1e-8, no weight decay),
+// all parameter tensors in ONE launch: a table of (param, grad, exp_avg, exp_avg_sq) pointers with prefix
+// offsets; each thread finds its tensor by binary search.
+// ---------------------------------------------------------------------------------------------
+namespace gp {
+__global__ void k_adam_multi(float* const* __restrict__ params, const float* const* __restrict__ grads,
+                             float* const* __restrict__ m1, float* const* __restrict__ m2, const long long* __restrict__ offs,
+                             int ntensors, long long total, float lr, float beta1, float beta2, float eps, float bc1, float bc2) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = ntensors - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (offs[mid] <= e) lo = mid; else hi = mid - 1; }
+    const long long i = e - offs[lo];
+    const float g = grads[lo][i];
+    const float a = beta1 * m1[lo][i] + (1.f - beta1) * g;
+    const float b = beta2 * m2[lo][i] + (1.f - beta2) * g * g;
+    m1[lo][i] = a;
+    m2[lo][i] = b;
+    // torch: denom = sqrt(v)/sqrt(bc2) + eps ; p -= lr/bc1 * m / denom
+    params[lo][i] -= (lr / bc1) * a / (sqrtf(b) / sqrtf(bc2) + eps);
+  }
+}
+
+int adam_multi(float* const* params, const float* const* grads, float* const* m1, float* const* m2, const long long* offs,
+               int ntensors, long long total, float lr, float beta1, float beta2, float eps, int step, hipStream_t st) {
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(k_adam_multi, ew_grid((size_t)total), 256, 0, st, params, grads, m1, m2, offs, ntensors, total, lr, beta1, beta2, eps, bc1, bc2);
+  return check_launch("adam_multi");
+}
+}  // namespace gp

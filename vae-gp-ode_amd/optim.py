@@ -1,0 +1,51 @@
+"""Adam in one HIP launch over the whole parameter list (csrc/vae_conv.hip:k_adam_multi); same update rule
+and defaults as ``torch.optim.Adam(params, lr)`` at experiments/main.py:194."""
+import ctypes
+
+import torch
+
+from . import _lib
+from .ops import _stream
+from .parallel import FlatGrads
+
+
+class HipAdam:
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params or not all(p.is_cuda and p.dtype == torch.float32 for p in self.params):
+            raise _lib.GpodeError('HipAdam needs float32 CUDA/HIP parameters')
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+        dev = self.params[0].device
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        # persistent gradient storage: views into one flat bucket (all-reduced in place under data parallelism)
+        self.flat_grads = FlatGrads(self.params)
+        offs, tot = [], 0
+        for p in self.params:
+            offs.append(tot)
+            tot += p.numel()
+        self.total = tot
+        tab = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)
+        self._p, self._m, self._v = tab(self.params), tab(self.exp_avg), tab(self.exp_avg_sq)
+        self._g = tab([p.grad for p in self.params])
+        self._gptrs = [p.grad.data_ptr() for p in self.params]
+        self._offs = torch.tensor(offs, dtype=torch.int64, device=dev)
+
+    def zero_grad(self):
+        fg = self.flat_grads
+        for p, o in zip(fg.params, fg.offsets):
+            if p.grad is None or p.grad.data_ptr() != fg.flat.data_ptr() + 4 * o:
+                p.grad = fg.flat[o:o + p.numel()].view_as(p)
+        fg.zero()
+
+    def step(self):
+        cur = [p.grad.data_ptr() for p in self.params]
+        if cur != self._gptrs:  # a gradient tensor was replaced: refresh the table
+            self._g = torch.tensor(cur, dtype=torch.int64, device=self._offs.device)
+            self._gptrs = cur
+        self.step_count += 1
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.call('gpode_adam_multi', vp(self._p), vp(self._g), vp(self._m), vp(self._v), vp(self._offs), len(self.params),
+                  self.total, ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]),
+                  ctypes.c_float(self.eps), self.step_count, _stream())
