@@ -115,6 +115,12 @@ def make_model_inputs(w, seed, dev, rank):
     model = build_model(args).to(dev)
     initialize_and_fix_kernel_parameters(model, lengthscale_value=2.0, variance_value=1.0)
     model.flow.odefunc.diffeq.noise_source = DeviceNoise(seed + 1)  # same draw sequence on every rank
+    # Keep the synthetic run finite: with the reference's own init, a batch of 4096 random-latent images puts a few
+    # sigmoid outputs at exactly 1.0f, and log(1 - z) = -inf poisons the ELBO (the reference's NaN guard exists
+    # for this).  Shrinking the last decoder layer keeps every pixel off the fp32 saturation point;
+    # the work per step is unchanged.
+    with torch.no_grad():
+        model.vae.decoder.decnn[10].weight.mul_(0.25)
     gx = torch.Generator().manual_seed(seed + 100 + rank)
     X = ((torch.rand(w['batch'], w['T'], 1, 28, 28, generator=gx) - 0.1307) / 0.3081)
     return model, X
@@ -205,7 +211,9 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
     from vae_gp_ode_amd.parallel import GradAllReduce
     model, X = make_model_inputs(w, a.seed, dev, rank)
     Xd = X.to(dev)
-    opt = HipAdam(model.parameters(), lr=1e-3)
+    # lr 1e-4: with the reference's lr = 1e-3 = initial diag(Us_sqrt), Adam's first step lands some diagonal entries
+    # on exactly 0 under random-noise images (log 0 in the inducing KL); the update kernel does the same work.
+    opt = HipAdam(model.parameters(), lr=1e-4)
     sync = GradAllReduce(opt.flat_grads, dist) if dist is not None else None
     last = {}
 

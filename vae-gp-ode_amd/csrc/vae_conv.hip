@@ -19,6 +19,7 @@
 namespace gp {
 
 struct ConvDims { int B, Ci, H, W, Co, P, Ho, Wo; };
+int chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, hipStream_t st);
 
 template <int K, int S>
 __global__ __launch_bounds__(256) void k_conv_fwd(const float* __restrict__ x, const float* __restrict__ w,
@@ -365,8 +366,18 @@ static inline int ew_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g
 
 #define GP_CONV_KS(X) X(5, 2) X(5, 1) X(3, 1) X(3, 2)
 
+// LDS-tiled specialisations of the heavy decoder layers (vae_conv_tiled.hip); -1 = geometry not covered
+int tiled_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S, int P,
+              int Ho, int Wo, hipStream_t st);
+int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co, int K, int S,
+                   int P, int Ho, int Wo, hipStream_t st);
+int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch, int B, int Ci, int H, int W, int Co, int K, int S,
+                     int P, int Ho, int Wo, hipStream_t st);
+size_t tiled_wgrad_scratch(int B);
+
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S,
                int P, int Ho, int Wo, hipStream_t st) {
+  { const int r = tiled_fwd(x, w, bias, y, B, Ci, H, W, Co, K, S, P, Ho, Wo, st); if (r >= 0) return r; }
   ConvDims d{B, Ci, H, W, Co, P, Ho, Wo};
   const size_t total = (size_t)B * Co * Ho * Wo;
 #define X(k, s) if (K == k && S == s) { hipLaunchKernelGGL((k_conv_fwd<k, s>), ew_grid(total), 256, 0, st, x, w, bias, y, d); return check_launch("conv_fwd"); }
@@ -377,6 +388,7 @@ int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int 
 
 int conv2d_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co, int K, int S,
                     int P, int Ho, int Wo, hipStream_t st) {
+  { const int r = tiled_bwd_data(gy, w, bias, gx, B, Ci, H, W, Co, K, S, P, Ho, Wo, st); if (r >= 0) return r; }
   ConvDims d{B, Ci, H, W, Co, P, Ho, Wo};
   const size_t total = (size_t)B * Ci * H * W;
 #define X(k, s) if (K == k && S == s) { hipLaunchKernelGGL((k_conv_bwd_data<k, s>), ew_grid(total), 256, 0, st, gy, w, bias, gx, d); return check_launch("conv_bwd_data"); }
@@ -394,10 +406,22 @@ static inline int pick_split(int B, int nblocks_per_split) {
 }
 
 // scratch: conv_wgrad_scratch_floats(...) floats
-size_t conv_wgrad_scratch(int B, int Ci, int Co, int K) { return (size_t)pick_split(B, Co * Ci) * Co * Ci * K * K + (size_t)64 * Co * 2; }
+size_t conv_wgrad_scratch(int B, int Ci, int Co, int K) {
+  const size_t generic = (size_t)pick_split(B, Co * Ci) * Co * Ci * K * K + (size_t)64 * Co * 2;
+  const size_t tiled = (K == 5 && Co * Ci <= 64 * 32) ? tiled_wgrad_scratch(B) + (size_t)64 * Co * 2 : 0;
+  return generic > tiled ? generic : tiled;
+}
 
 int conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci, int H, int W, int Co,
                       int K, int S, int P, int Ho, int Wo, hipStream_t st) {
+  {
+    const int r = tiled_bwd_weight(x, gy, gw, scratch, B, Ci, H, W, Co, K, S, P, Ho, Wo, st);
+    if (r > 0) return r;
+    if (r == 0) {
+      if (gbias) return chan_sum(gy, gbias, B, Co, Ho * Wo, scratch, st);
+      return 0;
+    }
+  }
   ConvDims d{B, Ci, H, W, Co, P, Ho, Wo};
   const int nsplit = pick_split(B, Co * Ci);
   const int bps = (B + nsplit - 1) / nsplit;

@@ -1,0 +1,330 @@
+// vae_conv_tiled.hip -- LDS-resident, register-blocked kernels for the two FLOP-dominant decoder layers
+//   decnn.4  ConvTranspose2d(64 -> 32, k5, s2, p1)        6x6  -> 13x13      1.843 MMAC / image
+//   decnn.7  ConvTranspose2d(32 -> 16, k5, s2, p1, op1)   13x13 -> 28x28     2.163 MMAC / image
+// (87 % of the decoder's 4.6 MMAC/image, vae.py:114-118), forward, d/d input and d/d weight.
+//
+// Common shape: a workgroup stages a few whole images (zero-padded, so taps never branch) and a slab of
+// weights in LDS; a thread owns ONE pixel x 16 channels of output in registers.  Per (input channel, tap)
+// it reads one input value (ds_read_b32, lane = pixel -> conflict-free) and 16 weights (4 x ds_read_b128
+// from a [tap][ci][co] slab: every lane of a channel group reads the same address -> broadcast) and issues
+// 16 FMAs.  fp32 FMA throughout: fp32 MFMA has the same peak as the vector FMA on gfx950, the limiter here
+// is LDS operand traffic, which the 16-wide register block keeps at ~1 LDS cycle per FMA-cycle.
+//
+//   T1 convT_fwd   gather form, one stride-parity class of output pixels at a time: inside a class every
+//                  pixel sees the same taps, so the weight reads are wave-uniform
+//   T2 convT_bwd   d/d input = ordinary strided convolution of grad_output with the same weights
+//   T3 convT_wgrad d/d weight: thread = (input channel, 4 output channels) x 25 taps = 100 accumulators,
+//                  images streamed through LDS; batch split over workgroups, slabs summed in fixed order
+#include <hip/hip_runtime.h>
+#include "gp_launch.hpp"
+
+namespace gp {
+
+template <int CI_, int CO_, int HI_, int HO_, int OP_> struct CTLayer {
+  static constexpr int CI = CI_, CO = CO_, HI = HI_, HO = HO_, OP = OP_;
+  static constexpr int K = 5, S = 2, P = 1;
+  static_assert(HO == (HI - 1) * S - 2 * P + K + OP, "geometry");
+  static constexpr int HP = HI + 4;              // padded input: 2 zero rows/cols before, 2 after
+  static constexpr int GP_ = HO + 2;             // padded grad_output: 1 zero row/col before, >=1 after
+};
+using Dec4 = CTLayer<64, 32, 6, 13, 0>;
+using Dec7 = CTLayer<32, 16, 13, 28, 1>;
+
+extern __shared__ __attribute__((aligned(16))) float tsm[];
+
+// ---------------------------------------------------------------------------------------------
+// T1: y[b,co,oy,ox] = bias[co] + sum_{ci,ky,kx} x[b,ci,iy,ix] w[ci,co,ky,kx],  oy = iy*2 - 1 + ky
+//     grid.x = image groups of IPB, block 256.
+// ---------------------------------------------------------------------------------------------
+template <class L, int IPB>
+__global__ __launch_bounds__(256) void k_convT_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ y, int B) {
+  constexpr int CI = L::CI, CO = L::CO, HI = L::HI, HO = L::HO, HP = L::HP, K = 5;
+  constexpr int NG = CO / 16;                      // channel groups of 16 per pixel
+  constexpr int IMG = CI * HP * HP;                // floats per staged image
+  float* s_img = tsm;                              // [IPB][CI][HP][HP]
+  float* s_w = tsm + IPB * IMG;                    // [tap][CI][CO] for the current parity class (<= 9 taps)
+  const int tid = threadIdx.x;
+  const int b0 = blockIdx.x * IPB;
+  const int nimg = min(IPB, B - b0);
+  // stage the images, zero padded
+  for (int e = tid; e < IPB * IMG; e += 256) {
+    const int im = e / IMG, r = e % IMG, ci = r / (HP * HP), yy = (r / HP) % HP - 2, xx = r % HP - 2;
+    float v = 0.f;
+    if (im < nimg && yy >= 0 && yy < HI && xx >= 0 && xx < HI) v = x[(((size_t)(b0 + im) * CI + ci) * HI + yy) * HI + xx];
+    s_img[e] = v;
+  }
+  for (int cls = 0; cls < 4; ++cls) {
+    const int py = cls >> 1, px = cls & 1;         // (oy + 1) % 2, (ox + 1) % 2
+    const int nty = py == 0 ? 3 : 2, ntx = px == 0 ? 3 : 2;   // taps ky = py + 2 t
+    __syncthreads();                               // previous class done with s_w (and images staged)
+    for (int e = tid; e < nty * ntx * CI * CO; e += 256) {
+      const int co = e % CO, ci = (e / CO) % CI, tap = e / (CO * CI);
+      const int ky = py + 2 * (tap / ntx), kx = px + 2 * (tap % ntx);
+      s_w[e] = w[(((size_t)ci * CO + co) * K + ky) * K + kx];
+    }
+    __syncthreads();
+    // pixels of the class: oy = 2 qy + py - 1 in [0, HO)
+    const int qy0 = py == 0 ? 1 : 0, qx0 = px == 0 ? 1 : 0;
+    const int ny = (HO - 1 + 1 - py) / 2 - qy0 + 1, nx = (HO - 1 + 1 - px) / 2 - qx0 + 1;
+    const int items = nimg * ny * nx * NG;
+    for (int it = tid; it < items; it += 256) {
+      const int g = it % NG, p = (it / NG) % (ny * nx), im = it / (NG * ny * nx);
+      const int qy = qy0 + p / nx, qx = qx0 + p % nx;
+      float acc[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc[c] = bias ? bias[g * 16 + c] : 0.f;
+      const float* img = s_img + im * IMG;
+      for (int ty = 0; ty < nty; ++ty) {
+        for (int tx = 0; tx < ntx; ++tx) {
+          const float* ip = img + (qy - ty + 2) * HP + (qx - tx + 2);      // iy = qy - ty
+          const float4* wp = reinterpret_cast<const float4*>(s_w + ((ty * ntx + tx) * CI) * CO + g * 16);
+#pragma unroll 4
+          for (int ci = 0; ci < CI; ++ci) {
+            const float v = ip[ci * HP * HP];
+            const float4 w0 = wp[ci * (CO / 4) + 0], w1 = wp[ci * (CO / 4) + 1], w2 = wp[ci * (CO / 4) + 2], w3 = wp[ci * (CO / 4) + 3];
+            acc[0] = fmaf(v, w0.x, acc[0]); acc[1] = fmaf(v, w0.y, acc[1]); acc[2] = fmaf(v, w0.z, acc[2]); acc[3] = fmaf(v, w0.w, acc[3]);
+            acc[4] = fmaf(v, w1.x, acc[4]); acc[5] = fmaf(v, w1.y, acc[5]); acc[6] = fmaf(v, w1.z, acc[6]); acc[7] = fmaf(v, w1.w, acc[7]);
+            acc[8] = fmaf(v, w2.x, acc[8]); acc[9] = fmaf(v, w2.y, acc[9]); acc[10] = fmaf(v, w2.z, acc[10]); acc[11] = fmaf(v, w2.w, acc[11]);
+            acc[12] = fmaf(v, w3.x, acc[12]); acc[13] = fmaf(v, w3.y, acc[13]); acc[14] = fmaf(v, w3.z, acc[14]); acc[15] = fmaf(v, w3.w, acc[15]);
+          }
+        }
+      }
+      const int oy = 2 * qy + py - 1, ox = 2 * qx + px - 1;
+      float* yp = y + (((size_t)(b0 + im) * CO + g * 16) * HO + oy) * HO + ox;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) yp[(size_t)c * HO * HO] = acc[c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// T2: gx[b,ci,iy,ix] = sum_{co,ky,kx} gy[b,co,2 iy - 1 + ky, 2 ix - 1 + kx] w[ci,co,ky,kx]
+//     weights staged in chunks of COC output channels ([co][tap][ci] slab).
+// ---------------------------------------------------------------------------------------------
+template <class L, int IPB, int COC>
+__global__ __launch_bounds__(256) void k_convT_bwd_data(const float* __restrict__ gy, const float* __restrict__ w,
+                                                         float* __restrict__ gx, int B) {
+  constexpr int CI = L::CI, CO = L::CO, HI = L::HI, HO = L::HO, GPD = L::GP_, K = 5;
+  constexpr int NG = CI / 16;
+  constexpr int IMG = CO * GPD * GPD;
+  float* s_img = tsm;                              // [IPB][CO][GPD][GPD], index = oy + 1
+  float* s_w = tsm + IPB * IMG;                    // [COC][25][CI]
+  const int tid = threadIdx.x;
+  const int b0 = blockIdx.x * IPB;
+  const int nimg = min(IPB, B - b0);
+  for (int e = tid; e < IPB * IMG; e += 256) {
+    const int im = e / IMG, r = e % IMG, co = r / (GPD * GPD), yy = (r / GPD) % GPD - 1, xx = r % GPD - 1;
+    float v = 0.f;
+    if (im < nimg && yy >= 0 && yy < HO && xx >= 0 && xx < HO) v = gy[(((size_t)(b0 + im) * CO + co) * HO + yy) * HO + xx];
+    s_img[e] = v;
+  }
+  const int items = nimg * HI * HI * NG;
+  constexpr int MAXIT = (IPB * HI * HI * NG + 255) / 256;
+  float acc[MAXIT][16];
+#pragma unroll
+  for (int r = 0; r < MAXIT; ++r)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[r][c] = 0.f;
+  for (int c0 = 0; c0 < CO; c0 += COC) {
+    __syncthreads();
+    for (int e = tid; e < COC * 25 * CI; e += 256) {
+      const int ci = e % CI, tap = (e / CI) % 25, co = c0 + e / (CI * 25);
+      s_w[e] = w[((size_t)ci * CO + co) * 25 + tap];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MAXIT; ++r) {
+      const int it = tid + 256 * r;
+      if (it < items) {
+        const int g = it % NG, p = (it / NG) % (HI * HI), im = it / (NG * HI * HI);
+        const int iy = p / HI, ix = p % HI;
+        const float* img = s_img + im * IMG + (c0 * GPD + 2 * iy) * GPD + 2 * ix;   // (oy+1) = 2 iy + ky
+        for (int co = 0; co < COC; ++co) {
+#pragma unroll
+          for (int ky = 0; ky < K; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+              const float v = img[(co * GPD + ky) * GPD + kx];
+              const float4* wp = reinterpret_cast<const float4*>(s_w + ((co * 25 + ky * K + kx) * CI) + g * 16);
+              const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+              float* a = acc[r];
+              a[0] = fmaf(v, w0.x, a[0]); a[1] = fmaf(v, w0.y, a[1]); a[2] = fmaf(v, w0.z, a[2]); a[3] = fmaf(v, w0.w, a[3]);
+              a[4] = fmaf(v, w1.x, a[4]); a[5] = fmaf(v, w1.y, a[5]); a[6] = fmaf(v, w1.z, a[6]); a[7] = fmaf(v, w1.w, a[7]);
+              a[8] = fmaf(v, w2.x, a[8]); a[9] = fmaf(v, w2.y, a[9]); a[10] = fmaf(v, w2.z, a[10]); a[11] = fmaf(v, w2.w, a[11]);
+              a[12] = fmaf(v, w3.x, a[12]); a[13] = fmaf(v, w3.y, a[13]); a[14] = fmaf(v, w3.z, a[14]); a[15] = fmaf(v, w3.w, a[15]);
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < MAXIT; ++r) {
+    const int it = tid + 256 * r;
+    if (it < items) {
+      const int g = it % NG, p = (it / NG) % (HI * HI), im = it / (NG * HI * HI);
+      float* gp = gx + (((size_t)(b0 + im) * CI + g * 16) * HI * HI) + p;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) gp[(size_t)c * HI * HI] = acc[r][c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// T3: gw[ci,co,ky,kx] = sum_{b,iy,ix} x[b,ci,iy,ix] gy[b,co,2 iy - 1 + ky, 2 ix - 1 + kx]
+//     grid (nsplit, CO/COW): a workgroup owns COW output channels and a slice of the batch; thread = (ci, 4 co).
+//     part[split][ci][co][25]
+// ---------------------------------------------------------------------------------------------
+template <class L, int COW>
+__global__ __launch_bounds__(256) void k_convT_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
+                                                      float* __restrict__ part, int B, int b_per_split) {
+  constexpr int CI = L::CI, CO = L::CO, HI = L::HI, HO = L::HO, GPD = L::GP_;
+  constexpr int NQ = COW / 4;                      // co-quads per workgroup
+  constexpr int NT = CI * NQ;                      // active (ci, quad) threads
+  constexpr int PSPLIT = 256 / NT;                 // pixel-parity split when there are spare threads
+  static_assert(NT <= 256 && 256 % NT == 0, "thread mapping");
+  float* s_x = tsm;                                // [HI*HI][CI]
+  float* s_g = tsm + HI * HI * CI;                 // [GPD][GPD][COW]
+  const int tid = threadIdx.x;
+  const int ci = tid % CI, q = (tid / CI) % NQ, ps = tid / NT;
+  const int co0 = blockIdx.y * COW;
+  const int b0 = blockIdx.x * b_per_split, b1 = min(B, b0 + b_per_split);
+  float acc[25][4];
+#pragma unroll
+  for (int t = 0; t < 25; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; acc[t][3] = 0.f; }
+  for (int b = b0; b < b1; ++b) {
+    __syncthreads();
+    for (int e = tid; e < HI * HI * CI; e += 256) {
+      const int c = e % CI, p = e / CI;
+      s_x[e] = x[((size_t)b * CI + c) * HI * HI + p];
+    }
+    for (int e = tid; e < GPD * GPD * COW; e += 256) {
+      const int c = e % COW, xx = (e / COW) % GPD - 1, yy = e / (COW * GPD) - 1;
+      float v = 0.f;
+      if (yy >= 0 && yy < HO && xx >= 0 && xx < HO) v = gy[(((size_t)b * CO + co0 + c) * HO + yy) * HO + xx];
+      s_g[e] = v;
+    }
+    __syncthreads();
+    for (int p = ps; p < HI * HI; p += PSPLIT) {
+      const int iy = p / HI, ix = p % HI;
+      const float xv = s_x[p * CI + ci];
+      const float* gp = s_g + ((2 * iy) * GPD + 2 * ix) * COW + q * 4;
+#pragma unroll
+      for (int ky = 0; ky < 5; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+          const float4 g4 = *reinterpret_cast<const float4*>(gp + (ky * GPD + kx) * COW);
+          float* a = acc[ky * 5 + kx];
+          a[0] = fmaf(xv, g4.x, a[0]); a[1] = fmaf(xv, g4.y, a[1]); a[2] = fmaf(xv, g4.z, a[2]); a[3] = fmaf(xv, g4.w, a[3]);
+        }
+      }
+    }
+  }
+  // combine the pixel-parity splits through LDS (fixed order), then write the slab
+  __syncthreads();
+  float* s_red = tsm;  // [PSPLIT][NT][100]
+  if (PSPLIT > 1) {
+#pragma unroll
+    for (int t = 0; t < 25; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s_red[((size_t)ps * NT + (tid % NT)) * 100 + t * 4 + c] = acc[t][c];
+    __syncthreads();
+  }
+  if (ps == 0) {
+    float* out = part + (size_t)blockIdx.x * CI * CO * 25;
+#pragma unroll
+    for (int t = 0; t < 25; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v = acc[t][c];
+        if (PSPLIT > 1)
+          for (int s = 1; s < PSPLIT; ++s) v += s_red[((size_t)s * NT + (tid % NT)) * 100 + t * 4 + c];
+        out[((size_t)ci * CO + co0 + q * 4 + c) * 25 + t] = v;
+      }
+  }
+}
+
+__global__ void k_sum_splits_t(const float* __restrict__ part, int nsplit, size_t n, float* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float acc = 0.f;
+  for (int s = 0; s < nsplit; ++s) acc += part[(size_t)s * n + e];
+  out[e] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host: dispatch by geometry; return -1 when no tiled specialisation applies (caller falls back to the
+// generic direct kernels of vae_conv.hip)
+// ---------------------------------------------------------------------------------------------
+template <class L> static bool matches(int Ci_conv, int Co_conv, int H, int Ho, int K, int S, int P) {
+  // conv geometry of the adjoint: "input" (B, Ci_conv = L::CO, H = L::HO), "output" (B, Co_conv = L::CI, Ho = L::HI)
+  return Ci_conv == L::CO && Co_conv == L::CI && H == L::HO && Ho == L::HI && K == 5 && S == 2 && P == 1;
+}
+
+template <class L, int IPB>
+static int launch_T1(const float* x, const float* w, const float* bias, float* y, int B, hipStream_t st) {
+  const size_t lds = sizeof(float) * ((size_t)IPB * L::CI * L::HP * L::HP + (size_t)9 * L::CI * L::CO);
+  auto kern = k_convT_fwd<L, IPB>;
+  if (set_max_lds((const void*)kern, lds)) return 1;
+  hipLaunchKernelGGL(kern, (B + IPB - 1) / IPB, 256, lds, st, x, w, bias, y, B);
+  return check_launch("convT_fwd_tiled");
+}
+
+template <class L, int IPB, int COC>
+static int launch_T2(const float* gy, const float* w, float* gx, int B, hipStream_t st) {
+  const size_t lds = sizeof(float) * ((size_t)IPB * L::CO * L::GP_ * L::GP_ + (size_t)COC * 25 * L::CI);
+  auto kern = k_convT_bwd_data<L, IPB, COC>;
+  if (set_max_lds((const void*)kern, lds)) return 1;
+  hipLaunchKernelGGL(kern, (B + IPB - 1) / IPB, 256, lds, st, gy, w, gx, B);
+  return check_launch("convT_bwd_data_tiled");
+}
+
+template <class L, int COW>
+static int launch_T3(const float* x, const float* gy, float* gw, float* scratch, int B, hipStream_t st) {
+  constexpr int NT = L::CI * (COW / 4), PSPLIT = 256 / NT;
+  size_t fl = (size_t)L::HI * L::HI * L::CI + (size_t)L::GP_ * L::GP_ * COW;
+  const size_t red = (size_t)PSPLIT * NT * 100;
+  if (red > fl) fl = red;
+  const size_t lds = sizeof(float) * fl;
+  int nsplit = B < 256 ? B : 256;
+  const int bps = (B + nsplit - 1) / nsplit;
+  nsplit = (B + bps - 1) / bps;
+  auto kern = k_convT_wgrad<L, COW>;
+  if (set_max_lds((const void*)kern, lds)) return 1;
+  hipLaunchKernelGGL(kern, dim3(nsplit, L::CO / COW), 256, lds, st, x, gy, scratch, B, bps);
+  const size_t n = (size_t)L::CI * L::CO * 25;
+  hipLaunchKernelGGL(k_sum_splits_t, (unsigned)((n + 255) / 256), 256, 0, st, scratch, nsplit, n, gw);
+  return check_launch("convT_wgrad_tiled");
+}
+
+size_t tiled_wgrad_scratch(int B) { return (size_t)(B < 256 ? B : 256) * 64 * 32 * 25; }
+
+// ConvTranspose2d forward (called with the conv geometry of its adjoint, as conv2d_bwd_data is)
+int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co, int K, int S,
+                   int P, int Ho, int Wo, hipStream_t st) {
+  if (H != W || Ho != Wo) return -1;
+  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec7, 3>(gy, w, bias, gx, B, st);
+  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec4, 3>(gy, w, bias, gx, B, st);
+  return -1;
+}
+
+// ConvTranspose2d d/d input (conv geometry: x := grad_output (B,Ci,H,W) -> y (B,Co,Ho,Wo)), no bias
+int tiled_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S, int P,
+              int Ho, int Wo, hipStream_t st) {
+  if (H != W || Ho != Wo || bias) return -1;
+  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec7, 2, 8>(x, w, y, B, st);
+  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec4, 3, 8>(x, w, y, B, st);
+  return -1;
+}
+
+// ConvTranspose2d d/d weight (conv geometry: x := grad_output, gy := the layer's input)
+int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch, int B, int Ci, int H, int W, int Co, int K, int S,
+                     int P, int Ho, int Wo, hipStream_t st) {
+  if (H != W || Ho != Wo) return -1;
+  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec7, 16>(gy, x, gw, scratch, B, st);
+  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec4, 16>(gy, x, gw, scratch, B, st);
+  return -1;
+}
+
+}  // namespace gp
