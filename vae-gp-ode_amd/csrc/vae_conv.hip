@@ -251,24 +251,28 @@ __global__ __launch_bounds__(256) void k_bn_bwd_sums(const float* __restrict__ x
     part[((size_t)blockIdx.y * C + c) * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// chan[c] = {sum g, sum g*xhat} over all splits; also the affine gradients
+__global__ void k_bn_bwd_finalize(const float* __restrict__ part, int nsplit, int C, float* __restrict__ chan,
+                                  float* __restrict__ ggamma, float* __restrict__ gbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int s = 0; s < nsplit; ++s) { a += part[((size_t)s * C + c) * 2]; b += part[((size_t)s * C + c) * 2 + 1]; }
+  chan[2 * c] = a; chan[2 * c + 1] = b;
+  gbeta[c] = a;
+  ggamma[c] = b;
+}
+
 __global__ void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
                                const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
-                               const float* __restrict__ part, int nsplit, float count, float* __restrict__ gx,
-                               float* __restrict__ ggamma, float* __restrict__ gbeta, size_t total, int C, int HW, int relu) {
+                               const float* __restrict__ chan, float count, float* __restrict__ gx, size_t total, int C, int HW, int relu) {
+  const float ic = 1.f / count;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)((e / HW) % C);
-    float sg = 0.f, sgx = 0.f;
-    for (int s = 0; s < nsplit; ++s) { sg += part[((size_t)s * C + c) * 2]; sgx += part[((size_t)s * C + c) * 2 + 1]; }
     float g = gy[e];
     if (relu && !(y[e] > 0.f)) g = 0.f;
     const float xh = (x[e] - mean[c]) * invstd[c];
-    gx[e] = gamma[c] * invstd[c] * (g - sg / count - xh * sgx / count);
-    if (e < (size_t)C) {  // one thread per channel also publishes the affine gradients
-      float a = 0.f, bq = 0.f;
-      for (int s = 0; s < nsplit; ++s) { a += part[((size_t)s * C + e) * 2]; bq += part[((size_t)s * C + e) * 2 + 1]; }
-      gbeta[e] = a;
-      ggamma[e] = bq;
-    }
+    gx[e] = gamma[c] * invstd[c] * (g - chan[2 * c] * ic - xh * chan[2 * c + 1] * ic);
   }
 }
 
@@ -373,7 +377,6 @@ int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx
                    int P, int Ho, int Wo, hipStream_t st);
 int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch, int B, int Ci, int H, int W, int Co, int K, int S,
                      int P, int Ho, int Wo, hipStream_t st);
-size_t tiled_wgrad_scratch(int B);
 
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S,
                int P, int Ho, int Wo, hipStream_t st) {
@@ -408,7 +411,8 @@ static inline int pick_split(int B, int nblocks_per_split) {
 // scratch: conv_wgrad_scratch_floats(...) floats
 size_t conv_wgrad_scratch(int B, int Ci, int Co, int K) {
   const size_t generic = (size_t)pick_split(B, Co * Ci) * Co * Ci * K * K + (size_t)64 * Co * 2;
-  const size_t tiled = (K == 5 && Co * Ci <= 64 * 32) ? tiled_wgrad_scratch(B) + (size_t)64 * Co * 2 : 0;
+  // the tiled weight-gradient kernels split the batch into up to 256 slabs of Co*Ci*K*K floats
+  const size_t tiled = (size_t)(B < 256 ? B : 256) * Co * Ci * K * K + (size_t)64 * Co * 2;
   return generic > tiled ? generic : tiled;
 }
 
@@ -442,7 +446,7 @@ int conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, 
   return check_launch("conv_bwd_weight");
 }
 
-size_t bn_scratch(int B, int C) { return (size_t)(B < 64 ? B : 64) * C * 2; }
+size_t bn_scratch(int B, int C) { return (size_t)(B < 64 ? B : 64) * C * 2 + (size_t)C * 2; }
 
 int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
            float* running_mean, float* running_var, float momentum, float eps, int B, int C, int HW, int relu,
@@ -463,8 +467,10 @@ int bn_bwd(const float* x, const float* y, const float* gy, const float* gamma, 
   const int ns = B < 64 ? B : 64, bps = (B + ns - 1) / ns, used = (B + bps - 1) / bps;
   hipLaunchKernelGGL(k_bn_bwd_sums, dim3(C, used), 256, 0, st, x, y, gy, save_mean, save_invstd, B, C, HW, relu, bps, scratch);
   const size_t total = (size_t)B * C * HW;
-  hipLaunchKernelGGL(k_bn_bwd_apply, ew_grid(total), 256, 0, st, x, y, gy, gamma, save_mean, save_invstd, scratch, used,
-                     (float)B * HW, gx, ggamma, gbeta, total, C, HW, relu);
+  float* chan = scratch + (size_t)ns * C * 2;
+  hipLaunchKernelGGL(k_bn_bwd_finalize, (C + 63) / 64, 64, 0, st, scratch, used, C, chan, ggamma, gbeta);
+  hipLaunchKernelGGL(k_bn_bwd_apply, ew_grid(total), 256, 0, st, x, y, gy, gamma, save_mean, save_invstd, chan, (float)B * HW, gx,
+                     total, C, HW, relu);
   return check_launch("bn_bwd");
 }
 

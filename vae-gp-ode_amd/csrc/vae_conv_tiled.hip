@@ -20,15 +20,23 @@
 
 namespace gp {
 
-template <int CI_, int CO_, int HI_, int HO_, int OP_> struct CTLayer {
-  static constexpr int CI = CI_, CO = CO_, HI = HI_, HO = HO_, OP = OP_;
-  static constexpr int K = 5, S = 2, P = 1;
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// ConvTranspose2d(CI -> CO, K, stride S, padding P, output_padding OP), square HI x HI -> HO x HO
+template <int CI_, int CO_, int HI_, int HO_, int OP_, int K_ = 5, int S_ = 2, int P_ = 1> struct CTLayer {
+  static constexpr int CI = CI_, CO = CO_, HI = HI_, HO = HO_, OP = OP_, K = K_, S = S_, P = P_;
   static_assert(HO == (HI - 1) * S - 2 * P + K + OP, "geometry");
-  static constexpr int HP = HI + 4;              // padded input: 2 zero rows/cols before, 2 after
-  static constexpr int GP_ = HO + 2;             // padded grad_output: 1 zero row/col before, >=1 after
+  // gather form: oy = S qy + py - P, taps ky = py + S t, iy = qy - t
+  static constexpr int PL = (K - 1) / S;                             // zero rows/cols before (max t)
+  static constexpr int QMAX = (HO - 1 + P) / S;                      // largest qy
+  static constexpr int PH = cmax(0, QMAX - (HI - 1));                // zero rows/cols after
+  static constexpr int HP = HI + PL + PH;                            // padded input extent
+  static constexpr int GP_ = cmax((HI - 1) * S + K, HO + P);         // padded grad_output extent, index = oy + P
 };
+using Dec1 = CTLayer<32, 64, 4, 6, 0, 3, 1, 0>;
 using Dec4 = CTLayer<64, 32, 6, 13, 0>;
 using Dec7 = CTLayer<32, 16, 13, 28, 1>;
+using Dec10 = CTLayer<16, 1, 28, 28, 0, 5, 1, 2>;
 
 extern __shared__ __attribute__((aligned(16))) float tsm[];
 
@@ -39,7 +47,8 @@ extern __shared__ __attribute__((aligned(16))) float tsm[];
 template <class L, int IPB>
 __global__ __launch_bounds__(256) void k_convT_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ bias, float* __restrict__ y, int B) {
-  constexpr int CI = L::CI, CO = L::CO, HI = L::HI, HO = L::HO, HP = L::HP, K = 5;
+  constexpr int CI = L::CI, CO = L::CO, HI = L::HI, HO = L::HO, HP = L::HP, K = L::K, S = L::S, P = L::P, PL = L::PL;
+  static_assert(CO % 16 == 0, "16 output channels per thread");
   constexpr int NG = CO / 16;                      // channel groups of 16 per pixel
   constexpr int IMG = CI * HP * HP;                // floats per staged image
   float* s_img = tsm;                              // [IPB][CI][HP][HP]
@@ -49,24 +58,24 @@ __global__ __launch_bounds__(256) void k_convT_fwd(const float* __restrict__ x, 
   const int nimg = min(IPB, B - b0);
   // stage the images, zero padded
   for (int e = tid; e < IPB * IMG; e += 256) {
-    const int im = e / IMG, r = e % IMG, ci = r / (HP * HP), yy = (r / HP) % HP - 2, xx = r % HP - 2;
+    const int im = e / IMG, r = e % IMG, ci = r / (HP * HP), yy = (r / HP) % HP - PL, xx = r % HP - PL;
     float v = 0.f;
     if (im < nimg && yy >= 0 && yy < HI && xx >= 0 && xx < HI) v = x[(((size_t)(b0 + im) * CI + ci) * HI + yy) * HI + xx];
     s_img[e] = v;
   }
-  for (int cls = 0; cls < 4; ++cls) {
-    const int py = cls >> 1, px = cls & 1;         // (oy + 1) % 2, (ox + 1) % 2
-    const int nty = py == 0 ? 3 : 2, ntx = px == 0 ? 3 : 2;   // taps ky = py + 2 t
+  for (int cls = 0; cls < S * S; ++cls) {
+    const int py = cls / S, px = cls % S;          // (oy + P) % S, (ox + P) % S
+    const int nty = (K - py + S - 1) / S, ntx = (K - px + S - 1) / S;   // taps ky = py + S t
     __syncthreads();                               // previous class done with s_w (and images staged)
     for (int e = tid; e < nty * ntx * CI * CO; e += 256) {
       const int co = e % CO, ci = (e / CO) % CI, tap = e / (CO * CI);
-      const int ky = py + 2 * (tap / ntx), kx = px + 2 * (tap % ntx);
+      const int ky = py + S * (tap / ntx), kx = px + S * (tap % ntx);
       s_w[e] = w[(((size_t)ci * CO + co) * K + ky) * K + kx];
     }
     __syncthreads();
-    // pixels of the class: oy = 2 qy + py - 1 in [0, HO)
-    const int qy0 = py == 0 ? 1 : 0, qx0 = px == 0 ? 1 : 0;
-    const int ny = (HO - 1 + 1 - py) / 2 - qy0 + 1, nx = (HO - 1 + 1 - px) / 2 - qx0 + 1;
+    // pixels of the class: oy = S qy + py - P in [0, HO)
+    const int qy0 = (P - py + S - 1 > 0) ? (P - py + S - 1) / S : 0, qx0 = (P - px + S - 1 > 0) ? (P - px + S - 1) / S : 0;
+    const int ny = (HO - 1 + P - py) / S - qy0 + 1, nx = (HO - 1 + P - px) / S - qx0 + 1;
     const int items = nimg * ny * nx * NG;
     for (int it = tid; it < items; it += 256) {
       const int g = it % NG, p = (it / NG) % (ny * nx), im = it / (NG * ny * nx);
@@ -77,7 +86,7 @@ __global__ __launch_bounds__(256) void k_convT_fwd(const float* __restrict__ x, 
       const float* img = s_img + im * IMG;
       for (int ty = 0; ty < nty; ++ty) {
         for (int tx = 0; tx < ntx; ++tx) {
-          const float* ip = img + (qy - ty + 2) * HP + (qx - tx + 2);      // iy = qy - ty
+          const float* ip = img + (qy - ty + PL) * HP + (qx - tx + PL);    // iy = qy - ty
           const float4* wp = reinterpret_cast<const float4*>(s_w + ((ty * ntx + tx) * CI) * CO + g * 16);
 #pragma unroll 4
           for (int ci = 0; ci < CI; ++ci) {
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(256) void k_convT_fwd(const float* __restrict__ x, 
           }
         }
       }
-      const int oy = 2 * qy + py - 1, ox = 2 * qx + px - 1;
+      const int oy = S * qy + py - P, ox = S * qx + px - P;
       float* yp = y + (((size_t)(b0 + im) * CO + g * 16) * HO + oy) * HO + ox;
 #pragma unroll
       for (int c = 0; c < 16; ++c) yp[(size_t)c * HO * HO] = acc[c];
@@ -105,16 +114,17 @@ __global__ __launch_bounds__(256) void k_convT_fwd(const float* __restrict__ x, 
 template <class L, int IPB, int COC>
 __global__ __launch_bounds__(256) void k_convT_bwd_data(const float* __restrict__ gy, const float* __restrict__ w,
                                                          float* __restrict__ gx, int B) {
-  constexpr int CI = L::CI, CO = L::CO, HI = L::HI, HO = L::HO, GPD = L::GP_, K = 5;
+  constexpr int CI = L::CI, CO = L::CO, HI = L::HI, HO = L::HO, GPD = L::GP_, K = L::K, S = L::S, P = L::P, KK = K * K;
+  static_assert(CI % 16 == 0 && CO % COC == 0, "blocking");
   constexpr int NG = CI / 16;
   constexpr int IMG = CO * GPD * GPD;
-  float* s_img = tsm;                              // [IPB][CO][GPD][GPD], index = oy + 1
-  float* s_w = tsm + IPB * IMG;                    // [COC][25][CI]
+  float* s_img = tsm;                              // [IPB][CO][GPD][GPD], index = oy + P
+  float* s_w = tsm + IPB * IMG;                    // [COC][K*K][CI]
   const int tid = threadIdx.x;
   const int b0 = blockIdx.x * IPB;
   const int nimg = min(IPB, B - b0);
   for (int e = tid; e < IPB * IMG; e += 256) {
-    const int im = e / IMG, r = e % IMG, co = r / (GPD * GPD), yy = (r / GPD) % GPD - 1, xx = r % GPD - 1;
+    const int im = e / IMG, r = e % IMG, co = r / (GPD * GPD), yy = (r / GPD) % GPD - P, xx = r % GPD - P;
     float v = 0.f;
     if (im < nimg && yy >= 0 && yy < HO && xx >= 0 && xx < HO) v = gy[(((size_t)(b0 + im) * CO + co) * HO + yy) * HO + xx];
     s_img[e] = v;
@@ -128,9 +138,9 @@ __global__ __launch_bounds__(256) void k_convT_bwd_data(const float* __restrict_
     for (int c = 0; c < 16; ++c) acc[r][c] = 0.f;
   for (int c0 = 0; c0 < CO; c0 += COC) {
     __syncthreads();
-    for (int e = tid; e < COC * 25 * CI; e += 256) {
-      const int ci = e % CI, tap = (e / CI) % 25, co = c0 + e / (CI * 25);
-      s_w[e] = w[((size_t)ci * CO + co) * 25 + tap];
+    for (int e = tid; e < COC * KK * CI; e += 256) {
+      const int ci = e % CI, tap = (e / CI) % KK, co = c0 + e / (CI * KK);
+      s_w[e] = w[((size_t)ci * CO + co) * KK + tap];
     }
     __syncthreads();
 #pragma unroll
@@ -139,14 +149,14 @@ __global__ __launch_bounds__(256) void k_convT_bwd_data(const float* __restrict_
       if (it < items) {
         const int g = it % NG, p = (it / NG) % (HI * HI), im = it / (NG * HI * HI);
         const int iy = p / HI, ix = p % HI;
-        const float* img = s_img + im * IMG + (c0 * GPD + 2 * iy) * GPD + 2 * ix;   // (oy+1) = 2 iy + ky
+        const float* img = s_img + im * IMG + (c0 * GPD + S * iy) * GPD + S * ix;   // (oy + P) = S iy + ky
         for (int co = 0; co < COC; ++co) {
 #pragma unroll
           for (int ky = 0; ky < K; ++ky) {
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
               const float v = img[(co * GPD + ky) * GPD + kx];
-              const float4* wp = reinterpret_cast<const float4*>(s_w + ((co * 25 + ky * K + kx) * CI) + g * 16);
+              const float4* wp = reinterpret_cast<const float4*>(s_w + ((co * KK + ky * K + kx) * CI) + g * 16);
               const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
               float* a = acc[r];
               a[0] = fmaf(v, w0.x, a[0]); a[1] = fmaf(v, w0.y, a[1]); a[2] = fmaf(v, w0.z, a[2]); a[3] = fmaf(v, w0.w, a[3]);
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(256) void k_convT_bwd_data(const float* __restrict_
 template <class L, int COW>
 __global__ __launch_bounds__(256) void k_convT_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
                                                       float* __restrict__ part, int B, int b_per_split) {
-  constexpr int CI = L::CI, CO = L::CO, HI = L::HI, HO = L::HO, GPD = L::GP_;
+  constexpr int CI = L::CI, CO = L::CO, HI = L::HI, HO = L::HO, GPD = L::GP_, K = L::K, S = L::S, P = L::P, KK = K * K;
   constexpr int NQ = COW / 4;                      // co-quads per workgroup
   constexpr int NT = CI * NQ;                      // active (ci, quad) threads
   constexpr int PSPLIT = 256 / NT;                 // pixel-parity split when there are spare threads
@@ -190,9 +200,9 @@ __global__ __launch_bounds__(256) void k_convT_wgrad(const float* __restrict__ x
   const int ci = tid % CI, q = (tid / CI) % NQ, ps = tid / NT;
   const int co0 = blockIdx.y * COW;
   const int b0 = blockIdx.x * b_per_split, b1 = min(B, b0 + b_per_split);
-  float acc[25][4];
+  float acc[KK][4];
 #pragma unroll
-  for (int t = 0; t < 25; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; acc[t][3] = 0.f; }
+  for (int t = 0; t < KK; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; acc[t][3] = 0.f; }
   for (int b = b0; b < b1; ++b) {
     __syncthreads();
     for (int e = tid; e < HI * HI * CI; e += 256) {
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(256) void k_convT_wgrad(const float* __restrict__ x
       s_x[e] = x[((size_t)b * CI + c) * HI * HI + p];
     }
     for (int e = tid; e < GPD * GPD * COW; e += 256) {
-      const int c = e % COW, xx = (e / COW) % GPD - 1, yy = e / (COW * GPD) - 1;
+      const int c = e % COW, xx = (e / COW) % GPD - P, yy = e / (COW * GPD) - P;
       float v = 0.f;
       if (yy >= 0 && yy < HO && xx >= 0 && xx < HO) v = gy[(((size_t)b * CO + co0 + c) * HO + yy) * HO + xx];
       s_g[e] = v;
@@ -209,13 +219,13 @@ __global__ __launch_bounds__(256) void k_convT_wgrad(const float* __restrict__ x
     for (int p = ps; p < HI * HI; p += PSPLIT) {
       const int iy = p / HI, ix = p % HI;
       const float xv = s_x[p * CI + ci];
-      const float* gp = s_g + ((2 * iy) * GPD + 2 * ix) * COW + q * 4;
+      const float* gp = s_g + ((S * iy) * GPD + S * ix) * COW + q * 4;
 #pragma unroll
-      for (int ky = 0; ky < 5; ++ky) {
+      for (int ky = 0; ky < K; ++ky) {
 #pragma unroll
-        for (int kx = 0; kx < 5; ++kx) {
+        for (int kx = 0; kx < K; ++kx) {
           const float4 g4 = *reinterpret_cast<const float4*>(gp + (ky * GPD + kx) * COW);
-          float* a = acc[ky * 5 + kx];
+          float* a = acc[ky * K + kx];
           a[0] = fmaf(xv, g4.x, a[0]); a[1] = fmaf(xv, g4.y, a[1]); a[2] = fmaf(xv, g4.z, a[2]); a[3] = fmaf(xv, g4.w, a[3]);
         }
       }
@@ -223,25 +233,120 @@ __global__ __launch_bounds__(256) void k_convT_wgrad(const float* __restrict__ x
   }
   // combine the pixel-parity splits through LDS (fixed order), then write the slab
   __syncthreads();
-  float* s_red = tsm;  // [PSPLIT][NT][100]
+  float* s_red = tsm;  // [PSPLIT][NT][KK*4]
   if (PSPLIT > 1) {
 #pragma unroll
-    for (int t = 0; t < 25; ++t)
+    for (int t = 0; t < KK; ++t)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) s_red[((size_t)ps * NT + (tid % NT)) * 100 + t * 4 + c] = acc[t][c];
+      for (int c = 0; c < 4; ++c) s_red[((size_t)ps * NT + (tid % NT)) * (KK * 4) + t * 4 + c] = acc[t][c];
     __syncthreads();
   }
   if (ps == 0) {
-    float* out = part + (size_t)blockIdx.x * CI * CO * 25;
+    float* out = part + (size_t)blockIdx.x * CI * CO * KK;
 #pragma unroll
-    for (int t = 0; t < 25; ++t)
+    for (int t = 0; t < KK; ++t)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float v = acc[t][c];
         if (PSPLIT > 1)
-          for (int s = 1; s < PSPLIT; ++s) v += s_red[((size_t)s * NT + (tid % NT)) * 100 + t * 4 + c];
-        out[((size_t)ci * CO + co0 + q * 4 + c) * 25 + t] = v;
+          for (int sp = 1; sp < PSPLIT; ++sp) v += s_red[((size_t)sp * NT + (tid % NT)) * (KK * 4) + t * 4 + c];
+        out[((size_t)ci * CO + co0 + q * 4 + c) * KK + t] = v;
       }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// decnn.10  ConvTranspose2d(16 -> 1, k5, s1, p2): one output channel, so the register block runs over
+// PIXELS instead of channels.  T1b: a thread owns 4 consecutive output pixels of a row; per (ci, ky) it reads
+// 8 consecutive inputs (2 x ds_read_b128) and the 5 taps of that kernel row (broadcast) for 20 FMAs.
+// ---------------------------------------------------------------------------------------------
+template <int IPB>
+__global__ __launch_bounds__(256) void k_dec10_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ y, int B) {
+  constexpr int CI = 16, H = 28, WP = 32, IMG = CI * WP * WP;   // stored index = i + 2
+  float* s_img = tsm;                  // [IPB][CI][32][32]
+  float* s_w = tsm + IPB * IMG;        // [CI][5][8]  (kx 0..4, padded to 8)
+  const int tid = threadIdx.x;
+  const int b0 = blockIdx.x * IPB;
+  const int nimg = min(IPB, B - b0);
+  for (int e = tid; e < IPB * IMG; e += 256) {
+    const int im = e / IMG, r = e % IMG, ci = r / (WP * WP), yy = (r / WP) % WP - 2, xx = r % WP - 2;
+    float v = 0.f;
+    if (im < nimg && yy >= 0 && yy < H && xx >= 0 && xx < H) v = x[(((size_t)(b0 + im) * CI + ci) * H + yy) * H + xx];
+    s_img[e] = v;
+  }
+  for (int e = tid; e < CI * 5 * 8; e += 256) {
+    const int kx = e % 8, ky = (e / 8) % 5, ci = e / 40;
+    s_w[e] = kx < 5 ? w[(size_t)ci * 25 + ky * 5 + kx] : 0.f;
+  }
+  __syncthreads();
+  const float bv = bias ? bias[0] : 0.f;
+  const int items = nimg * H * 7;
+  for (int it = tid; it < items; it += 256) {
+    const int seg = it % 7, oy = (it / 7) % H, im = it / (7 * H);
+    const int ox0 = seg * 4;
+    float acc[4] = {bv, bv, bv, bv};
+    const float* img = s_img + im * IMG;
+#pragma unroll 2
+    for (int ci = 0; ci < CI; ++ci) {
+#pragma unroll
+      for (int ky = 0; ky < 5; ++ky) {
+        // iy = oy + 2 - ky -> stored row oy + 4 - ky ; stored col of (pixel j, tap kx) = ox0 + j + 4 - kx
+        const float4* rp = reinterpret_cast<const float4*>(img + (ci * WP + (oy + 4 - ky)) * WP + ox0);
+        const float4 a = rp[0], b = rp[1];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const float4 w4 = *reinterpret_cast<const float4*>(s_w + (ci * 5 + ky) * 8);
+        const float w5 = s_w[(ci * 5 + ky) * 8 + 4];
+        const float wk[5] = {w4.x, w4.y, w4.z, w4.w, w5};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int kx = 0; kx < 5; ++kx) acc[j] = fmaf(v[j + 4 - kx], wk[kx], acc[j]);
+      }
+    }
+    *reinterpret_cast<float4*>(y + ((size_t)(b0 + im) * H + oy) * H + ox0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
+// T3b: gw[ci,0,ky,kx] = sum_{b,iy,ix} x[b,ci,iy,ix] gy[b,0,iy-2+ky,ix-2+kx].  thread = (ci, 1 of 16 pixel lanes).
+__global__ __launch_bounds__(256) void k_dec10_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
+                                                      float* __restrict__ part, int B, int b_per_split) {
+  constexpr int CI = 16, H = 28, NP = H * H, XS = NP + 1, GW = 32;   // x rows padded to 785 floats (bank spread)
+  float* s_x = tsm;                    // [CI][785]
+  float* s_g = tsm + CI * XS;          // [32][32], index = o + 2
+  const int tid = threadIdx.x, ci = tid & 15, pl = tid >> 4;
+  const int b0 = blockIdx.x * b_per_split, b1 = min(B, b0 + b_per_split);
+  float acc[25];
+#pragma unroll
+  for (int t = 0; t < 25; ++t) acc[t] = 0.f;
+  for (int b = b0; b < b1; ++b) {
+    __syncthreads();
+    for (int e = tid; e < CI * NP; e += 256) s_x[(e / NP) * XS + e % NP] = x[(size_t)b * CI * NP + e];
+    for (int e = tid; e < GW * GW; e += 256) {
+      const int yy = e / GW - 2, xx = e % GW - 2;
+      s_g[e] = (yy >= 0 && yy < H && xx >= 0 && xx < H) ? gy[(size_t)b * NP + yy * H + xx] : 0.f;
+    }
+    __syncthreads();
+    for (int p = pl; p < NP; p += 16) {
+      const int iy = p / H, ix = p % H;
+      const float xv = s_x[ci * XS + p];
+      const float* gp = s_g + iy * GW + ix;   // (oy + 2) = iy + ky
+#pragma unroll
+      for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) acc[ky * 5 + kx] = fmaf(xv, gp[ky * GW + kx], acc[ky * 5 + kx]);
+    }
+  }
+  __syncthreads();
+  float* s_red = tsm;  // [16 pixel lanes][16 ci][25]
+#pragma unroll
+  for (int t = 0; t < 25; ++t) s_red[(pl * 16 + ci) * 25 + t] = acc[t];
+  __syncthreads();
+  for (int e = tid; e < CI * 25; e += 256) {
+    float v = 0.f;
+    for (int l = 0; l < 16; ++l) v += s_red[l * 400 + e];
+    part[(size_t)blockIdx.x * 400 + e] = v;
   }
 }
 
@@ -259,12 +364,13 @@ __global__ void k_sum_splits_t(const float* __restrict__ part, int nsplit, size_
 // ---------------------------------------------------------------------------------------------
 template <class L> static bool matches(int Ci_conv, int Co_conv, int H, int Ho, int K, int S, int P) {
   // conv geometry of the adjoint: "input" (B, Ci_conv = L::CO, H = L::HO), "output" (B, Co_conv = L::CI, Ho = L::HI)
-  return Ci_conv == L::CO && Co_conv == L::CI && H == L::HO && Ho == L::HI && K == 5 && S == 2 && P == 1;
+  return Ci_conv == L::CO && Co_conv == L::CI && H == L::HO && Ho == L::HI && K == L::K && S == L::S && P == L::P;
 }
 
 template <class L, int IPB>
 static int launch_T1(const float* x, const float* w, const float* bias, float* y, int B, hipStream_t st) {
-  const size_t lds = sizeof(float) * ((size_t)IPB * L::CI * L::HP * L::HP + (size_t)9 * L::CI * L::CO);
+  constexpr int MAXTAPS = ((L::K + L::S - 1) / L::S) * ((L::K + L::S - 1) / L::S);
+  const size_t lds = sizeof(float) * ((size_t)IPB * L::CI * L::HP * L::HP + (size_t)MAXTAPS * L::CI * L::CO);
   auto kern = k_convT_fwd<L, IPB>;
   if (set_max_lds((const void*)kern, lds)) return 1;
   hipLaunchKernelGGL(kern, (B + IPB - 1) / IPB, 256, lds, st, x, w, bias, y, B);
@@ -273,7 +379,7 @@ static int launch_T1(const float* x, const float* w, const float* bias, float* y
 
 template <class L, int IPB, int COC>
 static int launch_T2(const float* gy, const float* w, float* gx, int B, hipStream_t st) {
-  const size_t lds = sizeof(float) * ((size_t)IPB * L::CO * L::GP_ * L::GP_ + (size_t)COC * 25 * L::CI);
+  const size_t lds = sizeof(float) * ((size_t)IPB * L::CO * L::GP_ * L::GP_ + (size_t)COC * L::K * L::K * L::CI);
   auto kern = k_convT_bwd_data<L, IPB, COC>;
   if (set_max_lds((const void*)kern, lds)) return 1;
   hipLaunchKernelGGL(kern, (B + IPB - 1) / IPB, 256, lds, st, gy, w, gx, B);
@@ -282,9 +388,9 @@ static int launch_T2(const float* gy, const float* w, float* gx, int B, hipStrea
 
 template <class L, int COW>
 static int launch_T3(const float* x, const float* gy, float* gw, float* scratch, int B, hipStream_t st) {
-  constexpr int NT = L::CI * (COW / 4), PSPLIT = 256 / NT;
+  constexpr int NT = L::CI * (COW / 4), PSPLIT = 256 / NT, KK = L::K * L::K;
   size_t fl = (size_t)L::HI * L::HI * L::CI + (size_t)L::GP_ * L::GP_ * COW;
-  const size_t red = (size_t)PSPLIT * NT * 100;
+  const size_t red = PSPLIT > 1 ? (size_t)PSPLIT * NT * KK * 4 : 0;
   if (red > fl) fl = red;
   const size_t lds = sizeof(float) * fl;
   int nsplit = B < 256 ? B : 256;
@@ -293,12 +399,11 @@ static int launch_T3(const float* x, const float* gy, float* gw, float* scratch,
   auto kern = k_convT_wgrad<L, COW>;
   if (set_max_lds((const void*)kern, lds)) return 1;
   hipLaunchKernelGGL(kern, dim3(nsplit, L::CO / COW), 256, lds, st, x, gy, scratch, B, bps);
-  const size_t n = (size_t)L::CI * L::CO * 25;
+  const size_t n = (size_t)L::CI * L::CO * KK;
   hipLaunchKernelGGL(k_sum_splits_t, (unsigned)((n + 255) / 256), 256, 0, st, scratch, nsplit, n, gw);
   return check_launch("convT_wgrad_tiled");
 }
 
-size_t tiled_wgrad_scratch(int B) { return (size_t)(B < 256 ? B : 256) * 64 * 32 * 25; }
 
 // ConvTranspose2d forward (called with the conv geometry of its adjoint, as conv2d_bwd_data is)
 int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co, int K, int S,
@@ -306,6 +411,15 @@ int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx
   if (H != W || Ho != Wo) return -1;
   if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec7, 3>(gy, w, bias, gx, B, st);
   if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec4, 3>(gy, w, bias, gx, B, st);
+  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec1, 8>(gy, w, bias, gx, B, st);
+  if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) {
+    constexpr int IPB = 2;
+    const size_t lds = sizeof(float) * ((size_t)IPB * 16 * 32 * 32 + 16 * 5 * 8);
+    auto kern = k_dec10_fwd<IPB>;
+    if (set_max_lds((const void*)kern, lds)) return 1;
+    hipLaunchKernelGGL(kern, (B + IPB - 1) / IPB, 256, lds, st, gy, w, bias, gx, B);
+    return check_launch("dec10_fwd");
+  }
   return -1;
 }
 
@@ -315,6 +429,8 @@ int tiled_fwd(const float* x, const float* w, const float* bias, float* y, int B
   if (H != W || Ho != Wo || bias) return -1;
   if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec7, 2, 8>(x, w, y, B, st);
   if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec4, 3, 8>(x, w, y, B, st);
+  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec1, 8, 32>(x, w, y, B, st);
+  if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec10, 1, 1>(x, w, y, B, st);
   return -1;
 }
 
@@ -324,6 +440,17 @@ int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch,
   if (H != W || Ho != Wo) return -1;
   if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec7, 16>(gy, x, gw, scratch, B, st);
   if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec4, 16>(gy, x, gw, scratch, B, st);
+  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec1, 32>(gy, x, gw, scratch, B, st);
+  if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) {
+    int nsplit = B < 256 ? B : 256;
+    const int bps = (B + nsplit - 1) / nsplit;
+    nsplit = (B + bps - 1) / bps;
+    const size_t lds = sizeof(float) * (16 * 785 + 32 * 32);   // >= the [16][16][25] reduction buffer
+    if (set_max_lds((const void*)k_dec10_wgrad, lds)) return 1;
+    hipLaunchKernelGGL(k_dec10_wgrad, nsplit, 256, lds, st, gy, x, scratch, B, bps);
+    hipLaunchKernelGGL(k_sum_splits_t, 2, 256, 0, st, scratch, nsplit, (size_t)400, gw);
+    return check_launch("dec10_wgrad");
+  }
   return -1;
 }
 
