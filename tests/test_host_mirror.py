@@ -73,3 +73,21 @@ def test_no_cpu_fallback():
     gp = SVGP_Layer(6, 6, 16, 32)
     with pytest.raises(_lib.GpodeError):
         gp.build_cache()
+
+
+def test_cli_argument_surface_matches_reference():
+    """Every flag of experiments/main.py:23-114 with the same default and type behaviour."""
+    from vae_gp_ode_amd.main import FLAGS, make_parser
+    assert len(FLAGS) == 39
+    a = make_parser().parse_args([])
+    expect = dict(data_root='data/', task='mnist', mask=True, value=3, data_seqlen=100, batch=20, T=16, Ndata=360, Ntest=40,
+                  rotrand=True, latent_dim=6, n_filt=8, frames=5, pretrained=False, kernel='RBF', num_features=256,
+                  num_inducing=100, dimwise=True, variance=0.7, lengthscale=2.0, q_diag=False, ode=1, D_in=6, D_out=6,
+                  solver='euler', ts_dense_scale=2, use_adjoint=False, dt=0.1, Nepoch=5000, lr=0.001, eval_sample_size=128,
+                  save='results/mnist', seed=121, log_freq=5, device='cuda:0', continue_training=False, model_path='None', Troll=2)
+    for k, v in expect.items():
+        assert getattr(a, k) == v, k
+    b = make_parser().parse_args(['--kernel', 'DF', '--solver', 'rk4', '--dimwise', 'False', '--ode', '2', '--mask', 'False'])
+    assert b.kernel == 'DF' and b.solver == 'rk4' and b.dimwise is False and b.ode == 2 and b.mask is False
+    with pytest.raises(SystemExit):  # 'euler' is only accepted as the default (SURVEY F1)
+        make_parser().parse_args(['--solver', 'euler'])
