@@ -16,6 +16,7 @@
 //   T3 convT_wgrad d/d weight: thread = (input channel, 4 output channels) x 25 taps = 100 accumulators,
 //                  images streamed through LDS; batch split over workgroups, slabs summed in fixed order
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "gp_launch.hpp"
 
 namespace gp {
@@ -31,6 +32,9 @@ template <int CI_, int CO_, int HI_, int HO_, int OP_, int K_ = 5, int S_ = 2, i
   static constexpr int QMAX = (HO - 1 + P) / S;                      // largest qy
   static constexpr int PH = cmax(0, QMAX - (HI - 1));                // zero rows/cols after
   static constexpr int HP = HI + PL + PH;                            // padded input extent
+  // channel-plane stride of the staged image: == 16 (mod 32) floats, so that the four 16-lane groups of an MFMA
+  // operand fetch (4 consecutive channels x 16 consecutive pixels) fall on disjoint LDS banks
+  static constexpr int PS = ((HP * HP + 15) / 32) * 32 + 16;
   static constexpr int GP_ = cmax((HI - 1) * S + K, HO + P);         // padded grad_output extent, index = oy + P
 };
 using Dec1 = CTLayer<32, 64, 4, 6, 0, 3, 1, 0>;
@@ -103,6 +107,120 @@ __global__ __launch_bounds__(256) void k_convT_fwd(const float* __restrict__ x, 
       float* yp = y + (((size_t)(b0 + im) * CO + g * 16) * HO + oy) * HO + ox;
 #pragma unroll
       for (int c = 0; c < 16; ++c) yp[(size_t)c * HO * HO] = acc[c];
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// T1m: the same gather-form transposed convolution as an implicit GEMM on the matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32, D = A(16x4) B(4x16) + C).
+//   rows  m = output pixels of one stride-parity class (all staged images), 16 per tile
+//   cols  n = output channels, 16 per tile
+//   k       = (tap, input channel), 4 input channels per MFMA
+// Operand fetch is one ds_read_b32 per lane per MFMA: lane l supplies A[m = l & 15][k = l >> 4] =
+// image[ci0 + (l >> 4)][qy - ty][qx - tx] (zero-padded image: no branches) and B[k = l >> 4][n = l & 15] =
+// w_class[tap][ci0 + (l >> 4)][n]; a B fragment is reused by the TG pixel tiles a wave keeps in flight.
+// Against the register-blocked VALU kernel this cuts LDS operand traffic per MAC by ~4.5x, which is
+// what that kernel is bound by.  Result layout (lane: col n = l & 15, rows 4 (l >> 4) + r).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <class L, int IPB, int TG>
+__global__ __launch_bounds__(256) void k_convT_fwd_mfma(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int B) {
+  constexpr int CI = L::CI, CO = L::CO, HI = L::HI, HO = L::HO, HP = L::HP, K = L::K, S = L::S, P = L::P, PL = L::PL;
+  static_assert(CO % 16 == 0 && CI % 4 == 0, "MFMA tiling");
+  constexpr int NCO = CO / 16;
+  constexpr int PS = L::PS;
+  constexpr int IMG = CI * PS;
+  float* s_img = tsm;
+  float* s_w = tsm + IPB * IMG;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int b0 = blockIdx.x * IPB;
+  const int nimg = min(IPB, B - b0);
+  for (int e = tid; e < IPB * IMG; e += 256) {
+    const int im = e / IMG, r = e % IMG, ci = r / PS, q = r % PS, yy = q / HP - PL, xx = q % HP - PL;
+    float v = 0.f;
+    if (im < nimg && q < HP * HP && yy >= 0 && yy < HI && xx >= 0 && xx < HI) v = x[(((size_t)(b0 + im) * CI + ci) * HI + yy) * HI + xx];
+    s_img[e] = v;
+  }
+  for (int cls = 0; cls < S * S; ++cls) {
+    const int py = cls / S, px = cls % S;
+    const int nty = (K - py + S - 1) / S, ntx = (K - px + S - 1) / S;
+    __syncthreads();
+    for (int e = tid; e < nty * ntx * CI * CO; e += 256) {
+      const int co = e % CO, ci = (e / CO) % CI, tap = e / (CO * CI);
+      const int ky = py + S * (tap / ntx), kx = px + S * (tap % ntx);
+      s_w[e] = w[(((size_t)ci * CO + co) * K + ky) * K + kx];
+    }
+    __syncthreads();
+    const int qy0 = (P - py + S - 1 > 0) ? (P - py + S - 1) / S : 0, qx0 = (P - px + S - 1 > 0) ? (P - px + S - 1) / S : 0;
+    const int ny = (HO - 1 + P - py) / S - qy0 + 1, nx = (HO - 1 + P - px) / S - qx0 + 1;
+    const int npc = ny * nx;                       // pixels of the class per image
+    const int mtot = nimg * npc;
+    const int ntiles = (mtot + 15) / 16;
+    for (int t0 = wave * TG; t0 < ntiles; t0 += 4 * TG) {
+      // A-operand base address of this lane's pixel in each tile (invalid rows alias pixel 0; masked at the store)
+      int abase[TG];
+#pragma unroll
+      for (int g = 0; g < TG; ++g) {
+        int m = (t0 + g) * 16 + lr;
+        m = m < mtot ? m : 0;
+        const int im = m / npc, p = m % npc;
+        abase[g] = im * IMG + lk * PS + (qy0 + p / nx + PL) * HP + (qx0 + p % nx + PL);
+      }
+      f32x4 acc[TG][NCO];
+#pragma unroll
+      for (int g = 0; g < TG; ++g)
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) acc[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ty = 0; ty < nty; ++ty) {
+        for (int tx = 0; tx < ntx; ++tx) {
+          const int toff = -ty * HP - tx;                                   // iy = qy - ty, ix = qx - tx
+          const float* wp = s_w + ((ty * ntx + tx) * CI + lk) * CO + lr;
+          // fetch the operands of KB k-steps first, then issue their MFMAs: left to itself hipcc emits
+          // ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per step, exposing a full LDS latency (~100 cycles) per MFMA
+          constexpr int KB = (CI / 4) < 8 ? (CI / 4) : 8;
+#pragma unroll
+          for (int cb = 0; cb < CI; cb += 4 * KB) {
+            float bf[KB][NCO], af[KB][TG];
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+#pragma unroll
+              for (int c = 0; c < NCO; ++c) bf[kk][c] = wp[(cb + 4 * kk) * CO + c * 16];
+#pragma unroll
+              for (int g = 0; g < TG; ++g) af[kk][g] = s_img[abase[g] + toff + (cb + 4 * kk) * PS];
+            }
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+              for (int g = 0; g < TG; ++g)
+#pragma unroll
+                for (int c = 0; c < NCO; ++c)
+                  acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[kk][c], af[kk][g], acc[g][c], 0, 0, 0);  // C^T: rows = channels, cols = pixels
+          }
+        }
+      }
+      // transposed product: lane holds pixel (t0+g)*16 + lr and channels c*16 + 4 lk + r -> for a fixed r the 16 lanes of a
+      // group write 16 neighbouring pixels of one channel plane
+#pragma unroll
+      for (int g = 0; g < TG; ++g) {
+        const int m = (t0 + g) * 16 + lr;
+        if (m < mtot) {
+          const int im = m / npc, p = m % npc;
+          const int oy = S * (qy0 + p / nx) + py - P, ox = S * (qx0 + p % nx) + px - P;
+          float* yp = y + ((size_t)(b0 + im) * CO * HO + oy) * HO + ox;
+#pragma unroll
+          for (int c = 0; c < NCO; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int co = c * 16 + 4 * lk + r;
+              yp[(size_t)co * HO * HO] = acc[g][c][r] + (bias ? bias[co] : 0.f);
+            }
+        }
+      }
     }
   }
 }
@@ -367,10 +485,24 @@ template <class L> static bool matches(int Ci_conv, int Co_conv, int H, int Ho, 
   return Ci_conv == L::CO && Co_conv == L::CI && H == L::HO && Ho == L::HI && K == L::K && S == L::S && P == L::P;
 }
 
+static bool use_mfma() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("GPODE_CONV_VALU"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
+
 template <class L, int IPB>
 static int launch_T1(const float* x, const float* w, const float* bias, float* y, int B, hipStream_t st) {
   constexpr int MAXTAPS = ((L::K + L::S - 1) / L::S) * ((L::K + L::S - 1) / L::S);
   const size_t lds = sizeof(float) * ((size_t)IPB * L::CI * L::HP * L::HP + (size_t)MAXTAPS * L::CI * L::CO);
+  if (use_mfma()) {
+    constexpr int TG = L::CO >= 64 ? 1 : (L::CO >= 32 ? 2 : 4);
+    const size_t ldsm = sizeof(float) * ((size_t)IPB * L::CI * L::PS + (size_t)MAXTAPS * L::CI * L::CO);
+    auto km = k_convT_fwd_mfma<L, IPB, TG>;
+    if (set_max_lds((const void*)km, ldsm)) return 1;
+    hipLaunchKernelGGL(km, (B + IPB - 1) / IPB, 256, ldsm, st, x, w, bias, y, B);
+    return check_launch("convT_fwd_mfma");
+  }
   auto kern = k_convT_fwd<L, IPB>;
   if (set_max_lds((const void*)kern, lds)) return 1;
   hipLaunchKernelGGL(kern, (B + IPB - 1) / IPB, 256, lds, st, x, w, bias, y, B);
