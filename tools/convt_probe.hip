@@ -24,9 +24,29 @@ template <class L> void run(const char* name, int B) {
   }
   hipFree(x); hipFree(w); hipFree(b); hipFree(y);
 }
+template <class L> void runb(const char* name, int B) {
+  using namespace gp;
+  float *gy, *w, *gx;
+  hipMalloc(&gy, sizeof(float) * B * L::CO * L::HO * L::HO); hipMalloc(&w, sizeof(float) * L::CI * L::CO * L::K * L::K);
+  hipMalloc(&gx, sizeof(float) * B * L::CI * L::HI * L::HI);
+  hipMemset(gy, 0, sizeof(float) * B * L::CO * L::HO * L::HO); hipMemset(w, 0, sizeof(float) * L::CI * L::CO * L::K * L::K);
+  for (int rep = 0; rep < 3; ++rep) {
+    unsigned long long z[8] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z));
+    tiled_fwd(gy, w, nullptr, gx, B, L::CO, L::HO, L::HO, L::CI, L::K, L::S, L::P, L::HI, L::HI, 0);
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(z, HIP_SYMBOL(g_probe), sizeof(z));
+    if (rep == 2)
+      printf("%s B=%d cycles: wstage %llu barrier %llu scatter %llu mma %llu store %llu total %llu\n", name, B, z[0], z[1], z[2], z[3], z[4], z[5]);
+  }
+  hipFree(gy); hipFree(w); hipFree(gx);
+}
 int main() {
   run<gp::Dec7>("dec7", 4096);
   run<gp::Dec4>("dec4", 4096);
   run<gp::Dec1>("dec1", 4096);
+  runb<gp::Dec7>("dec7 bwd-data", 4096);
+  runb<gp::Dec4>("dec4 bwd-data", 4096);
+  runb<gp::Dec1>("dec1 bwd-data", 4096);
   return 0;
 }

@@ -1,0 +1,332 @@
+// conv_mfma.hpp -- implicit-GEMM convolution engine on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32)
+// for the decoder's ConvTranspose2d layers (reference: experiments/model/core/vae.py:64-84, decnn.1/4/7) in both
+// directions:
+//   FwdPolicy      y  = convT(x, w) + bias        (gather form, one GEMM per stride-parity class)
+//   BwdDataPolicy  gx = conv(gy, w)               (the adjoint: an ordinary strided convolution)
+//
+// GEMM view per image group:  D[n][m] = sum_k  W[k][n] * X[k][m]
+//   m = output pixels (16 per tile; lanes 0..15 of every 16-lane group),
+//   n = output channels (16 per tile),  k = (tap, source channel), 4 source channels per MFMA.
+// The product is computed transposed (A := weights, B := pixels), so a lane ends up with one pixel and
+// 4 channels per tile and the global stores of a 16-lane group hit neighbouring pixels of one channel plane.
+//
+// Persistent kernel, one workgroup of NTHR = 512 threads per CU (two wavefronts per SIMD: one wavefront's LDS
+// operand waits hide under the other's MFMAs -- tools/mfma_probe.hip measures 32 cycles per MFMA, 58 with a
+// dependent LDS fetch and one wavefront, 34 with two):
+//   * the weights of all classes for NCS output channels stay resident in LDS ([cls][tap][k][n], staged once
+//     per pass; NC / NCS passes over the image groups);
+//   * source images live in LDS as zero-padded planes whose stride PS is chosen so that the four 16-lane
+//     groups of an operand fetch (4 consecutive k planes x 16 pixels) fall on disjoint banks;
+//   * the next group's source (contiguous floats) is fetched as float4 into registers right after the current
+//     group was scattered to LDS, so the global latency hides under the current group's MFMAs;
+//   * operands of k-step s+1 are fetched into a second register set while the MFMAs of step s issue;
+//   * the (class, pixel tile, channel-tile column) jobs of a group are split over the wavefronts by cost
+//     (taps), SIMD-wise contiguous.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <type_traits>
+
+namespace gp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+// phase timing for tools/convt_probe.hip (compiled out of the library)
+#ifdef CONVT_PROBE
+__device__ unsigned long long g_probe[8];
+#define PROBE_T(v) const long long v = clock64()
+#define PROBE_ADD(i, v) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[i] += (unsigned long long)(clock64() - (v)); } while (0)
+#else
+#define PROBE_T(v)
+#define PROBE_ADD(i, v)
+#endif
+
+constexpr int cmax_(int a, int b) { return a > b ? a : b; }
+// plane stride >= n with stride == 16 (mod 32): unit-stride pixels, 4 planes -> 4 disjoint 16-bank groups per half wave
+constexpr int plane_stride_unit(int n) { return ((n + 15) / 32) * 32 + 16; }
+
+// ---------------------------------------------------------------------------------------------
+// forward transposed convolution: source = x (CI planes HI x HI), output = y (CO planes HO x HO)
+// ---------------------------------------------------------------------------------------------
+template <class L, int NCS_> struct FwdPolicy {
+  static constexpr int KC = L::CI, NC = L::CO, NCS = NCS_, NCLS = L::S * L::S, KK = L::K * L::K;
+  static constexpr int SH = L::HI, OH = L::HO, HP = L::HP, PADL = L::PL;
+  static constexpr int PS = plane_stride_unit(HP * HP);
+  static constexpr int WROW = NCS;                           // slab row stride [cls][tap][k][n]
+  static constexpr int WSLAB = KK * KC * WROW;
+  static constexpr int NWE = KC * NCS * KK;                  // weights per pass
+  static constexpr int class_tap_offset(int cls) {
+    int off = 0;
+    for (int c = 0; c < cls; ++c) off += ((L::K - c / L::S + L::S - 1) / L::S) * ((L::K - c % L::S + L::S - 1) / L::S);
+    return off;
+  }
+  // stride-parity class CLS = py * S + px: taps ky = py + S t, output pixels oy = S qy + py - P in [0, HO), source iy = qy - t
+  template <int CLS> struct C {
+    static constexpr int py = CLS / L::S, px = CLS % L::S;
+    static constexpr int nty = (L::K - py + L::S - 1) / L::S, ntx = (L::K - px + L::S - 1) / L::S, ntaps = nty * ntx;
+    static constexpr int qy0 = cmax_(0, (L::P - py + L::S - 1) / L::S), qx0 = cmax_(0, (L::P - px + L::S - 1) / L::S);
+    static constexpr int ny = (L::HO - 1 + L::P - py) / L::S - qy0 + 1, nx = (L::HO - 1 + L::P - px) / L::S - qx0 + 1;
+    static constexpr int npc = ny * nx;                      // pixels of the class per image
+    static constexpr int slab_taps = class_tap_offset(CLS);
+    static __device__ __forceinline__ int tap_off(int t) { return -(t / ntx) * HP - t % ntx; }
+    static __device__ __forceinline__ int pix_addr(int p) { return (qy0 + p / nx + PADL) * HP + qx0 + p % nx + PADL; }
+    static __device__ __forceinline__ int out_off(int p) {
+      return (L::S * (qy0 + p / nx) + py - L::P) * OH + L::S * (qx0 + p % nx) + px - L::P;
+    }
+  };
+  // pass-local weight element e (runs of NCS*KK contiguous floats per source channel) -> global index, slab index
+  static __device__ __forceinline__ size_t w_src(int e, int n0) {
+    const int ci = e / (NCS * KK), r = e % (NCS * KK);
+    return ((size_t)ci * NC + n0) * KK + r;
+  }
+  static __device__ __forceinline__ int w_dst(int e) {
+    const int ci = e / (NCS * KK), r = e % (NCS * KK), col = r / KK, ky = (r % KK) / L::K, kx = r % L::K;
+    const int py = ky % L::S, px = kx % L::S;
+    int off = 0;
+    for (int c = 0; c < py * L::S + px; ++c) off += ((L::K - c / L::S + L::S - 1) / L::S) * ((L::K - c % L::S + L::S - 1) / L::S);
+    const int tap = (ky / L::S) * ((L::K - px + L::S - 1) / L::S) + kx / L::S;
+    return ((off + tap) * KC + ci) * WROW + col;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// d/d input of the transposed convolution: source = gy (CO planes HO x HO, stored at index oy + P),
+// output = gx (CI planes HI x HI); gx[ci][iy][ix] = sum_{co,ky,kx} gy[co][S iy - P + ky][S ix - P + kx] w[ci][co][ky][kx]
+// ---------------------------------------------------------------------------------------------
+template <class L, int NCS_> struct BwdDataPolicy {
+  static constexpr int KC = L::CO, NC = L::CI, NCS = NCS_, NCLS = 1, KK = L::K * L::K;
+  static constexpr int SH = L::HO, OH = L::HI, HP = L::GP_, PADL = L::P;
+  // pixel stride S in the plane: S = 2 wants an odd plane stride (planes k, k+1 then cover the even and the odd banks)
+  static constexpr int PS = L::S == 1 ? plane_stride_unit(HP * HP) : (HP * HP) | 1;
+  static constexpr int WROW = NCS;                           // [tap][co][ci_local]
+  static constexpr int WSLAB = KK * KC * WROW;
+  static constexpr int NWE = KC * NCS * KK;
+  template <int CLS> struct C {
+    static constexpr int ntaps = KK, ntx = L::K, npc = L::HI * L::HI, nx = L::HI, slab_taps = 0;
+    static __device__ __forceinline__ int tap_off(int t) { return (t / L::K) * HP + t % L::K; }
+    static __device__ __forceinline__ int pix_addr(int p) { return L::S * (p / nx) * HP + L::S * (p % nx); }
+    static __device__ __forceinline__ int out_off(int p) { return p; }
+  };
+  // w[ci][co][ky][kx]: a pass over NCS input channels is one contiguous block
+  static __device__ __forceinline__ size_t w_src(int e, int n0) { return (size_t)n0 * KC * KK + e; }
+  static __device__ __forceinline__ int w_dst(int e) {
+    const int cil = e / (KC * KK), co = (e / KK) % KC, tap = e % KK;
+    return (tap * KC + co) * WROW + cil;
+  }
+};
+
+// All k-steps (tap x 4*KB source channels) of NG pixel tiles x NCJ channel tiles of one wavefront.
+template <class CG, int NG, int TG, int NCJ, int KC, int WROW, int PS>
+__device__ __forceinline__ void igemm_tile_mma(const float* __restrict__ s_img, const float* __restrict__ sw, const int (&abase)[TG],
+                                               int lk, int lr, f32x4 (&acc)[TG][NCJ]) {
+  constexpr int KB = (KC / 4) < 8 ? (KC / 4) : 8;   // MFMA k-steps per fetch batch
+  constexpr int NB = KC / (4 * KB);                 // batches per tap
+  constexpr int nsteps = CG::ntaps * NB;
+  float bfA[KB][NCJ], afA[KB][NG], bfB[KB][NCJ], afB[KB][NG];
+  auto fetch = [&](int s, float (&bf)[KB][NCJ], float (&af)[KB][NG]) {
+    const int t = s / NB, cb = (s % NB) * 4 * KB;
+    const float* wp = sw + ((size_t)t * KC + cb + lk) * WROW + lr;
+    const int ao = CG::tap_off(t) + cb * PS;
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) {
+#pragma unroll
+      for (int c = 0; c < NCJ; ++c) bf[kk][c] = wp[4 * kk * WROW + c * 16];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) af[kk][g] = s_img[abase[g] + ao + 4 * kk * PS];
+    }
+  };
+  auto mma = [&](const float (&bf)[KB][NCJ], const float (&af)[KB][NG]) {
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int c = 0; c < NCJ; ++c)               // rows = channels, cols = pixels; consecutive MFMAs hit different accumulators
+          acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[kk][c], af[kk][g], acc[g][c], 0, 0, 0);
+  };
+  fetch(0, bfA, afA);
+  int s = 0;
+  while (true) {
+    if (s + 1 < nsteps) fetch(s + 1, bfB, afB);
+    mma(bfA, afA);
+    if (++s >= nsteps) break;
+    if (s + 1 < nsteps) fetch(s + 1, bfA, afA);
+    mma(bfB, afB);
+    if (++s >= nsteps) break;
+  }
+}
+
+extern __shared__ __attribute__((aligned(16))) float igemm_smem[];
+
+// grid.x <= number of CUs; block NTHR.  TG: pixel tiles per job sharing the weight fragments (needs NCJ == NCS / 16);
+// NCJ: channel tiles per job.
+template <class PL, int IPB, int TG, int NCJ, int NTHR>
+__global__ __launch_bounds__(NTHR) void k_conv_igemm(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y, int B) {
+  constexpr int KC = PL::KC, NC = PL::NC, NCS = PL::NCS, NCLS = PL::NCLS, SH = PL::SH, OH = PL::OH, HP = PL::HP, PS = PL::PS;
+  constexpr int PADL = PL::PADL, WROW = PL::WROW, NWE = PL::NWE;
+  static_assert(NCS % 16 == 0 && NC % NCS == 0 && KC % 4 == 0 && NTHR % 256 == 0, "MFMA tiling");
+  constexpr int NW = NTHR / 64;
+  constexpr int NCO = NCS / 16;                      // channel tiles per pass
+  static_assert(NCO % NCJ == 0, "channel tiles per job");
+  constexpr int NJ = NCO / NCJ;                      // job columns per pixel tile
+  static_assert(NJ == 1 || TG == 1, "tile groups share all channel tiles");
+  constexpr int IMG = KC * PS;
+  static_assert(IMG % 4 == 0, "float4 zero fill");
+  constexpr int SRC = KC * SH * SH;                  // floats per source image
+  static_assert(SRC % 4 == 0, "float4 source fetch");
+  constexpr int NLD = (IPB * SRC / 4 + NTHR - 1) / NTHR;   // float4 fetches per thread per group
+  float* s_img = igemm_smem;                         // [IPB][KC][PS] zero padded planes
+  float* s_w = igemm_smem + IPB * IMG;               // [cls][tap][KC][WROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  const int ngroups = (B + IPB - 1) / IPB;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  // wavefront w runs on SIMD w & 3: order the wavefronts SIMD-major so that each SIMD owns a contiguous cost range
+  const int jw = (wave & 3) * (NW / 4) + (wave >> 2);
+
+  PROBE_T(pt_all);
+  for (int e = tid; e < IPB * IMG / 4; e += NTHR) reinterpret_cast<float4*>(s_img)[e] = float4{0.f, 0.f, 0.f, 0.f};
+
+  for (int pass = 0; pass < NC / NCS; ++pass) {
+    const int n0 = pass * NCS;
+    __syncthreads();                                 // previous pass done with the slabs
+    PROBE_T(pt_w);
+    for (int base = 0; base < NWE; base += NTHR * 8) {     // batches of 8 loads in flight per thread
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = base + tid + NTHR * u;
+        v[u] = e < NWE ? w[PL::w_src(e, n0)] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = base + tid + NTHR * u;
+        if (e < NWE) s_w[PL::w_dst(e)] = v[u];
+      }
+    }
+    PROBE_ADD(0, pt_w);
+
+    float4 pre[NLD];
+    auto prefetch = [&](int grp) {
+      const int b0 = grp * IPB;
+      const int nf4 = min(IPB, B - b0) * (SRC / 4);
+      const float4* src = x4 + (size_t)b0 * (SRC / 4);
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int f = tid + NTHR * i;
+        if (f < nf4) pre[i] = src[f];
+      }
+    };
+    if ((int)blockIdx.x < ngroups) prefetch(blockIdx.x);
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+      const int b0 = grp * IPB;
+      const int nimg = min(IPB, B - b0);
+      PROBE_T(pt_b1);
+      __syncthreads();                               // previous group's MFMAs have read s_img; zero fill / slabs staged
+      PROBE_ADD(1, pt_b1);
+      PROBE_T(pt_sc);
+      {
+        const int nf4 = nimg * (SRC / 4);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+          const int f = tid + NTHR * i;
+          if (f < nf4) {
+            const float v[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int e = 4 * f + k, pl = e / (SH * SH), q = e % (SH * SH);
+              s_img[pl * PS + (q / SH + PADL) * HP + q % SH + PADL] = v[k];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      PROBE_ADD(2, pt_sc);
+      if (grp + (int)gridDim.x < ngroups) prefetch(grp + gridDim.x);
+
+      // cost (k-steps) of all jobs of the group, and this wavefront's share [lo, hi) of it
+      int wtot = 0;
+      static_for<NCLS>([&](auto c) {
+        using G = typename PL::template C<decltype(c)::value>;
+        wtot += ((nimg * G::npc + 15) / 16) * NJ * G::ntaps;
+      });
+      const int lo = (wtot * jw) / NW, hi = (wtot * (jw + 1)) / NW;
+      int cbase = 0;
+      static_for<NCLS>([&](auto c) {
+        using G = typename PL::template C<decltype(c)::value>;
+        constexpr int ntaps = G::ntaps, npc = G::npc;
+        const float* swc = s_w + G::slab_taps * KC * WROW;
+        const int mtot = nimg * npc;
+        const int njobs = ((mtot + 15) / 16) * NJ;
+        // job u of this class belongs to the wavefront whose range holds its cost midpoint
+        const int nlo = lo - cbase - ntaps / 2, nhi = hi - cbase - ntaps / 2;
+        const int ub = min(njobs, nlo <= 0 ? 0 : (nlo + ntaps - 1) / ntaps), ue = min(njobs, nhi <= 0 ? 0 : (nhi + ntaps - 1) / ntaps);
+        cbase += njobs * ntaps;
+        for (int u0 = ub; u0 < ue; u0 += TG) {
+          const int ng = min(TG, ue - u0);
+          const int t0 = u0 / NJ, jc = u0 % NJ;      // NJ > 1 implies TG == 1
+          const float* sw = swc + jc * NCJ * 16;
+          // B-operand base address of this lane's pixel in each tile (invalid rows alias pixel 0; masked at the store)
+          int abase[TG];
+#pragma unroll
+          for (int g = 0; g < TG; ++g) {
+            int m = (t0 + g) * 16 + lr;
+            m = (g < ng && m < mtot) ? m : 0;
+            const int im = m / npc, p = m % npc;
+            abase[g] = im * IMG + lk * PS + G::pix_addr(p);
+          }
+          f32x4 acc[TG][NCJ];
+#pragma unroll
+          for (int g = 0; g < TG; ++g)
+#pragma unroll
+            for (int cc = 0; cc < NCJ; ++cc) acc[g][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+          float bv[NCJ][4];                         // in flight during the MFMAs
+#pragma unroll
+          for (int cc = 0; cc < NCJ; ++cc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[cc][r] = bias ? bias[n0 + (jc * NCJ + cc) * 16 + 4 * lk + r] : 0.f;
+          PROBE_T(pt_mm);
+          switch (ng) {                              // wave-uniform
+            case 1: igemm_tile_mma<G, 1, TG, NCJ, KC, WROW, PS>(s_img, sw, abase, lk, lr, acc); break;
+            case 2: if constexpr (TG >= 2) igemm_tile_mma<G, 2, TG, NCJ, KC, WROW, PS>(s_img, sw, abase, lk, lr, acc); break;
+            case 3: if constexpr (TG >= 3) igemm_tile_mma<G, 3, TG, NCJ, KC, WROW, PS>(s_img, sw, abase, lk, lr, acc); break;
+            default: if constexpr (TG >= 4) igemm_tile_mma<G, 4, TG, NCJ, KC, WROW, PS>(s_img, sw, abase, lk, lr, acc); break;
+          }
+          PROBE_ADD(3, pt_mm);
+          PROBE_T(pt_st);
+          // lane: pixel (t0+g)*16 + lr, channels (jc*NCJ + cc)*16 + 4 lk + r
+#pragma unroll
+          for (int g = 0; g < TG; ++g) {
+            const int m = (t0 + g) * 16 + lr;
+            if (g < ng && m < mtot) {
+              const int im = m / npc, p = m % npc;
+              const int ch0 = n0 + jc * NCJ * 16 + 4 * lk;
+              float* yp = y + ((size_t)(b0 + im) * NC + ch0) * (OH * OH) + G::out_off(p);
+#pragma unroll
+              for (int cc = 0; cc < NCJ; ++cc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  yp[(size_t)(cc * 16 + r) * (OH * OH)] = acc[g][cc][r] + bv[cc][r];
+            }
+          }
+          PROBE_ADD(4, pt_st);
+        }
+      });
+    }
+  }
+  PROBE_ADD(5, pt_all);
+}
+
+template <class PL, int IPB> constexpr size_t igemm_lds_bytes() {
+  return sizeof(float) * ((size_t)IPB * PL::KC * PL::PS + (size_t)PL::WSLAB);
+}
+
+}  // namespace gp

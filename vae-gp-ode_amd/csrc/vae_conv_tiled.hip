@@ -18,8 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstdint>
-#include <type_traits>
 #include "gp_launch.hpp"
+#include "conv_mfma.hpp"
 
 namespace gp {
 
@@ -38,14 +38,6 @@ template <int CI_, int CO_, int HI_, int HO_, int OP_, int K_ = 5, int S_ = 2, i
   // operand fetch (4 consecutive channels x 16 consecutive pixels) fall on disjoint LDS banks
   static constexpr int PS = ((HP * HP + 15) / 32) * 32 + 16;
   static constexpr int GP_ = cmax((HI - 1) * S + K, HO + P);         // padded grad_output extent, index = oy + P
-};
-// stride-parity class CLS = py * S + px of a layer: taps ky = py + S t, output pixels oy = S qy + py - P in [0, HO)
-template <class L, int CLS> struct CTClass {
-  static constexpr int py = CLS / L::S, px = CLS % L::S;
-  static constexpr int nty = (L::K - py + L::S - 1) / L::S, ntx = (L::K - px + L::S - 1) / L::S, ntaps = nty * ntx;
-  static constexpr int qy0 = cmax(0, (L::P - py + L::S - 1) / L::S), qx0 = cmax(0, (L::P - px + L::S - 1) / L::S);
-  static constexpr int ny = (L::HO - 1 + L::P - py) / L::S - qy0 + 1, nx = (L::HO - 1 + L::P - px) / L::S - qx0 + 1;
-  static constexpr int npc = ny * nx;                // pixels of the class per image
 };
 using Dec1 = CTLayer<32, 64, 4, 6, 0, 3, 1, 0>;
 using Dec4 = CTLayer<64, 32, 6, 13, 0>;
@@ -121,260 +113,6 @@ __global__ __launch_bounds__(256) void k_convT_fwd(const float* __restrict__ x, 
   }
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// T1m: the same gather-form transposed convolution as an implicit GEMM on the matrix cores
-// (v_mfma_f32_16x16x4_f32: exact fp32, D = A(16x4) B(4x16) + C).
-//   rows  m = output pixels of one stride-parity class (all staged images), 16 per tile
-//   cols  n = output channels, 16 per tile
-//   k       = (tap, input channel), 4 input channels per MFMA
-// Operand fetch is one ds_read_b32 per lane per MFMA: lane l supplies A[m = l & 15][k = l >> 4] =
-// image[ci0 + (l >> 4)][qy - ty][qx - tx] (zero-padded image: no branches) and B[k = l >> 4][n = l & 15] =
-// w_class[tap][ci0 + (l >> 4)][n]; a B fragment is reused by the TG pixel tiles a wave keeps in flight.
-// Against the register-blocked VALU kernel this cuts LDS operand traffic per MAC by ~4.5x, which is
-// what that kernel is bound by.  Result layout (lane: col n = l & 15, rows 4 (l >> 4) + r).
-// ---------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
-// taps of the classes before cls ([cls][tap][ci][co] slab order)
-template <class L> constexpr int class_tap_offset(int cls) {
-  int off = 0;
-  for (int c = 0; c < cls; ++c) off += ((L::K - c / L::S + L::S - 1) / L::S) * ((L::K - c % L::S + L::S - 1) / L::S);
-  return off;
-}
-
-// phase timing for tools/convt_probe.hip (compiled out of the library)
-#ifdef CONVT_PROBE
-__device__ unsigned long long g_probe[8];
-#define PROBE_T(v) const long long v = clock64()
-#define PROBE_ADD(i, v) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[i] += (unsigned long long)(clock64() - (v)); } while (0)
-#else
-#define PROBE_T(v)
-#define PROBE_ADD(i, v)
-#endif
-
-// All k-steps (tap x 4*KB input channels) of NG pixel tiles x NCO channel tiles of one wavefront.  The operands of
-// step s+1 are fetched into a second register set while the MFMAs of step s issue (LDS returns in order, so the
-// wait before the MFMAs only covers the older set); consecutive MFMAs go to different accumulators.
-template <int NG, int TG, int NCO, int CI, int CO, int PS, int HP, int ntaps, int ntx>
-__device__ __forceinline__ void convT_tile_mma(const float* __restrict__ s_img, const float* __restrict__ sw, const int (&abase)[TG],
-                                               int lk, int lr, f32x4 (&acc)[TG][NCO]) {
-  constexpr int KB = (CI / 4) < 8 ? (CI / 4) : 8;   // MFMA k-steps per fetch batch
-  constexpr int NB = CI / (4 * KB);                 // batches per tap
-  constexpr int nsteps = ntaps * NB;
-  float bfA[KB][NCO], afA[KB][NG], bfB[KB][NCO], afB[KB][NG];
-  auto fetch = [&](int s, float (&bf)[KB][NCO], float (&af)[KB][NG]) {
-    const int t = s / NB, cb = (s % NB) * 4 * KB;
-    const int toff = -(t / ntx) * HP - t % ntx;                               // iy = qy - ty, ix = qx - tx
-    const float* wp = sw + ((size_t)t * CI + cb + lk) * CO + lr;
-    const int ao = toff + cb * PS;
-#pragma unroll
-    for (int kk = 0; kk < KB; ++kk) {
-#pragma unroll
-      for (int c = 0; c < NCO; ++c) bf[kk][c] = wp[4 * kk * CO + c * 16];
-#pragma unroll
-      for (int g = 0; g < NG; ++g) af[kk][g] = s_img[abase[g] + ao + 4 * kk * PS];
-    }
-  };
-  auto mma = [&](const float (&bf)[KB][NCO], const float (&af)[KB][NG]) {
-#pragma unroll
-    for (int kk = 0; kk < KB; ++kk)
-#pragma unroll
-      for (int g = 0; g < NG; ++g)
-#pragma unroll
-        for (int c = 0; c < NCO; ++c)               // C^T: rows = channels, cols = pixels
-          acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[kk][c], af[kk][g], acc[g][c], 0, 0, 0);
-  };
-  fetch(0, bfA, afA);
-  int s = 0;
-  while (true) {
-    if (s + 1 < nsteps) fetch(s + 1, bfB, afB);
-    mma(bfA, afA);
-    if (++s >= nsteps) break;
-    if (s + 1 < nsteps) fetch(s + 1, bfA, afA);
-    mma(bfB, afB);
-    if (++s >= nsteps) break;
-  }
-}
-
-// Persistent form: grid = one workgroup (NTHR = 512: two wavefronts per SIMD, so one wavefront's LDS operand
-// waits hide under the other's MFMAs) per CU; a workgroup walks image groups (IPB images) with stride gridDim.x.
-//   * the weights of ALL stride-parity classes for COS output channels stay resident in LDS, staged once per
-//     pass ([cls][tap][ci][COS], compact); CO / COS passes over the image groups (the groups are then re-read
-//     from L2/MALL);
-//   * the next group's input (contiguous IPB*CI*HI*HI floats) is fetched as float4 into registers right after
-//     the current group was scattered to LDS, so the global latency hides under the current group's MFMAs;
-//   * the (class, pixel tile) jobs of a group are split over the wavefronts by cost (taps), SIMD-wise contiguous.
-template <class L, int IPB, int TG, int COS, int NTHR>
-__global__ __launch_bounds__(NTHR) void k_convT_fwd_mfma(const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, float* __restrict__ y, int B) {
-  constexpr int CI = L::CI, CO = L::CO, HI = L::HI, HO = L::HO, HP = L::HP, K = L::K, S = L::S, P = L::P, PL = L::PL;
-  static_assert(COS % 16 == 0 && CO % COS == 0 && CI % 4 == 0 && NTHR % 256 == 0, "MFMA tiling");
-  constexpr int NW = NTHR / 64;
-  constexpr int NCO = COS / 16;
-  constexpr int PS = L::PS;
-  constexpr int IMG = CI * PS;
-  constexpr int NCLS = S * S;
-  constexpr int SRC = CI * HI * HI;                  // floats per source image
-  static_assert(SRC % 4 == 0, "float4 source fetch");
-  constexpr int NLD = (IPB * SRC / 4 + NTHR - 1) / NTHR;   // float4 fetches per thread per group
-  constexpr int NWE = CI * COS * K * K;              // weights per pass
-  float* s_img = tsm;                                // [IPB][CI][PS] zero padded planes
-  float* s_w = tsm + IPB * IMG;                      // [cls][tap][CI][COS]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 15, lk = lane >> 4;
-  const int ngroups = (B + IPB - 1) / IPB;
-  const float4* x4 = reinterpret_cast<const float4*>(x);
-  // wavefront w runs on SIMD w & 3: order the wavefronts SIMD-major so that each SIMD owns a contiguous cost range
-  const int jw = (wave & 3) * (NW / 4) + (wave >> 2);
-
-  PROBE_T(pt_all);
-  for (int e = tid; e < IPB * IMG / 4; e += NTHR) reinterpret_cast<float4*>(s_img)[e] = float4{0.f, 0.f, 0.f, 0.f};
-
-  for (int pass = 0; pass < CO / COS; ++pass) {
-    const int co0 = pass * COS;
-    __syncthreads();                                 // previous pass done with the slabs
-    PROBE_T(pt_w);
-    // weights: runs of COS*K*K contiguous floats per input channel, read in batches of 8 loads per thread
-    for (int base = 0; base < NWE; base += NTHR * 8) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = base + tid + NTHR * u;
-        const int ci = e / (COS * K * K), r = e % (COS * K * K);
-        v[u] = e < NWE ? w[((size_t)ci * CO + co0) * (K * K) + r] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = base + tid + NTHR * u;
-        if (e < NWE) {
-          const int ci = e / (COS * K * K), r = e % (COS * K * K), col = r / (K * K), ky = (r % (K * K)) / K, kx = r % K;
-          const int py = ky % S, px = kx % S;
-          int off = 0;                               // taps of the classes before (py, px)
-          for (int c = 0; c < py * S + px; ++c) off += ((K - c / S + S - 1) / S) * ((K - c % S + S - 1) / S);
-          const int tap = (ky / S) * ((K - px + S - 1) / S) + kx / S;
-          s_w[((off + tap) * CI + ci) * COS + col] = v[u];
-        }
-      }
-    }
-    PROBE_ADD(0, pt_w);
-    float bv[NCO][4];
-#pragma unroll
-    for (int c = 0; c < NCO; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[c][r] = bias ? bias[co0 + c * 16 + 4 * lk + r] : 0.f;
-
-    float4 pre[NLD];
-    auto prefetch = [&](int grp) {
-      const int b0 = grp * IPB;
-      const int nf4 = min(IPB, B - b0) * (SRC / 4);
-      const float4* src = x4 + (size_t)b0 * (SRC / 4);
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int f = tid + NTHR * i;
-        if (f < nf4) pre[i] = src[f];
-      }
-    };
-    if ((int)blockIdx.x < ngroups) prefetch(blockIdx.x);
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-      const int b0 = grp * IPB;
-      const int nimg = min(IPB, B - b0);
-      PROBE_T(pt_b1);
-      __syncthreads();                               // previous group's MFMAs have read s_img; zero fill / slabs staged
-      PROBE_ADD(1, pt_b1);
-      PROBE_T(pt_sc);
-      {
-        const int nf4 = nimg * (SRC / 4);
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-          const int f = tid + NTHR * i;
-          if (f < nf4) {
-            const float v[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int e = 4 * f + k, pl = e / (HI * HI), q = e % (HI * HI);
-              s_img[pl * PS + (q / HI + PL) * HP + q % HI + PL] = v[k];
-            }
-          }
-        }
-      }
-      __syncthreads();
-      PROBE_ADD(2, pt_sc);
-      if (grp + (int)gridDim.x < ngroups) prefetch(grp + gridDim.x);
-
-      // cost (k-steps) of all jobs of the group, and this wavefront's share [lo, hi) of it
-      int wtot = 0;
-      static_for<NCLS>([&](auto c) {
-        using G = CTClass<L, decltype(c)::value>;
-        wtot += ((nimg * G::npc + 15) / 16) * G::ntaps;
-      });
-      const int lo = (wtot * jw) / NW, hi = (wtot * (jw + 1)) / NW;
-      int cbase = 0;
-      static_for<NCLS>([&](auto c) {
-        constexpr int cls = decltype(c)::value;
-        using G = CTClass<L, cls>;
-        constexpr int py = G::py, px = G::px, ntx = G::ntx, ntaps = G::ntaps, qy0 = G::qy0, qx0 = G::qx0, nx = G::nx, npc = G::npc;
-        constexpr int woff = class_tap_offset<L>(cls);
-        const float* sw = s_w + woff * CI * COS;
-        const int mtot = nimg * npc;
-        const int ntiles = (mtot + 15) / 16;
-        // tile t of this class belongs to the wavefront whose range holds its cost midpoint
-        const int nlo = lo - cbase - ntaps / 2, nhi = hi - cbase - ntaps / 2;
-        const int tb = min(ntiles, nlo <= 0 ? 0 : (nlo + ntaps - 1) / ntaps), te = min(ntiles, nhi <= 0 ? 0 : (nhi + ntaps - 1) / ntaps);
-        cbase += ntiles * ntaps;
-        for (int t0 = tb; t0 < te; t0 += TG) {
-          const int ng = min(TG, te - t0);
-          // A-operand base address of this lane's pixel in each tile (invalid rows alias pixel 0; masked at the store)
-          int abase[TG];
-#pragma unroll
-          for (int g = 0; g < TG; ++g) {
-            int m = (t0 + g) * 16 + lr;
-            m = (g < ng && m < mtot) ? m : 0;
-            const int im = m / npc, p = m % npc;
-            abase[g] = im * IMG + lk * PS + (qy0 + p / nx + PL) * HP + (qx0 + p % nx + PL);
-          }
-          f32x4 acc[TG][NCO];
-#pragma unroll
-          for (int g = 0; g < TG; ++g)
-#pragma unroll
-            for (int c = 0; c < NCO; ++c) acc[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-          PROBE_T(pt_mm);
-          switch (ng) {                              // wave-uniform
-            case 1: convT_tile_mma<1, TG, NCO, CI, COS, PS, HP, ntaps, ntx>(s_img, sw, abase, lk, lr, acc); break;
-            case 2: if constexpr (TG >= 2) convT_tile_mma<2, TG, NCO, CI, COS, PS, HP, ntaps, ntx>(s_img, sw, abase, lk, lr, acc); break;
-            case 3: if constexpr (TG >= 3) convT_tile_mma<3, TG, NCO, CI, COS, PS, HP, ntaps, ntx>(s_img, sw, abase, lk, lr, acc); break;
-            default: if constexpr (TG >= 4) convT_tile_mma<4, TG, NCO, CI, COS, PS, HP, ntaps, ntx>(s_img, sw, abase, lk, lr, acc); break;
-          }
-          PROBE_ADD(3, pt_mm);
-          PROBE_T(pt_st);
-          // transposed product: lane holds pixel (t0+g)*16 + lr and channels c*16 + 4 lk + r -> for a fixed r the 16 lanes
-          // of a group write 16 neighbouring pixels of one channel plane
-#pragma unroll
-          for (int g = 0; g < TG; ++g) {
-            const int m = (t0 + g) * 16 + lr;
-            if (g < ng && m < mtot) {
-              const int im = m / npc, p = m % npc;
-              const int oy = S * (qy0 + p / nx) + py - P, ox = S * (qx0 + p % nx) + px - P;
-              float* yp = y + (((size_t)(b0 + im) * CO + co0) * HO + oy) * HO + ox;
-#pragma unroll
-              for (int c = 0; c < NCO; ++c)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) yp[(size_t)(c * 16 + 4 * lk + r) * HO * HO] = acc[g][c][r] + bv[c][r];
-            }
-          }
-          PROBE_ADD(4, pt_st);
-        }
-      });
-    }
-  }
-  PROBE_ADD(5, pt_all);
-}
 
 // ---------------------------------------------------------------------------------------------
 // T2: gx[b,ci,iy,ix] = sum_{co,ky,kx} gy[b,co,2 iy - 1 + ky, 2 ix - 1 + kx] w[ci,co,ky,kx]
@@ -642,6 +380,19 @@ static bool use_mfma() {
   return v == 1;
 }
 
+// matrix-core path (conv_mfma.hpp): persistent grid of one 512-thread workgroup per CU
+template <class PL, int IPB, int TG, int NCJ>
+static int launch_igemm(const float* x, const float* w, const float* bias, float* y, int B, hipStream_t st, const char* what) {
+  constexpr int NTHR = 512;
+  constexpr size_t lds = igemm_lds_bytes<PL, IPB>();
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto km = k_conv_igemm<PL, IPB, TG, NCJ, NTHR>;
+  if (set_max_lds((const void*)km, lds)) return 1;
+  const int ngroups = (B + IPB - 1) / IPB;
+  hipLaunchKernelGGL(km, ngroups < 256 ? ngroups : 256, NTHR, lds, st, x, w, bias, y, B);
+  return check_launch(what);
+}
+
 // IPB: images per workgroup of the VALU kernel; IPBM / COS: images per group and output channels per pass of the MFMA kernel
 template <class L, int IPB, int IPBM, int COS>
 static int launch_T1(const float* x, const float* w, const float* bias, float* y, int B, hipStream_t st) {
@@ -649,13 +400,7 @@ static int launch_T1(const float* x, const float* w, const float* bias, float* y
   const size_t lds = sizeof(float) * ((size_t)IPB * L::CI * L::HP * L::HP + (size_t)MAXTAPS * L::CI * L::CO);
   if (use_mfma() && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     constexpr int TG = COS >= 64 ? 1 : (COS >= 32 ? 2 : 4);
-    constexpr int NTHR = 512;
-    const size_t ldsm = sizeof(float) * ((size_t)IPBM * L::CI * L::PS + (size_t)L::K * L::K * L::CI * COS);
-    auto km = k_convT_fwd_mfma<L, IPBM, TG, COS, NTHR>;
-    if (set_max_lds((const void*)km, ldsm)) return 1;
-    const int ngroups = (B + IPBM - 1) / IPBM;
-    hipLaunchKernelGGL(km, ngroups < 256 ? ngroups : 256, NTHR, ldsm, st, x, w, bias, y, B);
-    return check_launch("convT_fwd_mfma");
+    return launch_igemm<FwdPolicy<L, COS>, IPBM, TG, COS / 16>(x, w, bias, y, B, st, "convT_fwd_mfma");
   }
   auto kern = k_convT_fwd<L, IPB>;
   if (set_max_lds((const void*)kern, lds)) return 1;
@@ -663,8 +408,13 @@ static int launch_T1(const float* x, const float* w, const float* bias, float* y
   return check_launch("convT_fwd_tiled");
 }
 
-template <class L, int IPB, int COC>
+// IPBM / CIS / TG / NCJ: images per group, input channels per pass, pixel tiles and channel tiles per job of the MFMA kernel
+template <class L, int IPB, int COC, int IPBM, int CIS, int TG, int NCJ>
 static int launch_T2(const float* gy, const float* w, float* gx, int B, hipStream_t st) {
+  if constexpr (IPBM > 0) {
+    if (use_mfma() && (reinterpret_cast<uintptr_t>(gy) & 15) == 0)
+      return launch_igemm<BwdDataPolicy<L, CIS>, IPBM, TG, NCJ>(gy, w, nullptr, gx, B, st, "convT_bwd_data_mfma");
+  }
   const size_t lds = sizeof(float) * ((size_t)IPB * L::CO * L::GP_ * L::GP_ + (size_t)COC * L::K * L::K * L::CI);
   auto kern = k_convT_bwd_data<L, IPB, COC>;
   if (set_max_lds((const void*)kern, lds)) return 1;
@@ -713,10 +463,10 @@ int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx
 int tiled_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S, int P,
               int Ho, int Wo, hipStream_t st) {
   if (H != W || Ho != Wo || bias) return -1;
-  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec7, 2, 8>(x, w, y, B, st);
-  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec4, 3, 8>(x, w, y, B, st);
-  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec1, 8, 32>(x, w, y, B, st);
-  if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec10, 1, 1>(x, w, y, B, st);
+  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec7, 2, 8, 2, 32, 2, 2>(x, w, y, B, st);
+  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec4, 3, 8, 2, 32, 1, 1>(x, w, y, B, st);
+  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec1, 8, 32, 6, 32, 1, 1>(x, w, y, B, st);
+  if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec10, 1, 1, 0, 16, 1, 1>(x, w, y, B, st);
   return -1;
 }
 
