@@ -325,6 +325,194 @@ __global__ __launch_bounds__(NTHR) void k_conv_igemm(const float* __restrict__ x
   PROBE_ADD(5, pt_all);
 }
 
+// ---------------------------------------------------------------------------------------------
+// d/d weight of the transposed convolution on the matrix cores:
+//   gw[ci][co][ky][kx] = sum_b sum_{iy,ix} x[b][ci][iy][ix] * gy[b][co][S iy - P + ky][S ix - P + kx]
+// one GEMM per tap with shared A:  D_tap[ci][co] = sum_k X[ci][k] * G_tap[k][co],  k = (image, pixel), 4 pixels per MFMA.
+//   A: lane (lr, lk) supplies x[ci = 16 mt + lr][pixel 4 ks + lk]        (plane stride == 2 mod 4: conflict-free)
+//   B: lane (lr, lk) supplies gy[co = 16 nt + lr][window of pixel 4 ks + lk shifted by the tap]; for S = 2 the
+//      gy planes are stored split by column parity, so a fixed tap walks the pixels with unit stride.
+// PIPE: operands of k-step s+1 fetched into a second register set while the MFMAs of step s issue.
+// The 8 wavefronts of a workgroup split the accumulator tiles (WM x WN x WT over ci tiles, co tiles and taps);
+// every wavefront walks all k of the workgroup's images.  Persistent grid; the partial sums of a workgroup go to
+// part[blockIdx.x][ci][co][tap] and are reduced in a fixed order by k_sum_splits4 (deterministic).
+// ---------------------------------------------------------------------------------------------
+constexpr int pad2mod4(int n) { return n + ((2 - n % 4) + 4) % 4; }
+
+template <class L> struct WgradGeo {
+  static constexpr int NPIX = L::HI * L::HI, NKS = (NPIX + 3) / 4;
+  static constexpr int PSX = pad2mod4(NKS * 4);                         // x plane stride (zero tail up to 4 NKS)
+  static constexpr int GP = L::GP_;                                     // gy rows / cols, index = oy + P
+  static constexpr int GPH = L::S == 2 ? (GP + 1) / 2 : GP;             // columns per (half) plane
+  static constexpr int HPL = GP * GPH;                                  // floats per half plane
+  static constexpr int PSG = pad2mod4(L::S == 2 ? 2 * HPL : HPL);       // gy plane stride
+  static constexpr int IMGX = L::CI * PSX, IMGG = L::CO * PSG;
+  static_assert(L::S == 1 || L::S == 2, "stride");
+};
+
+template <class L, int IPB, int WM, int WN, int WT, bool PIPE, int NTHR>
+__global__ __launch_bounds__(NTHR) void k_convT_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ gy,
+                                                            float* __restrict__ part, int B) {
+  using G = WgradGeo<L>;
+  constexpr int CI = L::CI, CO = L::CO, HI = L::HI, HO = L::HO, K = L::K, S = L::S, P = L::P, KK = K * K;
+  constexpr int MT = CI / 16, NT = CO / 16;
+  static_assert(WM * WN * WT * 64 == NTHR && MT % WM == 0 && NT % WN == 0, "wavefront split");
+  constexpr int MTW = MT / WM, NTW = NT / WN, NTAPW = (KK + WT - 1) / WT;
+  constexpr int NPIX = G::NPIX, NKS = G::NKS, PSX = G::PSX, PSG = G::PSG, GPH = G::GPH, HPL = G::HPL, IMGX = G::IMGX, IMGG = G::IMGG;
+  constexpr int SRCX = CI * NPIX, SRCG = CO * HO * HO;
+  static_assert(SRCX % 4 == 0 && SRCG % 4 == 0 && (IPB * IMGX) % 4 == 0 && (IPB * IMGG) % 4 == 0, "float4 access");
+  constexpr int NLX = (IPB * SRCX / 4 + NTHR - 1) / NTHR, NLG = (IPB * SRCG / 4 + NTHR - 1) / NTHR;
+  float* s_x = igemm_smem;                           // [IPB][CI][PSX]
+  float* s_g = igemm_smem + IPB * IMGX;              // [IPB][CO][PSG]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  const int wm = wave % WM, wn = (wave / WM) % WN, wt = wave / (WM * WN);
+  const int ngroups = (B + IPB - 1) / IPB;
+
+  for (int e = tid; e < IPB * (IMGX + IMGG) / 4; e += NTHR) reinterpret_cast<float4*>(igemm_smem)[e] = float4{0.f, 0.f, 0.f, 0.f};
+
+  // LDS offsets of this wavefront's taps (wave-uniform)
+  int toff[NTAPW];
+#pragma unroll
+  for (int j = 0; j < NTAPW; ++j) {
+    const int t = min(wt + WT * j, KK - 1), ky = t / K, kx = t % K;
+    toff[j] = S == 2 ? (kx & 1) * HPL + ky * GPH + (kx >> 1) : ky * GPH + kx;
+  }
+  f32x4 acc[MTW][NTW][NTAPW];
+#pragma unroll
+  for (int a = 0; a < MTW; ++a)
+#pragma unroll
+    for (int b = 0; b < NTW; ++b)
+#pragma unroll
+      for (int j = 0; j < NTAPW; ++j) acc[a][b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 prex[NLX], preg[NLG];
+  auto prefetch = [&](int grp) {
+    const int b0 = grp * IPB, nimg = min(IPB, B - b0);
+    const float4* sx = reinterpret_cast<const float4*>(x) + (size_t)b0 * (SRCX / 4);
+    const float4* sg = reinterpret_cast<const float4*>(gy) + (size_t)b0 * (SRCG / 4);
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+      const int f = tid + NTHR * i;
+      if (f < nimg * (SRCX / 4)) prex[i] = sx[f];
+    }
+#pragma unroll
+    for (int i = 0; i < NLG; ++i) {
+      const int f = tid + NTHR * i;
+      if (f < nimg * (SRCG / 4)) preg[i] = sg[f];
+    }
+  };
+  if ((int)blockIdx.x < ngroups) prefetch(blockIdx.x);
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int nimg = min(IPB, B - grp * IPB);
+    __syncthreads();                                 // previous group's MFMAs have read the planes; zero fill done
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+      const int f = tid + NTHR * i;
+      if (f < nimg * (SRCX / 4)) {
+        const float v[4] = {prex[i].x, prex[i].y, prex[i].z, prex[i].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = 4 * f + k;
+          s_x[(e / NPIX) * PSX + e % NPIX] = v[k];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NLG; ++i) {
+      const int f = tid + NTHR * i;
+      if (f < nimg * (SRCG / 4)) {
+        const float v[4] = {preg[i].x, preg[i].y, preg[i].z, preg[i].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = 4 * f + k, pl = e / (HO * HO), q = e % (HO * HO), row = q / HO + P, col = q % HO + P;
+          s_g[pl * PSG + (S == 2 ? (col & 1) * HPL + row * GPH + (col >> 1) : row * GPH + col)] = v[k];
+        }
+      }
+    }
+    __syncthreads();
+    if (grp + (int)gridDim.x < ngroups) prefetch(grp + gridDim.x);
+
+    // k loop over (image, 4-pixel step), operands of step s+1 in flight while the MFMAs of step s issue
+    const int nsteps = nimg * NKS;
+    float afA[MTW], bfA[NTAPW][NTW], afB[MTW], bfB[NTAPW][NTW];
+    auto fetch = [&](int s, float (&af)[MTW], float (&bf)[NTAPW][NTW]) {
+      const int im = s / NKS, ks = s % NKS;
+      const int p = 4 * ks + lk, pc = min(p, NPIX - 1), iy = pc / HI, ix = pc % HI;   // tail pixels: x is zero there
+      const float* xp = s_x + im * IMGX + (wm * MTW * 16 + lr) * PSX + p;
+      const float* gp = s_g + im * IMGG + (wn * NTW * 16 + lr) * PSG + (S == 2 ? S * iy * GPH + ix : iy * GPH + ix);
+#pragma unroll
+      for (int a = 0; a < MTW; ++a) af[a] = xp[a * 16 * PSX];
+#pragma unroll
+      for (int j = 0; j < NTAPW; ++j)
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) bf[j][b] = gp[b * 16 * PSG + toff[j]];
+    };
+    auto mma = [&](const float (&af)[MTW], const float (&bf)[NTAPW][NTW]) {
+#pragma unroll
+      for (int j = 0; j < NTAPW; ++j)
+        if (WT == 1 || wt + WT * j < KK) {           // wave-uniform
+#pragma unroll
+          for (int a = 0; a < MTW; ++a)
+#pragma unroll
+            for (int b = 0; b < NTW; ++b) acc[a][b][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bf[j][b], acc[a][b][j], 0, 0, 0);
+        }
+    };
+    if constexpr (PIPE) {
+      fetch(0, afA, bfA);
+      int s = 0;
+      while (true) {
+        if (s + 1 < nsteps) fetch(s + 1, afB, bfB);
+        mma(afA, bfA);
+        if (++s >= nsteps) break;
+        if (s + 1 < nsteps) fetch(s + 1, afA, bfA);
+        mma(afB, bfB);
+        if (++s >= nsteps) break;
+      }
+    } else {                                         // register-bound splits: the other wavefront of the SIMD covers the fetch
+#pragma unroll 1
+      for (int s = 0; s < nsteps; ++s) {
+        fetch(s, afA, bfA);
+        mma(afA, bfA);
+      }
+    }
+  }
+  // D[m = ci][n = co]: lane holds co = lr, ci = 4 lk + r of each tile
+  float* pp = part + (size_t)blockIdx.x * CI * CO * KK;
+#pragma unroll
+  for (int j = 0; j < NTAPW; ++j) {
+    const int t = wt + WT * j;
+    if (t < KK) {
+#pragma unroll
+      for (int a = 0; a < MTW; ++a)
+#pragma unroll
+        for (int b = 0; b < NTW; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ci = (wm * MTW + a) * 16 + 4 * lk + r, co = (wn * NTW + b) * 16 + lr;
+            pp[((size_t)ci * CO + co) * KK + t] = acc[a][b][j][r];
+          }
+    }
+  }
+}
+
+template <class L, int IPB> constexpr size_t wgrad_lds_bytes() {
+  return sizeof(float) * (size_t)IPB * (WgradGeo<L>::IMGX + WgradGeo<L>::IMGG);
+}
+
+// out[e] = sum_s part[s][e] in a fixed order: 4 interleaved partial sums per element, combined through LDS
+__global__ __launch_bounds__(256) void k_sum_splits4(const float* __restrict__ part, int nsplit, size_t n, float* __restrict__ out) {
+  __shared__ float red[256];
+  const int ex = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const size_t e = (size_t)blockIdx.x * 64 + ex;
+  float acc = 0.f;
+  if (e < n)
+    for (int s = sg; s < nsplit; s += 4) acc += part[(size_t)s * n + e];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (sg == 0 && e < n) out[e] = (red[ex] + red[64 + ex]) + (red[128 + ex] + red[192 + ex]);
+}
+
 template <class PL, int IPB> constexpr size_t igemm_lds_bytes() {
   return sizeof(float) * ((size_t)IPB * PL::KC * PL::PS + (size_t)PL::WSLAB);
 }

@@ -422,8 +422,21 @@ static int launch_T2(const float* gy, const float* w, float* gx, int B, hipStrea
   return check_launch("convT_bwd_data_tiled");
 }
 
-template <class L, int COW>
+// IPBM / WM x WN x WT: images per group and wavefront split (ci tiles, co tiles, taps) of the MFMA kernel
+template <class L, int COW, int IPBM, int WM, int WN, int WT, bool PIPE>
 static int launch_T3(const float* x, const float* gy, float* gw, float* scratch, int B, hipStream_t st) {
+  if (use_mfma() && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0) {
+    constexpr size_t ldsm = wgrad_lds_bytes<L, IPBM>();
+    static_assert(ldsm <= 160 * 1024, "LDS budget");
+    auto km = k_convT_wgrad_mfma<L, IPBM, WM, WN, WT, PIPE, 512>;
+    if (set_max_lds((const void*)km, ldsm)) return 1;
+    const int ngroups = (B + IPBM - 1) / IPBM;
+    const int nwg = ngroups < 256 ? ngroups : 256;
+    hipLaunchKernelGGL(km, nwg, 512, ldsm, st, x, gy, scratch, B);
+    const size_t n = (size_t)L::CI * L::CO * L::K * L::K;
+    hipLaunchKernelGGL(k_sum_splits4, (unsigned)((n + 63) / 64), 256, 0, st, scratch, nwg, n, gw);
+    return check_launch("convT_wgrad_mfma");
+  }
   constexpr int NT = L::CI * (COW / 4), PSPLIT = 256 / NT, KK = L::K * L::K;
   size_t fl = (size_t)L::HI * L::HI * L::CI + (size_t)L::GP_ * L::GP_ * COW;
   const size_t red = PSPLIT > 1 ? (size_t)PSPLIT * NT * KK * 4 : 0;
@@ -474,9 +487,9 @@ int tiled_fwd(const float* x, const float* w, const float* bias, float* y, int B
 int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch, int B, int Ci, int H, int W, int Co, int K, int S,
                      int P, int Ho, int Wo, hipStream_t st) {
   if (H != W || Ho != Wo) return -1;
-  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec7, 16>(gy, x, gw, scratch, B, st);
-  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec4, 16>(gy, x, gw, scratch, B, st);
-  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec1, 32>(gy, x, gw, scratch, B, st);
+  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec7, 16, 1, 1, 1, 8, true>(gy, x, gw, scratch, B, st);
+  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec4, 16, 2, 4, 2, 1, false>(gy, x, gw, scratch, B, st);
+  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec1, 32, 8, 2, 4, 1, true>(gy, x, gw, scratch, B, st);
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) {
     int nsplit = B < 256 ? B : 256;
     const int bps = (B + nsplit - 1) / nsplit;
