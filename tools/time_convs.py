@@ -22,9 +22,5 @@ for name, xs, ws, (s, p, op), macs in layers:
         x.grad = w.grad = b.grad = None
         y.backward(gy, retain_graph=True)
     tb = timeit(bw)
-    def bwd_data_only():
-        torch.autograd.grad(y, x, gy, retain_graph=True)
-    td = timeit(bwd_data_only)
     fl = 2 * macs * B
-    print('%s fwd %7.3f ms (%5.1f TF)   bwd-data %7.3f ms (%5.1f TF)   bwd-weight(+bias) %7.3f ms (%5.1f TF)' % (
-        name, tf, fl / tf / 1e9, td, fl / td / 1e9, tb - td, fl / (tb - td) / 1e9))
+    print('%s fwd %7.3f ms (%5.1f TF)   bwd(data+weight) %7.3f ms (%5.1f TF)' % (name, tf, fl / tf / 1e9, tb, 2 * fl / tb / 1e9))

@@ -1,0 +1,264 @@
+// conv_dec10_mfma.hpp -- the decoder's last layer, ConvTranspose2d(16 -> 1, K = 5, stride 1, padding 2) on 28 x 28 images
+// (reference: experiments/model/core/vae.py:80-84, decnn.10), on the fp32 matrix cores.  With one output channel the
+// channel dimension cannot fill an MFMA tile, so the 25 taps take that role:
+//
+//   forward   T[tap][p'] = sum_ci w[ci][tap] x[ci][p']           (MFMA: m = tap, n = source pixel, k = ci)
+//             y[oy][ox]  = b + sum_tap T[tap][oy + 2 - ky][ox + 2 - kx]   (shift-and-add through LDS)
+//   d/d x     gx[ci][p]  = sum_tap w[ci][tap] gy[window(p, tap)]  (MFMA: m = ci, n = pixel, k = tap, 25 -> 28)
+//   d/d w     gw[ci][tap] = sum_{b,p} x[b][ci][p] gy[b][window(p, tap)]   (MFMA: m = ci, n = tap, k = pixel)
+//
+// x is read from global memory straight into MFMA operands (every element is used by exactly one k-slot);
+// only the single-channel gy / T planes go through LDS, stored as zero-bordered 32 x 32 planes (index = o + 2).
+// Persistent grids (<= one 512-thread workgroup per CU, two wavefronts per SIMD).
+#pragma once
+#include "conv_mfma.hpp"
+
+namespace gp {
+namespace dec10 {
+
+constexpr int CI = 16, H = 28, NP = H * H, KK = 25, WP = 32, PLANE = WP * WP;
+constexpr int NTILE = NP / 16;                       // 49 tiles of 16 pixels
+constexpr int PST = PLANE + 4;                       // T plane stride: 4 planes apart == 16 banks apart
+
+// ---------------------------------------------------------------------------------------------
+// forward.  grid <= 256, block 512, LDS = 25 * PST floats.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                             const float* __restrict__ bias, float* __restrict__ y, int B) {
+  float* s_T = igemm_smem;                           // [25][PST], zero borders
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  constexpr int MAXT = (NTILE + 7) / 8;              // tiles per wavefront: t = wave + 8 j
+  for (int e = tid; e < KK * PST; e += 512) s_T[e] = 0.f;
+  // A = w[ci = 4 ks + lk][tap = 16 c + lr]
+  float wa[4][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int tap = 16 * c + lr;
+      wa[ks][c] = tap < KK ? w[(size_t)(4 * ks + lk) * KK + tap] : 0.f;
+    }
+  const float bv = bias ? bias[0] : 0.f;
+  // B = x[b][ci = 4 ks + lk][16 t + lr], fetched one image ahead
+  float xb[MAXT][4];
+  auto prefetch = [&](int b) {
+    const float* xp = x + (size_t)b * CI * NP + lr;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const int t = wave + 8 * j;
+      if (t < NTILE) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xb[j][ks] = xp[(size_t)(4 * ks + lk) * NP + 16 * t];
+      }
+    }
+  };
+  if ((int)blockIdx.x < B) prefetch(blockIdx.x);
+  __syncthreads();
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const int t = wave + 8 * j;
+      if (t < NTILE) {                               // wave-uniform
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks][c], xb[j][ks], acc[c], 0, 0, 0);
+        // lane: source pixel 16 t + lr, taps 16 c + 4 lk + r
+        const int p = 16 * t + lr, pa = (p / H + 2) * WP + p % H + 2;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int tap = 16 * c + 4 * lk + r;
+            if (tap < KK) s_T[tap * PST + pa] = acc[c][r];
+          }
+      }
+    }
+    if (b + (int)gridDim.x < B) prefetch(b + gridDim.x);
+    __syncthreads();
+    for (int o = tid; o < NP; o += 512) {
+      const int oy = o / H, ox = o % H;
+      const float* tp = s_T + (oy + 4) * WP + ox + 4;                // stored row oy + 4 - ky, col ox + 4 - kx
+      float s0 = bv, s1 = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+          const float v = tp[(ky * 5 + kx) * PST - ky * WP - kx];
+          if ((ky * 5 + kx) & 1) s1 += v; else s0 += v;
+        }
+      y[(size_t)b * NP + o] = s0 + s1;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// d/d input.  grid <= 256, block 512, LDS = IPB planes.
+// ---------------------------------------------------------------------------------------------
+template <int IPB>
+__global__ __launch_bounds__(512) void k_bwd_data(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx, int B) {
+  float* s_g = igemm_smem;                           // [IPB][32][32], index = o + 2, zero borders
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  constexpr int NKS = (KK + 3) / 4;                  // 7 k-steps of 4 taps
+  constexpr int NLD = (IPB * NP / 4 + 511) / 512;
+  for (int e = tid; e < IPB * PLANE; e += 512) s_g[e] = 0.f;
+  // A = w[ci = lr][tap = 4 ks + lk]; B gathers the window element of the lane's tap
+  float wa[NKS];
+  int toff[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int tap = 4 * ks + lk;
+    wa[ks] = tap < KK ? w[(size_t)lr * KK + tap] : 0.f;
+    toff[ks] = tap < KK ? (tap / 5) * WP + tap % 5 : 0;
+  }
+  const int ngroups = (B + IPB - 1) / IPB;
+  float4 pre[NLD];
+  auto prefetch = [&](int grp) {
+    const int b0 = grp * IPB, nf4 = min(IPB, B - b0) * (NP / 4);
+    const float4* src = reinterpret_cast<const float4*>(gy) + (size_t)b0 * (NP / 4);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int f = tid + 512 * i;
+      if (f < nf4) pre[i] = src[f];
+    }
+  };
+  if ((int)blockIdx.x < ngroups) prefetch(blockIdx.x);
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int b0 = grp * IPB, nimg = min(IPB, B - b0);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int f = tid + 512 * i;
+      if (f < nimg * (NP / 4)) {
+        const float v[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = 4 * f + k, im = e / NP, q = e % NP;
+          s_g[im * PLANE + (q / H + 2) * WP + q % H + 2] = v[k];
+        }
+      }
+    }
+    __syncthreads();
+    if (grp + (int)gridDim.x < ngroups) prefetch(grp + gridDim.x);
+    const int ntiles = nimg * NTILE;
+    for (int t = wave; t < ntiles; t += 8) {
+      const int im = t / NTILE, p = (t % NTILE) * 16 + lr;
+      const float* gp = s_g + im * PLANE + (p / H) * WP + p % H;     // window origin (iy + ky, ix + kx)
+      float bf[NKS];
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) bf[ks] = gp[toff[ks]];
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks], bf[ks], acc, 0, 0, 0);
+      // lane: pixel p, channels 4 lk + r
+      float* op = gx + ((size_t)(b0 + im) * CI + 4 * lk) * NP + p;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) op[(size_t)r * NP] = acc[r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// d/d weight.  grid <= 256, block 512, LDS = max(IPB planes, reduction buffer); part[blockIdx.x][ci][tap].
+// ---------------------------------------------------------------------------------------------
+template <int IPB>
+__global__ __launch_bounds__(512) void k_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int B) {
+  float* s_g = igemm_smem;                           // [IPB][32][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  constexpr int NLD = (IPB * NP / 4 + 511) / 512;
+  constexpr int NJ = (IPB * NTILE + 7) / 8;          // 16-pixel groups per wavefront per image group
+  for (int e = tid; e < IPB * PLANE; e += 512) s_g[e] = 0.f;
+  // B = gy window element of tap 16 c + lr (taps >= 25 alias tap 24; their columns are dropped at the end)
+  int toff[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int tap = min(16 * c + lr, KK - 1);
+    toff[c] = (tap / 5) * WP + tap % 5;
+  }
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const int ngroups = (B + IPB - 1) / IPB;
+  float4 pre[NLD];
+  float4 xa[NJ];                                     // A = x[b][ci = lr][16 j + 4 lk + i], i = 0..3 -> MFMA i
+  auto prefetch = [&](int grp) {
+    const int b0 = grp * IPB, nimg = min(IPB, B - b0);
+    const float4* src = reinterpret_cast<const float4*>(gy) + (size_t)b0 * (NP / 4);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int f = tid + 512 * i;
+      if (f < nimg * (NP / 4)) pre[i] = src[f];
+    }
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) {
+      const int g = wave + 8 * q;                    // group index over (image, 16-pixel group)
+      if (g < nimg * NTILE) {
+        const int im = g / NTILE, j = g % NTILE;
+        xa[q] = *reinterpret_cast<const float4*>(x + ((size_t)(b0 + im) * CI + lr) * NP + 16 * j + 4 * lk);
+      }
+    }
+  };
+  if ((int)blockIdx.x < ngroups) prefetch(blockIdx.x);
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int nimg = min(IPB, B - grp * IPB);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int f = tid + 512 * i;
+      if (f < nimg * (NP / 4)) {
+        const float v[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = 4 * f + k, im = e / NP, q = e % NP;
+          s_g[im * PLANE + (q / H + 2) * WP + q % H + 2] = v[k];
+        }
+      }
+    }
+    __syncthreads();
+    float4 xc[NJ];
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) xc[q] = xa[q];
+    if (grp + (int)gridDim.x < ngroups) prefetch(grp + gridDim.x);
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) {
+      const int g = wave + 8 * q;
+      if (g < nimg * NTILE) {                        // wave-uniform
+        const int im = g / NTILE, j = g % NTILE;
+        const float av[4] = {xc[q].x, xc[q].y, xc[q].z, xc[q].w};
+        float bf[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int p = 16 * j + 4 * lk + i;
+          const float* gp = s_g + im * PLANE + (p / H) * WP + p % H;
+          bf[i][0] = gp[toff[0]];
+          bf[i][1] = gp[toff[1]];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bf[i][c], acc[c], 0, 0, 0);
+      }
+    }
+  }
+  // D[m = ci][n = tap]: lane holds tap 16 c + lr, ci = 4 lk + r; combine the 8 wavefronts in a fixed order
+  __syncthreads();
+  float* s_red = igemm_smem;                         // [8][16][32]
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_red[(wave * CI + 4 * lk + r) * 32 + 16 * c + lr] = acc[c][r];
+  __syncthreads();
+  for (int e = tid; e < CI * KK; e += 512) {
+    const int ci = e / KK, tap = e % KK;
+    float v = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 8; ++wv) v += s_red[(wv * CI + ci) * 32 + tap];
+    part[(size_t)blockIdx.x * (CI * KK) + e] = v;
+  }
+}
+
+}  // namespace dec10
+}  // namespace gp

@@ -20,6 +20,7 @@
 #include <cstdint>
 #include "gp_launch.hpp"
 #include "conv_mfma.hpp"
+#include "conv_dec10_mfma.hpp"
 
 namespace gp {
 
@@ -462,6 +463,12 @@ int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx
   if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec4, 3, 2, 16>(gy, w, bias, gx, B, st);
   if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec1, 8, 8, 64>(gy, w, bias, gx, B, st);
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) {
+    if (use_mfma()) {
+      const size_t ldsm = sizeof(float) * dec10::KK * dec10::PST;
+      if (set_max_lds((const void*)dec10::k_fwd, ldsm)) return 1;
+      hipLaunchKernelGGL(dec10::k_fwd, B < 256 ? B : 256, 512, ldsm, st, gy, w, bias, gx, B);
+      return check_launch("dec10_fwd_mfma");
+    }
     constexpr int IPB = 2;
     const size_t lds = sizeof(float) * ((size_t)IPB * 16 * 32 * 32 + 16 * 5 * 8);
     auto kern = k_dec10_fwd<IPB>;
@@ -479,7 +486,16 @@ int tiled_fwd(const float* x, const float* w, const float* bias, float* y, int B
   if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec7, 2, 8, 2, 32, 2, 2>(x, w, y, B, st);
   if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec4, 3, 8, 2, 32, 1, 1>(x, w, y, B, st);
   if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec1, 8, 32, 6, 32, 1, 1>(x, w, y, B, st);
-  if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec10, 1, 1, 0, 16, 1, 1>(x, w, y, B, st);
+  if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) {
+    if (use_mfma() && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+      constexpr int IPB = 8;
+      const size_t ldsm = sizeof(float) * IPB * dec10::PLANE;
+      const int ngroups = (B + IPB - 1) / IPB;
+      hipLaunchKernelGGL(dec10::k_bwd_data<IPB>, ngroups < 256 ? ngroups : 256, 512, ldsm, st, x, w, y, B);
+      return check_launch("dec10_bwd_data_mfma");
+    }
+    return launch_T2<Dec10, 1, 1, 0, 16, 1, 1>(x, w, y, B, st);
+  }
   return -1;
 }
 
@@ -490,6 +506,16 @@ int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch,
   if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec7, 16, 1, 1, 1, 8, true>(gy, x, gw, scratch, B, st);
   if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec4, 16, 2, 4, 2, 1, false>(gy, x, gw, scratch, B, st);
   if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec1, 32, 8, 2, 4, 1, true>(gy, x, gw, scratch, B, st);
+  if (matches<Dec10>(Ci, Co, H, Ho, K, S, P) && use_mfma() &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0) {
+    constexpr int IPB = 1;
+    const size_t fl = (size_t)IPB * dec10::PLANE > 8 * 16 * 32 ? (size_t)IPB * dec10::PLANE : 8 * 16 * 32;
+    const int ngroups = (B + IPB - 1) / IPB;
+    const int nwg = ngroups < 256 ? ngroups : 256;
+    hipLaunchKernelGGL(dec10::k_wgrad<IPB>, nwg, 512, sizeof(float) * fl, st, gy, x, scratch, B);
+    hipLaunchKernelGGL(k_sum_splits4, (400 + 63) / 64, 256, 0, st, scratch, nwg, (size_t)400, gw);
+    return check_launch("dec10_wgrad_mfma");
+  }
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) {
     int nsplit = B < 256 ? B : 256;
     const int bps = (B + nsplit - 1) / nsplit;
