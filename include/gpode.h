@@ -134,7 +134,7 @@ size_t gpode_bn_scratch(int B, int C);
 int gpode_bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
                  float* running_mean, float* running_var, float momentum, float eps, int B, int C, int HW, int relu,
                  float* scratch, void* stream);
-int gpode_bn_bwd(const float* x, const float* y, const float* gy, const float* gamma, const float* save_mean,
+int gpode_bn_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
                  const float* save_invstd, float* gx, float* ggamma, float* gbeta, int B, int C, int HW, int relu,
                  float* scratch, void* stream);
 /* out[c] = sum_{b,hw} v[b,c,hw] (bias gradients); scratch: gpode_bn_scratch(B,C) floats. */

@@ -137,145 +137,6 @@ __global__ void k_sum_splits(const float* __restrict__ part, int nsplit, size_t 
   out[e] = acc;
 }
 
-// per-channel sum over (B, HW) of v (and optionally of v*u): part[split][c][2]; grid (C, nsplit)
-__global__ __launch_bounds__(256) void k_chan_sums(const float* __restrict__ v, const float* __restrict__ u, int B, int C, int HW,
-                                                    int b_per_split, float* __restrict__ part) {
-  __shared__ float red[4][2];
-  const int c = blockIdx.x;
-  const int b0 = blockIdx.y * b_per_split, b1 = min(B, b0 + b_per_split);
-  float s0 = 0.f, s1 = 0.f;
-  const size_t work = (size_t)(b1 - b0) * HW;
-  for (size_t e = threadIdx.x; e < work; e += 256) {
-    const int b = b0 + (int)(e / HW), p = (int)(e % HW);
-    const size_t idx = ((size_t)b * C + c) * HW + p;
-    const float a = v[idx];
-    s0 += a;
-    s1 = fmaf(a, u ? u[idx] : a, s1);
-  }
-  float in2[2] = {s0, s1}, out2[2];
-  wave_sum_multi<2>(in2, out2);
-  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = out2[0]; red[threadIdx.x >> 6][1] = out2[1]; }
-  __syncthreads();
-  if (threadIdx.x < 2)
-    part[((size_t)blockIdx.y * C + c) * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-}
-
-// part[split][c][0] = sum (v - mean[c])^2 over the split (second pass of the variance: no E[x^2]-E[x]^2 cancellation)
-__global__ __launch_bounds__(256) void k_chan_sqdev(const float* __restrict__ v, const float* __restrict__ mean, int B, int C, int HW,
-                                                     int b_per_split, float* __restrict__ part) {
-  __shared__ float red[4];
-  const int c = blockIdx.x;
-  const int b0 = blockIdx.y * b_per_split, b1 = min(B, b0 + b_per_split);
-  const float m = mean[c];
-  float s0 = 0.f;
-  const size_t work = (size_t)(b1 - b0) * HW;
-  for (size_t e = threadIdx.x; e < work; e += 256) {
-    const int b = b0 + (int)(e / HW), p = (int)(e % HW);
-    const float a = v[((size_t)b * C + c) * HW + p] - m;
-    s0 = fmaf(a, a, s0);
-  }
-  float in1[1] = {s0}, out1[1];
-  wave_sum_multi<1>(in1, out1);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = out1[0];
-  __syncthreads();
-  if (threadIdx.x == 0) part[((size_t)blockIdx.y * C + c) * 2] = red[0] + red[1] + red[2] + red[3];
-}
-
-// out[c] = sum_s part[s][c][comp]
-__global__ void k_reduce_chan(const float* __restrict__ part, int nsplit, int C, int comp, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float a = 0.f;
-  for (int s = 0; s < nsplit; ++s) a += part[((size_t)s * C + c) * 2 + comp];
-  out[c] = a;
-}
-
-// BatchNorm2d, training mode (vae.py:55,58,113,116,119): batch statistics, biased variance for the
-// normalisation, unbiased for the running estimate, momentum 0.1.
-// pass 1: mean ; pass 2: biased variance -> invstd, running statistics (unbiased variance, momentum)
-__global__ void k_bn_mean(const float* __restrict__ part, int nsplit, int C, float count, float* __restrict__ save_mean) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s0 = 0.f;
-  for (int s = 0; s < nsplit; ++s) s0 += part[((size_t)s * C + c) * 2];
-  save_mean[c] = s0 / count;
-}
-__global__ void k_bn_finalize(const float* __restrict__ part, int nsplit, int C, float count, float eps, float momentum,
-                              const float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                              float* __restrict__ running_mean, float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s1 = 0.f;
-  for (int s = 0; s < nsplit; ++s) s1 += part[((size_t)s * C + c) * 2];
-  const float var = s1 / count;
-  save_invstd[c] = rsqrtf(var + eps);
-  if (running_mean) {
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * save_mean[c];
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count / (count - 1.f));
-  }
-}
-
-__global__ void k_bn_apply(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                           const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ y,
-                           size_t total, int C, int HW, int relu) {
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)((e / HW) % C);
-    float v = (x[e] - mean[c]) * invstd[c] * gamma[c] + beta[c];
-    y[e] = relu ? fmaxf(v, 0.f) : v;
-  }
-}
-
-// dy -> (masked by relu) -> g ; channel sums of g and g*xhat
-__global__ __launch_bounds__(256) void k_bn_bwd_sums(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
-                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                      int B, int C, int HW, int relu, int b_per_split, float* __restrict__ part) {
-  __shared__ float red[4][2];
-  const int c = blockIdx.x;
-  const int b0 = blockIdx.y * b_per_split, b1 = min(B, b0 + b_per_split);
-  float s0 = 0.f, s1 = 0.f;
-  const float m = mean[c], is = invstd[c];
-  const size_t work = (size_t)(b1 - b0) * HW;
-  for (size_t e = threadIdx.x; e < work; e += 256) {
-    const int b = b0 + (int)(e / HW), p = (int)(e % HW);
-    const size_t idx = ((size_t)b * C + c) * HW + p;
-    float g = gy[idx];
-    if (relu && !(y[idx] > 0.f)) g = 0.f;
-    s0 += g;
-    s1 = fmaf(g, (x[idx] - m) * is, s1);
-  }
-  float in2[2] = {s0, s1}, out2[2];
-  wave_sum_multi<2>(in2, out2);
-  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = out2[0]; red[threadIdx.x >> 6][1] = out2[1]; }
-  __syncthreads();
-  if (threadIdx.x < 2)
-    part[((size_t)blockIdx.y * C + c) * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-}
-
-// chan[c] = {sum g, sum g*xhat} over all splits; also the affine gradients
-__global__ void k_bn_bwd_finalize(const float* __restrict__ part, int nsplit, int C, float* __restrict__ chan,
-                                  float* __restrict__ ggamma, float* __restrict__ gbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float a = 0.f, b = 0.f;
-  for (int s = 0; s < nsplit; ++s) { a += part[((size_t)s * C + c) * 2]; b += part[((size_t)s * C + c) * 2 + 1]; }
-  chan[2 * c] = a; chan[2 * c + 1] = b;
-  gbeta[c] = a;
-  ggamma[c] = b;
-}
-
-__global__ void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy,
-                               const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
-                               const float* __restrict__ chan, float count, float* __restrict__ gx, size_t total, int C, int HW, int relu) {
-  const float ic = 1.f / count;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)((e / HW) % C);
-    float g = gy[e];
-    if (relu && !(y[e] > 0.f)) g = 0.f;
-    const float xh = (x[e] - mean[c]) * invstd[c];
-    gx[e] = gamma[c] * invstd[c] * (g - chan[2 * c] * ic - xh * chan[2 * c + 1] * ic);
-  }
-}
-
 // elementwise activations: mode 0 relu, 1 sigmoid
 __global__ void k_act_fwd(const float* __restrict__ x, float* __restrict__ y, size_t n, int mode) {
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
@@ -437,49 +298,8 @@ int conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, 
 #undef X
   if (!ok) return set_error("gpode_conv2d_bwd_weight: kernel %d stride %d not built", K, S);
   hipLaunchKernelGGL(k_sum_splits, (unsigned)((n + 255) / 256), 256, 0, st, scratch, used, n, gw);
-  if (gbias) {
-    float* part = scratch + (size_t)nsplit * n;
-    const int ns2 = B < 64 ? B : 64, bps2 = (B + ns2 - 1) / ns2, used2 = (B + bps2 - 1) / bps2;
-    hipLaunchKernelGGL(k_chan_sums, dim3(Co, used2), 256, 0, st, gy, (const float*)nullptr, B, Co, Ho * Wo, bps2, part);
-    hipLaunchKernelGGL(k_reduce_chan, (Co + 63) / 64, 64, 0, st, part, used2, Co, 0, gbias);
-  }
+  if (gbias) return chan_sum(gy, gbias, B, Co, Ho * Wo, scratch + (size_t)nsplit * n, st);
   return check_launch("conv_bwd_weight");
-}
-
-size_t bn_scratch(int B, int C) { return (size_t)(B < 64 ? B : 64) * C * 2 + (size_t)C * 2; }
-
-int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
-           float* running_mean, float* running_var, float momentum, float eps, int B, int C, int HW, int relu,
-           float* scratch, hipStream_t st) {
-  const int ns = B < 64 ? B : 64, bps = (B + ns - 1) / ns, used = (B + bps - 1) / bps;
-  hipLaunchKernelGGL(k_chan_sums, dim3(C, used), 256, 0, st, x, (const float*)nullptr, B, C, HW, bps, scratch);
-  hipLaunchKernelGGL(k_bn_mean, (C + 63) / 64, 64, 0, st, scratch, used, C, (float)B * HW, save_mean);
-  hipLaunchKernelGGL(k_chan_sqdev, dim3(C, used), 256, 0, st, x, save_mean, B, C, HW, bps, scratch);
-  hipLaunchKernelGGL(k_bn_finalize, (C + 63) / 64, 64, 0, st, scratch, used, C, (float)B * HW, eps, momentum, save_mean, save_invstd,
-                     running_mean, running_var);
-  const size_t total = (size_t)B * C * HW;
-  hipLaunchKernelGGL(k_bn_apply, ew_grid(total), 256, 0, st, x, gamma, beta, save_mean, save_invstd, y, total, C, HW, relu);
-  return check_launch("bn_fwd");
-}
-
-int bn_bwd(const float* x, const float* y, const float* gy, const float* gamma, const float* save_mean, const float* save_invstd,
-           float* gx, float* ggamma, float* gbeta, int B, int C, int HW, int relu, float* scratch, hipStream_t st) {
-  const int ns = B < 64 ? B : 64, bps = (B + ns - 1) / ns, used = (B + bps - 1) / bps;
-  hipLaunchKernelGGL(k_bn_bwd_sums, dim3(C, used), 256, 0, st, x, y, gy, save_mean, save_invstd, B, C, HW, relu, bps, scratch);
-  const size_t total = (size_t)B * C * HW;
-  float* chan = scratch + (size_t)ns * C * 2;
-  hipLaunchKernelGGL(k_bn_bwd_finalize, (C + 63) / 64, 64, 0, st, scratch, used, C, chan, ggamma, gbeta);
-  hipLaunchKernelGGL(k_bn_bwd_apply, ew_grid(total), 256, 0, st, x, y, gy, gamma, save_mean, save_invstd, chan, (float)B * HW, gx,
-                     total, C, HW, relu);
-  return check_launch("bn_bwd");
-}
-
-// out[c] = sum over (b, hw) of v[b,c,hw]   (bias gradient of ConvTranspose2d / Conv2d)
-int chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, hipStream_t st) {
-  const int ns = B < 64 ? B : 64, bps = (B + ns - 1) / ns, used = (B + bps - 1) / bps;
-  hipLaunchKernelGGL(k_chan_sums, dim3(C, used), 256, 0, st, v, (const float*)nullptr, B, C, HW, bps, scratch);
-  hipLaunchKernelGGL(k_reduce_chan, (C + 63) / 64, 64, 0, st, scratch, used, C, 0, out);
-  return check_launch("chan_sum");
 }
 
 int act_fwd(const float* x, float* y, size_t n, int mode, hipStream_t st) {

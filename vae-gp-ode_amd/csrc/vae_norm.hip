@@ -1,0 +1,264 @@
+// vae_norm.hip -- BatchNorm2d (training mode) and per-channel sums for the VAE encoder / decoder
+// (reference: experiments/model/core/vae.py:52-60 and 64-84, nn.BatchNorm2d after every hidden conv layer).
+//
+// All kernels are HBM-bound passes over an activation tensor (B, C, HW).  Layout of the work: grid (C, nsplit);
+// a workgroup owns channel c and a contiguous slab of images, so the channel's scalars are workgroup constants and
+// the loop body has no integer division (float4 accesses when HW % 4 == 0).  Pass counts:
+//   forward   statistics (1 read)  + normalise / affine / ReLU (1 read, 1 write)
+//   backward  channel sums (2 reads: x, gy) + apply (2 reads, 1 write); the ReLU mask is recomputed from x with the
+//             same pinned arithmetic as the forward pass, so the forward output y is not read again.
+// Variance: sums of (x - k) and (x - k)^2 with a per-channel shift k (mean of the first <= 64 elements of the
+// channel), so the E[x^2] - E[x]^2 cancellation is relative to (mean - k)^2 / var = O(1), not mean^2 / var.
+// Reductions use fixed slabs and a fixed combine order: results are bitwise reproducible.
+#include <hip/hip_runtime.h>
+#include "gp_launch.hpp"
+#include "wave_reduce.hpp"
+
+namespace gp {
+
+namespace {
+
+// normalised value and affine output with pinned rounding (forward and backward must agree on the ReLU mask)
+__device__ __forceinline__ float bn_xhat(float x, float m, float is) { return __fmul_rn(__fsub_rn(x, m), is); }
+__device__ __forceinline__ float bn_affine(float x, float m, float is, float g, float b) { return __fmaf_rn(bn_xhat(x, m, is), g, b); }
+
+// visit channel c of images [b0, b0 + nb): f4(offset of 4 consecutive floats) when HW % 4 == 0, else f1(offset)
+template <class F4, class F1>
+__device__ __forceinline__ void chan_slab(int C, int HW, int c, int b0, int nb, F4&& f4, F1&& f1) {
+  if ((HW & 3) == 0) {
+    const int hw4 = HW >> 2, work = nb * hw4;
+    int q = threadIdx.x, b = q / hw4, p = q - b * hw4;
+    const int sb = 256 / hw4, sp = 256 - sb * hw4;
+#pragma unroll 4
+    for (; q < work; q += 256) {
+      f4(((size_t)(b0 + b) * C + c) * HW + 4 * p);
+      p += sp; b += sb;
+      if (p >= hw4) { p -= hw4; ++b; }
+    }
+  } else {
+    const int work = nb * HW;
+    int q = threadIdx.x, b = q / HW, p = q - b * HW;
+    const int sb = 256 / HW, sp = 256 - sb * HW;
+#pragma unroll 4
+    for (; q < work; q += 256) {
+      f1(((size_t)(b0 + b) * C + c) * HW + p);
+      p += sp; b += sb;
+      if (p >= HW) { p -= HW; ++b; }
+    }
+  }
+}
+
+// workgroup sum of NV per-thread values -> part[0..NV) (written by thread 0..NV-1); 256 threads
+template <int NV> __device__ __forceinline__ void block_sum_store(const float (&v)[NV], float* __restrict__ dst) {
+  __shared__ float red[4][NV];
+  float out[NV];
+  wave_sum_multi<NV>(v, out);
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[threadIdx.x >> 6][i] = out[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) dst[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// shift k(c): mean of the first min(HW, 64) elements of image 0 (every wavefront of every workgroup computes the same value)
+__device__ __forceinline__ float chan_shift(const float* __restrict__ x, int HW, int c) {
+  const int n = HW < 64 ? HW : 64, lane = threadIdx.x & 63;
+  const float in1[1] = {lane < n ? x[(size_t)c * HW + lane] : 0.f};
+  float out1[1];
+  wave_sum_multi<1>(in1, out1);
+  return out1[0] / (float)n;
+}
+
+// part[split][c] = {sum (x - k), sum (x - k)^2}; shift[c] = k
+__global__ __launch_bounds__(256) void k_bn_stats(const float* __restrict__ x, int B, int C, int HW, int bps, float* __restrict__ part,
+                                                   float* __restrict__ shift) {
+  const int c = blockIdx.x, b0 = blockIdx.y * bps, nb = min(B, b0 + bps) - b0;
+  const float k = chan_shift(x, HW, c);
+  float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;      // two interleaved accumulator pairs
+  chan_slab(C, HW, c, b0, nb,
+            [&](size_t i) {
+              const float4 v = *reinterpret_cast<const float4*>(x + i);
+              const float a = v.x - k, b = v.y - k, d = v.z - k, e = v.w - k;
+              s0 += a; t0 += b; s0 += d; t0 += e;
+              s1 = fmaf(a, a, s1); t1 = fmaf(b, b, t1); s1 = fmaf(d, d, s1); t1 = fmaf(e, e, t1);
+            },
+            [&](size_t i) {
+              const float a = x[i] - k;
+              s0 += a;
+              s1 = fmaf(a, a, s1);
+            });
+  const float in2[2] = {s0 + t0, s1 + t1};
+  block_sum_store<2>(in2, part + ((size_t)blockIdx.y * C + c) * 2);
+  if (blockIdx.y == 0 && threadIdx.x == 0) shift[c] = k;
+}
+
+// batch statistics (biased variance for the normalisation, unbiased for the running estimate, momentum as nn.BatchNorm2d)
+__global__ void k_bn_finalize(const float* __restrict__ part, const float* __restrict__ shift, int nsplit, int C, float count, float eps,
+                              float momentum, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                              float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int s = 0; s < nsplit; ++s) { s0 += part[((size_t)s * C + c) * 2]; s1 += part[((size_t)s * C + c) * 2 + 1]; }
+  const float d = s0 / count;                        // mean - k
+  const float mean = shift[c] + d;
+  const float var = fmaxf(s1 / count - d * d, 0.f);
+  save_mean[c] = mean;
+  save_invstd[c] = rsqrtf(var + eps);
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count / (count - 1.f));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ y,
+                                                   int B, int C, int HW, int bps, int relu) {
+  const int c = blockIdx.x, b0 = blockIdx.y * bps, nb = min(B, b0 + bps) - b0;
+  const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+  const float lo = relu ? 0.f : -INFINITY;
+  chan_slab(C, HW, c, b0, nb,
+            [&](size_t i) {
+              const float4 v = *reinterpret_cast<const float4*>(x + i);
+              float4 o;
+              o.x = fmaxf(bn_affine(v.x, m, is, g, bt), lo); o.y = fmaxf(bn_affine(v.y, m, is, g, bt), lo);
+              o.z = fmaxf(bn_affine(v.z, m, is, g, bt), lo); o.w = fmaxf(bn_affine(v.w, m, is, g, bt), lo);
+              *reinterpret_cast<float4*>(y + i) = o;
+            },
+            [&](size_t i) { y[i] = fmaxf(bn_affine(x[i], m, is, g, bt), lo); });
+}
+
+// g = gy masked by the ReLU; part[split][c] = {sum g, sum g * xhat}
+__global__ __launch_bounds__(256) void k_bn_bwd_sums(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, int B, int C, int HW, int bps, int relu,
+                                                      float* __restrict__ part) {
+  const int c = blockIdx.x, b0 = blockIdx.y * bps, nb = min(B, b0 + bps) - b0;
+  const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+  float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
+  auto one = [&](float xv, float gv, float& a0, float& a1) {
+    const float xh = bn_xhat(xv, m, is);
+    if (relu && !(__fmaf_rn(xh, g, bt) > 0.f)) gv = 0.f;
+    a0 += gv;
+    a1 = fmaf(gv, xh, a1);
+  };
+  chan_slab(C, HW, c, b0, nb,
+            [&](size_t i) {
+              const float4 v = *reinterpret_cast<const float4*>(x + i), w = *reinterpret_cast<const float4*>(gy + i);
+              one(v.x, w.x, s0, s1); one(v.y, w.y, t0, t1); one(v.z, w.z, s0, s1); one(v.w, w.w, t0, t1);
+            },
+            [&](size_t i) { one(x[i], gy[i], s0, s1); });
+  const float in2[2] = {s0 + t0, s1 + t1};
+  block_sum_store<2>(in2, part + ((size_t)blockIdx.y * C + c) * 2);
+}
+
+// chan[c] = {sum g, sum g*xhat} over all splits; also the affine gradients
+__global__ void k_bn_bwd_finalize(const float* __restrict__ part, int nsplit, int C, float* __restrict__ chan,
+                                  float* __restrict__ ggamma, float* __restrict__ gbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int s = 0; s < nsplit; ++s) { a += part[((size_t)s * C + c) * 2]; b += part[((size_t)s * C + c) * 2 + 1]; }
+  chan[2 * c] = a; chan[2 * c + 1] = b;
+  gbeta[c] = a;
+  ggamma[c] = b;
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ chan, float count,
+                                                       float* __restrict__ gx, int B, int C, int HW, int bps, int relu) {
+  const int c = blockIdx.x, b0 = blockIdx.y * bps, nb = min(B, b0 + bps) - b0;
+  const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+  const float ic = 1.f / count, ca = chan[2 * c] * ic, cb = chan[2 * c + 1] * ic, sc = g * is;
+  auto one = [&](float xv, float gv) {
+    const float xh = bn_xhat(xv, m, is);
+    if (relu && !(__fmaf_rn(xh, g, bt) > 0.f)) gv = 0.f;
+    return sc * (gv - ca - xh * cb);
+  };
+  chan_slab(C, HW, c, b0, nb,
+            [&](size_t i) {
+              const float4 v = *reinterpret_cast<const float4*>(x + i), w = *reinterpret_cast<const float4*>(gy + i);
+              float4 o;
+              o.x = one(v.x, w.x); o.y = one(v.y, w.y); o.z = one(v.z, w.z); o.w = one(v.w, w.w);
+              *reinterpret_cast<float4*>(gx + i) = o;
+            },
+            [&](size_t i) { gx[i] = one(x[i], gy[i]); });
+}
+
+// part[split][c][0] = sum v
+__global__ __launch_bounds__(256) void k_chan_sum(const float* __restrict__ v, int B, int C, int HW, int bps, float* __restrict__ part) {
+  const int c = blockIdx.x, b0 = blockIdx.y * bps, nb = min(B, b0 + bps) - b0;
+  float s0 = 0.f, t0 = 0.f;
+  chan_slab(C, HW, c, b0, nb,
+            [&](size_t i) {
+              const float4 a = *reinterpret_cast<const float4*>(v + i);
+              s0 += a.x; t0 += a.y; s0 += a.z; t0 += a.w;
+            },
+            [&](size_t i) { s0 += v[i]; });
+  const float in1[1] = {s0 + t0};
+  block_sum_store<1>(in1, part + ((size_t)blockIdx.y * C + c) * 2);
+}
+
+// out[c] = sum_s part[s][c][comp]
+__global__ void k_reduce_chan(const float* __restrict__ part, int nsplit, int C, int comp, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int s = 0; s < nsplit; ++s) a += part[((size_t)s * C + c) * 2 + comp];
+  out[c] = a;
+}
+
+struct Split { int ns, bps, used; };
+inline Split pick(int B) {
+  Split s;
+  s.ns = B < 64 ? B : 64;
+  s.bps = (B + s.ns - 1) / s.ns;
+  s.used = (B + s.bps - 1) / s.bps;
+  return s;
+}
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// floats: part[64][C][2], chan[C][2], shift[C]
+size_t bn_scratch(int B, int C) { return (size_t)(B < 64 ? B : 64) * C * 2 + (size_t)C * 3; }
+
+int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
+           float* running_mean, float* running_var, float momentum, float eps, int B, int C, int HW, int relu,
+           float* scratch, hipStream_t st) {
+  if ((HW & 3) == 0 && !(aligned16(x) && aligned16(y))) return set_error("gpode_bn_fwd: x / y must be 16-byte aligned");
+  const Split sp = pick(B);
+  float* shift = scratch + (size_t)sp.ns * C * 2 + (size_t)C * 2;
+  hipLaunchKernelGGL(k_bn_stats, dim3(C, sp.used), 256, 0, st, x, B, C, HW, sp.bps, scratch, shift);
+  hipLaunchKernelGGL(k_bn_finalize, (C + 63) / 64, 64, 0, st, scratch, shift, sp.used, C, (float)B * HW, eps, momentum, save_mean,
+                     save_invstd, running_mean, running_var);
+  hipLaunchKernelGGL(k_bn_apply, dim3(C, sp.used), 256, 0, st, x, gamma, beta, save_mean, save_invstd, y, B, C, HW, sp.bps, relu);
+  return check_launch("bn_fwd");
+}
+
+// the forward output is not needed: the ReLU mask is recomputed from x (same pinned arithmetic as k_bn_apply)
+int bn_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
+           const float* save_invstd, float* gx, float* ggamma, float* gbeta, int B, int C, int HW, int relu, float* scratch,
+           hipStream_t st) {
+  if ((HW & 3) == 0 && !(aligned16(x) && aligned16(gy) && aligned16(gx))) return set_error("gpode_bn_bwd: x / gy / gx must be 16-byte aligned");
+  const Split sp = pick(B);
+  float* chan = scratch + (size_t)sp.ns * C * 2;
+  hipLaunchKernelGGL(k_bn_bwd_sums, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, save_mean, save_invstd, B, C, HW, sp.bps, relu, scratch);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, (C + 63) / 64, 64, 0, st, scratch, sp.used, C, chan, ggamma, gbeta);
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, save_mean, save_invstd, chan, (float)B * HW, gx, B, C,
+                     HW, sp.bps, relu);
+  return check_launch("bn_bwd");
+}
+
+// out[c] = sum over (b, hw) of v[b,c,hw]   (bias gradient of ConvTranspose2d / Conv2d)
+int chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, hipStream_t st) {
+  if ((HW & 3) == 0 && !aligned16(v)) return set_error("gpode_chan_sum: v must be 16-byte aligned");
+  const Split sp = pick(B);
+  hipLaunchKernelGGL(k_chan_sum, dim3(C, sp.used), 256, 0, st, v, B, C, HW, sp.bps, scratch);
+  hipLaunchKernelGGL(k_reduce_chan, (C + 63) / 64, 64, 0, st, scratch, sp.used, C, 0, out);
+  return check_launch("chan_sum");
+}
+
+}  // namespace gp

@@ -100,17 +100,17 @@ class _BatchNormTrain(torch.autograd.Function):
         _lib.call('gpode_bn_fwd', _ptr(x), _ptr(_chk(gamma, 'gamma')), _ptr(_chk(beta, 'beta')), _ptr(y), _ptr(mean), _ptr(invstd),
                   _ptr(running_mean), _ptr(running_var), ctypes.c_float(momentum), ctypes.c_float(eps), B, C, HW, int(relu),
                   _ptr(_bn_scratch(B, C, x)), _stream())
-        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
         ctx.relu = int(relu)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, y, gamma, mean, invstd = ctx.saved_tensors
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
         B, C = x.shape[0], x.shape[1]
         HW = x[0, 0].numel()
         gx, gg, gb = _new(x.shape, x), _new((C,), x), _new((C,), x)
-        _lib.call('gpode_bn_bwd', _ptr(x), _ptr(y), _ptr(gy.contiguous()), _ptr(gamma), _ptr(mean), _ptr(invstd), _ptr(gx), _ptr(gg),
+        _lib.call('gpode_bn_bwd', _ptr(x), _ptr(gy.contiguous()), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(gx), _ptr(gg),
                   _ptr(gb), B, C, HW, ctx.relu, _ptr(_bn_scratch(B, C, x)), _stream())
         return gx, gg, gb, None, None, None, None, None
 
