@@ -500,17 +500,25 @@ template <class L, int IPB> constexpr size_t wgrad_lds_bytes() {
   return sizeof(float) * (size_t)IPB * (WgradGeo<L>::IMGX + WgradGeo<L>::IMGG);
 }
 
-// out[e] = sum_s part[s][e] in a fixed order: 4 interleaved partial sums per element, combined through LDS
-__global__ __launch_bounds__(256) void k_sum_splits4(const float* __restrict__ part, int nsplit, size_t n, float* __restrict__ out) {
-  __shared__ float red[256];
+// out[e] = sum_s part[s][e] in a fixed order: 16 interleaved partial sums per element, combined through LDS.
+// grid = ceil(n / 64), block = 1024 (64 elements x 16 split groups).
+__global__ __launch_bounds__(1024) void k_sum_splits4(const float* __restrict__ part, int nsplit, size_t n, float* __restrict__ out) {
+  __shared__ float red[16][64];
   const int ex = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const size_t e = (size_t)blockIdx.x * 64 + ex;
   float acc = 0.f;
-  if (e < n)
-    for (int s = sg; s < nsplit; s += 4) acc += part[(size_t)s * n + e];
-  red[threadIdx.x] = acc;
+  if (e < n) {
+#pragma unroll 8
+    for (int s = sg; s < nsplit; s += 16) acc += part[(size_t)s * n + e];
+  }
+  red[sg][ex] = acc;
   __syncthreads();
-  if (sg == 0 && e < n) out[e] = (red[ex] + red[64 + ex]) + (red[128 + ex] + red[192 + ex]);
+  if (sg == 0 && e < n) {
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v += red[g][ex];
+    out[e] = v;
+  }
 }
 
 template <class PL, int IPB> constexpr size_t igemm_lds_bytes() {

@@ -435,7 +435,7 @@ static int launch_T3(const float* x, const float* gy, float* gw, float* scratch,
     const int nwg = ngroups < 256 ? ngroups : 256;
     hipLaunchKernelGGL(km, nwg, 512, ldsm, st, x, gy, scratch, B);
     const size_t n = (size_t)L::CI * L::CO * L::K * L::K;
-    hipLaunchKernelGGL(k_sum_splits4, (unsigned)((n + 63) / 64), 256, 0, st, scratch, nwg, n, gw);
+    hipLaunchKernelGGL(k_sum_splits4, (unsigned)((n + 63) / 64), 1024, 0, st, scratch, nwg, n, gw);
     return check_launch("convT_wgrad_mfma");
   }
   constexpr int NT = L::CI * (COW / 4), PSPLIT = 256 / NT, KK = L::K * L::K;
@@ -513,7 +513,7 @@ int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch,
     const int ngroups = (B + IPB - 1) / IPB;
     const int nwg = ngroups < 256 ? ngroups : 256;
     hipLaunchKernelGGL(dec10::k_wgrad<IPB>, nwg, 512, sizeof(float) * fl, st, gy, x, scratch, B);
-    hipLaunchKernelGGL(k_sum_splits4, (400 + 63) / 64, 256, 0, st, scratch, nwg, (size_t)400, gw);
+    hipLaunchKernelGGL(k_sum_splits4, (400 + 63) / 64, 1024, 0, st, scratch, nwg, (size_t)400, gw);
     return check_launch("dec10_wgrad_mfma");
   }
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) {

@@ -4,7 +4,7 @@
 // All kernels are HBM-bound passes over an activation tensor (B, C, HW).  Layout of the work: grid (C, nsplit);
 // a workgroup owns channel c and a contiguous slab of images, so the channel's scalars are workgroup constants and
 // the loop body has no integer division (float4 accesses when HW % 4 == 0).  Pass counts:
-//   forward   statistics (1 read)  + normalise / affine / ReLU (1 read, 1 write)
+//   forward   statistics (1 read)  + normalise / affine / ReLU (1 read, 1 write; finalises the statistics itself)
 //   backward  channel sums (2 reads: x, gy) + apply (2 reads, 1 write); the ReLU mask is recomputed from x with the
 //             same pinned arithmetic as the forward pass, so the forward output y is not read again.
 // Variance: sums of (x - k) and (x - k)^2 with a per-channel shift k (mean of the first <= 64 elements of the
@@ -61,6 +61,16 @@ template <int NV> __device__ __forceinline__ void block_sum_store(const float (&
   if (threadIdx.x < NV) dst[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// sum over the splits (<= 64) of part[s][c][0..1]: lane s loads split s; identical in every wavefront of every workgroup
+__device__ __forceinline__ void split_sums(const float* __restrict__ part, int nsplit, int C, int c, float& a, float& b) {
+  const int lane = threadIdx.x & 63;
+  const float in2[2] = {lane < nsplit ? part[((size_t)lane * C + c) * 2] : 0.f, lane < nsplit ? part[((size_t)lane * C + c) * 2 + 1] : 0.f};
+  float out2[2];
+  wave_sum_multi<2>(in2, out2);
+  a = out2[0];
+  b = out2[1];
+}
+
 // shift k(c): mean of the first min(HW, 64) elements of image 0 (every wavefront of every workgroup computes the same value)
 __device__ __forceinline__ float chan_shift(const float* __restrict__ x, int HW, int c) {
   const int n = HW < 64 ? HW : 64, lane = threadIdx.x & 63;
@@ -93,30 +103,30 @@ __global__ __launch_bounds__(256) void k_bn_stats(const float* __restrict__ x, i
   if (blockIdx.y == 0 && threadIdx.x == 0) shift[c] = k;
 }
 
-// batch statistics (biased variance for the normalisation, unbiased for the running estimate, momentum as nn.BatchNorm2d)
-__global__ void k_bn_finalize(const float* __restrict__ part, const float* __restrict__ shift, int nsplit, int C, float count, float eps,
-                              float momentum, float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                              float* __restrict__ running_mean, float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s0 = 0.f, s1 = 0.f;
-  for (int s = 0; s < nsplit; ++s) { s0 += part[((size_t)s * C + c) * 2]; s1 += part[((size_t)s * C + c) * 2 + 1]; }
-  const float d = s0 / count;                        // mean - k
-  const float mean = shift[c] + d;
-  const float var = fmaxf(s1 / count - d * d, 0.f);
-  save_mean[c] = mean;
-  save_invstd[c] = rsqrtf(var + eps);
-  if (running_mean) {
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count / (count - 1.f));
-  }
-}
-
+// batch statistics from the split sums (biased variance for the normalisation, unbiased for the running estimate,
+// momentum as nn.BatchNorm2d), then normalise / affine / ReLU.  Every workgroup of channel c derives the same statistics;
+// split 0 publishes them.
 __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ y,
+                                                   const float* __restrict__ part, const float* __restrict__ shift, int nsplit, float count,
+                                                   float eps, float momentum, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                   float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ y,
                                                    int B, int C, int HW, int bps, int relu) {
   const int c = blockIdx.x, b0 = blockIdx.y * bps, nb = min(B, b0 + bps) - b0;
-  const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+  float s0, s1;
+  split_sums(part, nsplit, C, c, s0, s1);
+  const float d = s0 / count;                        // mean - k
+  const float m = shift[c] + d;
+  const float var = fmaxf(s1 / count - d * d, 0.f);
+  const float is = rsqrtf(var + eps);
+  if (blockIdx.y == 0 && threadIdx.x == 0) {
+    save_mean[c] = m;
+    save_invstd[c] = is;
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count / (count - 1.f));
+    }
+  }
+  const float g = gamma[c], bt = beta[c];
   const float lo = relu ? 0.f : -INFINITY;
   chan_slab(C, HW, c, b0, nb,
             [&](size_t i) {
@@ -153,25 +163,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_sums(const float* __restrict__ x
   block_sum_store<2>(in2, part + ((size_t)blockIdx.y * C + c) * 2);
 }
 
-// chan[c] = {sum g, sum g*xhat} over all splits; also the affine gradients
-__global__ void k_bn_bwd_finalize(const float* __restrict__ part, int nsplit, int C, float* __restrict__ chan,
-                                  float* __restrict__ ggamma, float* __restrict__ gbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float a = 0.f, b = 0.f;
-  for (int s = 0; s < nsplit; ++s) { a += part[((size_t)s * C + c) * 2]; b += part[((size_t)s * C + c) * 2 + 1]; }
-  chan[2 * c] = a; chan[2 * c + 1] = b;
-  gbeta[c] = a;
-  ggamma[c] = b;
-}
-
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ mean,
-                                                       const float* __restrict__ invstd, const float* __restrict__ chan, float count,
+                                                       const float* __restrict__ invstd, const float* __restrict__ part, int nsplit,
+                                                       float count, float* __restrict__ ggamma, float* __restrict__ gbeta,
                                                        float* __restrict__ gx, int B, int C, int HW, int bps, int relu) {
   const int c = blockIdx.x, b0 = blockIdx.y * bps, nb = min(B, b0 + bps) - b0;
   const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
-  const float ic = 1.f / count, ca = chan[2 * c] * ic, cb = chan[2 * c + 1] * ic, sc = g * is;
+  float sa, sb;                                      // sum g, sum g * xhat over all splits: also the affine gradients
+  split_sums(part, nsplit, C, c, sa, sb);
+  if (blockIdx.y == 0 && threadIdx.x == 0) { gbeta[c] = sa; ggamma[c] = sb; }
+  const float ic = 1.f / count, ca = sa * ic, cb = sb * ic, sc = g * is;
   auto one = [&](float xv, float gv) {
     const float xh = bn_xhat(xv, m, is);
     if (relu && !(__fmaf_rn(xh, g, bt) > 0.f)) gv = 0.f;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
             [&](size_t i) { gx[i] = one(x[i], gy[i]); });
 }
 
-// part[split][c][0] = sum v
+// part[split][c] = {sum v, 0}
 __global__ __launch_bounds__(256) void k_chan_sum(const float* __restrict__ v, int B, int C, int HW, int bps, float* __restrict__ part) {
   const int c = blockIdx.x, b0 = blockIdx.y * bps, nb = min(B, b0 + bps) - b0;
   float s0 = 0.f, t0 = 0.f;
@@ -197,17 +199,15 @@ __global__ __launch_bounds__(256) void k_chan_sum(const float* __restrict__ v, i
               s0 += a.x; t0 += a.y; s0 += a.z; t0 += a.w;
             },
             [&](size_t i) { s0 += v[i]; });
-  const float in1[1] = {s0 + t0};
-  block_sum_store<1>(in1, part + ((size_t)blockIdx.y * C + c) * 2);
+  const float in2[2] = {s0 + t0, 0.f};
+  block_sum_store<2>(in2, part + ((size_t)blockIdx.y * C + c) * 2);
 }
 
-// out[c] = sum_s part[s][c][comp]
-__global__ void k_reduce_chan(const float* __restrict__ part, int nsplit, int C, int comp, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float a = 0.f;
-  for (int s = 0; s < nsplit; ++s) a += part[((size_t)s * C + c) * 2 + comp];
-  out[c] = a;
+// out[c] = sum_s part[s][c][0]; one wavefront per channel
+__global__ __launch_bounds__(64) void k_reduce_chan(const float* __restrict__ part, int nsplit, int C, float* __restrict__ out) {
+  float a, b;
+  split_sums(part, nsplit, C, blockIdx.x, a, b);
+  if (threadIdx.x == 0) out[blockIdx.x] = a;
 }
 
 struct Split { int ns, bps, used; };
@@ -222,7 +222,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-// floats: part[64][C][2], chan[C][2], shift[C]
+// floats: part[64][C][2], (unused [C][2]), shift[C]
 size_t bn_scratch(int B, int C) { return (size_t)(B < 64 ? B : 64) * C * 2 + (size_t)C * 3; }
 
 int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
@@ -232,9 +232,8 @@ int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, floa
   const Split sp = pick(B);
   float* shift = scratch + (size_t)sp.ns * C * 2 + (size_t)C * 2;
   hipLaunchKernelGGL(k_bn_stats, dim3(C, sp.used), 256, 0, st, x, B, C, HW, sp.bps, scratch, shift);
-  hipLaunchKernelGGL(k_bn_finalize, (C + 63) / 64, 64, 0, st, scratch, shift, sp.used, C, (float)B * HW, eps, momentum, save_mean,
-                     save_invstd, running_mean, running_var);
-  hipLaunchKernelGGL(k_bn_apply, dim3(C, sp.used), 256, 0, st, x, gamma, beta, save_mean, save_invstd, y, B, C, HW, sp.bps, relu);
+  hipLaunchKernelGGL(k_bn_apply, dim3(C, sp.used), 256, 0, st, x, gamma, beta, scratch, shift, sp.used, (float)B * HW, eps, momentum, save_mean,
+                     save_invstd, running_mean, running_var, y, B, C, HW, sp.bps, relu);
   return check_launch("bn_fwd");
 }
 
@@ -244,11 +243,9 @@ int bn_bwd(const float* x, const float* gy, const float* gamma, const float* bet
            hipStream_t st) {
   if ((HW & 3) == 0 && !(aligned16(x) && aligned16(gy) && aligned16(gx))) return set_error("gpode_bn_bwd: x / gy / gx must be 16-byte aligned");
   const Split sp = pick(B);
-  float* chan = scratch + (size_t)sp.ns * C * 2;
   hipLaunchKernelGGL(k_bn_bwd_sums, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, save_mean, save_invstd, B, C, HW, sp.bps, relu, scratch);
-  hipLaunchKernelGGL(k_bn_bwd_finalize, (C + 63) / 64, 64, 0, st, scratch, sp.used, C, chan, ggamma, gbeta);
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, save_mean, save_invstd, chan, (float)B * HW, gx, B, C,
-                     HW, sp.bps, relu);
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, save_mean, save_invstd, scratch, sp.used, (float)B * HW,
+                     ggamma, gbeta, gx, B, C, HW, sp.bps, relu);
   return check_launch("bn_bwd");
 }
 
@@ -257,7 +254,7 @@ int chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, h
   if ((HW & 3) == 0 && !aligned16(v)) return set_error("gpode_chan_sum: v must be 16-byte aligned");
   const Split sp = pick(B);
   hipLaunchKernelGGL(k_chan_sum, dim3(C, sp.used), 256, 0, st, v, B, C, HW, sp.bps, scratch);
-  hipLaunchKernelGGL(k_reduce_chan, (C + 63) / 64, 64, 0, st, scratch, sp.used, C, 0, out);
+  hipLaunchKernelGGL(k_reduce_chan, C, 64, 0, st, scratch, sp.used, C, out);
   return check_launch("chan_sum");
 }
 
