@@ -174,6 +174,7 @@ def main():
     ap.add_argument('--mode', default='elbo', choices=['elbo', 'integrator'])
     ap.add_argument('--seed', type=int, default=121)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel of the step eagerly instead of replaying a captured HIP graph')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -217,14 +218,47 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
     sync = GradAllReduce(opt.flat_grads, dist) if dist is not None else None
     last = {}
 
-    def step():
+    def fwd_bwd():
         opt.zero_grad()
         loss, nl, klr, klu = compute_loss(model, Xd, 1)
         loss.backward()
+        return loss
+
+    def eager_step():
+        last['loss'] = fwd_bwd()
         if sync is not None:
             sync.all_reduce_grads()
         opt.step()
-        last['loss'] = loss
+
+    def whole_step():
+        loss = fwd_bwd()
+        opt.step()
+        return loss
+
+    # One HIP graph per step instead of ~250 launches (vae_gp_ode_amd/graph.py).  N = 1: the whole step; N > 1: forward +
+    # backward are replayed, the gradient all-reduce (RCCL) and the Adam launch stay eager between replays.
+    step, graphed = eager_step, False
+    if not a.no_graph:
+        try:
+            from vae_gp_ode_amd.graph import GraphedStep, device_generators
+            model.flow.odefunc.diffeq.noise_source.draw(w['kernel'], w['q'] * w['order'], w['q'], w['M'], w['S'], dev)  # creates the generator
+            gens = device_generators(model)
+            g = GraphedStep(whole_step if sync is None else fwd_bwd, generators=gens, warmup=2)
+            if sync is None:
+                def step():
+                    last['loss'] = g()
+            else:
+                def step():
+                    last['loss'] = g()
+                    sync.all_reduce_grads()
+                    opt.step()
+            graphed = True
+        except Exception as e:  # capture is an optimisation of the launch path, not of the kernels: report and run eagerly
+            import traceback
+            traceback.print_exc(limit=14, file=sys.stderr)
+            print('[bench] HIP graph capture failed (%s); running the step eagerly' % type(e).__name__, file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            step = eager_step
     for _ in range(a.warmup):
         step()
     barrier()
@@ -246,7 +280,8 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
         'n_gpus': n_gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': el / a.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': w['desc'] + '; step = full ELBO training step (encoder, GP draw, rk4 rollout, decoder, ELBO, backward, Adam), L=1',
-                   'global_batch': w['batch'] * n_gpus, 'solver': 'rk4 (3/8 rule)', 'parallelism': 'dp%d' % n_gpus},
+                   'global_batch': w['batch'] * n_gpus, 'solver': 'rk4 (3/8 rule)', 'parallelism': 'dp%d' % n_gpus,
+                   'hip_graph': graphed},
         'elbo_step_ms': el / a.steps * 1e3,
         'roofline': roof,
     }
@@ -331,7 +366,8 @@ def run_integrator(a, w, dev, rank, n_gpus, dist, barrier):
         'n_gpus': n_gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': el / a.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': w['desc'] + '; step = GP draw (K_uu, Cholesky, nu) + rk4 rollout, L=1 [integrator fwd]',
-                   'global_batch': w['batch'] * n_gpus, 'solver': 'rk4 (3/8 rule)', 'parallelism': 'dp%d' % n_gpus},
+                   'global_batch': w['batch'] * n_gpus, 'solver': 'rk4 (3/8 rule)', 'parallelism': 'dp%d' % n_gpus,
+                   'hip_graph': graphed},
         'roofline': {'bound': 'mfma', 'kernel': 'rollout_kernel', 'achieved': achieved, 'peak': PEAK_FP32_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS, 'traffic': None,
                      'ms_per_launch': roll_ms,

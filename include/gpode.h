@@ -156,9 +156,10 @@ int gpode_loglik_rowsum_bwd(const float* X, const float* z, const float* grow, f
 
 /* torch.optim.Adam step (main.py:194,211) over a whole parameter list in one launch.  params/grads/m1/m2:
  * DEVICE arrays of `ntensors` device pointers; offs: DEVICE array of element prefix offsets (offs[0]=0);
- * step: 1-based step count (bias correction). */
+ * step: 1-based step count (bias correction).  step_dev (optional, DEVICE int): when non-NULL it is incremented on the
+ * stream and used instead of `step`, so that a captured HIP graph of the training step replays with a live count. */
 int gpode_adam_multi(void* params, void* grads, void* m1, void* m2, const long long* offs, int ntensors, long long total,
-                     float lr, float beta1, float beta2, float eps, int step, void* stream);
+                     float lr, float beta1, float beta2, float eps, int step, int* step_dev, void* stream);
 
 #ifdef __cplusplus
 }

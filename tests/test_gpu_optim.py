@@ -68,3 +68,57 @@ def test_main_training_loop_runs(tmp_path, monkeypatch):
     assert 'flow.odefunc.diffeq.Us_sqrt.optvar' in sd and all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
     rel = os.path.relpath(os.path.dirname(ck[0]), tmp_path)
     M.main(common + ['--Nepoch', '1', '--save', 'results/u', '--continue_training', 'True', '--model_path', rel])
+
+
+def test_graph_replay_equals_eager_steps():
+    """A training step replayed from a captured HIP graph updates the parameters exactly like the same step launched
+    kernel by kernel (fixed noise, so both paths see identical draws): 1 eager + 2 replayed steps == 3 eager steps."""
+    import copy
+    from vae_gp_ode_amd.graph import GraphedStep
+    from vae_gp_ode_amd.model.core.initialization import initialize_and_fix_kernel_parameters
+    from vae_gp_ode_amd.model.core.noise import DeviceNoise
+    from vae_gp_ode_amd.model.create_model import build_model, compute_loss
+    from vae_gp_ode_amd.model.misc.torch_utils import seed_everything
+    from vae_gp_ode_amd.optim import HipAdam
+    seed_everything(4)
+    args = types.SimpleNamespace(D_in=6, D_out=6, num_inducing=32, num_features=64, dimwise=True, q_diag=False, device='cuda',
+                                 kernel='DF', ode=1, solver='rk4', use_adjoint=False, frames=5, n_filt=8, latent_dim=6, Ndata=64, dt=0.1)
+    m = build_model(args).cuda()
+    initialize_and_fix_kernel_parameters(m, 2.0, 1.0)
+    init = copy.deepcopy(m.state_dict())
+    X = torch.rand(16, 8, 1, 28, 28, device='cuda')
+    fixed = DeviceNoise(9).draw('DF', 6, 6, 32, 64, 'cuda')
+
+    class FixedNoise:
+        def draw(self, *a):
+            return fixed
+    m.flow.odefunc.diffeq.noise_source = FixedNoise()
+    eps = torch.randn(16, 6, device='cuda')
+    enc = m.vae.encoder
+
+    def run(use_graph):
+        m.load_state_dict(init)
+        opt = HipAdam(m.parameters(), lr=1e-3)
+
+        def step():
+            enc.next_eps = eps
+            opt.zero_grad()
+            loss, *_ = compute_loss(m, X, 1)
+            loss.backward()
+            opt.step()
+            return loss
+        if use_graph:
+            g = GraphedStep(step, warmup=1)
+            g(); g()
+        else:
+            for _ in range(3):
+                step()
+        torch.cuda.synchronize()
+        assert int(opt.step_dev.item()) == 3
+        return [p.detach().clone() for p in m.parameters()], [b.detach().clone() for b in m.buffers()]
+    pe, be = run(False)
+    pg, bg = run(True)
+    for a, b in zip(pe, pg):
+        assert torch.equal(a, b)
+    for a, b in zip(be, bg):   # BatchNorm running statistics advance in the replayed steps too
+        assert torch.equal(a, b)

@@ -53,7 +53,7 @@ SIGNATURES.update({
     'gpode_loglik_fwd': (_i, [_c_float_p] * 3 + [_sz, _sz, _vp]),
     'gpode_loglik_bwd': (_i, [_c_float_p] * 4 + [_sz, _sz, _vp]),
     'gpode_loglik_rowsum_fwd': (_i, [_c_float_p] * 3 + [_sz, _sz, _sz, _vp]),
-    'gpode_adam_multi': (_i, [_vp, _vp, _vp, _vp, _vp, _i, ctypes.c_longlong, _f, _f, _f, _f, _i, _vp]),
+    'gpode_adam_multi': (_i, [_vp, _vp, _vp, _vp, _vp, _i, ctypes.c_longlong, _f, _f, _f, _f, _i, _vp, _vp]),
     'gpode_loglik_rowsum_bwd': (_i, [_c_float_p] * 4 + [_sz, _sz, _sz, _vp]),
 })
 

@@ -171,10 +171,10 @@ int gpode_loglik_rowsum_bwd(const float* X, const float* z, const float* grow, f
   return gp::loglik_rowsum_bwd(X, z, grow, gz, rows, inner, nX, GP_ST);
 }
 int gpode_adam_multi(void* params, void* grads, void* m1, void* m2, const long long* offs, int ntensors, long long total,
-                     float lr, float beta1, float beta2, float eps, int step, void* stream) {
+                     float lr, float beta1, float beta2, float eps, int step, int* step_dev, void* stream) {
   if (!params || !grads || !m1 || !m2 || !offs) return gp::set_error("gpode_adam_multi: null pointer");
   return gp::adam_multi((float* const*)params, (const float* const*)grads, (float* const*)m1, (float* const*)m2, offs, ntensors, total,
-                        lr, beta1, beta2, eps, step, GP_ST);
+                        lr, beta1, beta2, eps, step, step_dev, GP_ST);
 }
 #undef GP_ST
 

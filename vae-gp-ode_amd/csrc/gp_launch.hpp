@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
+#include <unordered_map>
 
 namespace gp {
 
@@ -22,10 +24,19 @@ inline int check_launch(const char* what) {
   return 0;
 }
 
+// Raise a kernel's dynamic-LDS limit above the 64 KB default.  The attribute is set once per (kernel, size) and
+// remembered: hipFuncSetAttribute is not a stream operation (it is refused while the stream is being captured into
+// a graph), and the first eager run of a step has already set every attribute its replay needs.
 inline int set_max_lds(const void* kern, size_t bytes) {
   if (bytes <= 64 * 1024) return 0;
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> done;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find(kern);
+  if (it != done.end() && it->second >= bytes) return 0;
   hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return set_error("hipFuncSetAttribute(max dynamic LDS=%zu): %s", bytes, hipGetErrorString(e));
+  done[kern] = bytes;
   return 0;
 }
 
@@ -81,6 +92,6 @@ int loglik_bwd(const float* X, const float* z, const float* g, float* gz, size_t
 int loglik_rowsum_fwd(const float* X, const float* z, float* out, size_t rows, size_t inner, size_t nX, hipStream_t st);
 int loglik_rowsum_bwd(const float* X, const float* z, const float* grow, float* gz, size_t rows, size_t inner, size_t nX, hipStream_t st);
 int adam_multi(float* const* params, const float* const* grads, float* const* m1, float* const* m2, const long long* offs,
-               int ntensors, long long total, float lr, float beta1, float beta2, float eps, int step, hipStream_t st);
+               int ntensors, long long total, float lr, float beta1, float beta2, float eps, int step, int* step_dev, hipStream_t st);
 
 }  // namespace gp

@@ -349,7 +349,13 @@ int loglik_rowsum_bwd(const float* X, const float* z, const float* grow, float* 
 namespace gp {
 __global__ void k_adam_multi(float* const* __restrict__ params, const float* const* __restrict__ grads,
                              float* const* __restrict__ m1, float* const* __restrict__ m2, const long long* __restrict__ offs,
-                             int ntensors, long long total, float lr, float beta1, float beta2, float eps, float bc1, float bc2) {
+                             int ntensors, long long total, float lr, float beta1, float beta2, float eps, float bc1, float bc2,
+                             const int* __restrict__ step_dev) {
+  if (step_dev) {                                    // step counter kept on the device (captured graphs replay with a live count)
+    const float t = (float)*step_dev;
+    bc1 = 1.f - powf(beta1, t);
+    bc2 = 1.f - powf(beta2, t);
+  }
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     int lo = 0, hi = ntensors - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (offs[mid] <= e) lo = mid; else hi = mid - 1; }
@@ -364,10 +370,15 @@ __global__ void k_adam_multi(float* const* __restrict__ params, const float* con
   }
 }
 
+__global__ void k_inc_step(int* step) { *step += 1; }
+
+// step_dev != nullptr: *step_dev is incremented on the stream and used as the step count (host `step` ignored)
 int adam_multi(float* const* params, const float* const* grads, float* const* m1, float* const* m2, const long long* offs,
-               int ntensors, long long total, float lr, float beta1, float beta2, float eps, int step, hipStream_t st) {
+               int ntensors, long long total, float lr, float beta1, float beta2, float eps, int step, int* step_dev, hipStream_t st) {
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(k_adam_multi, ew_grid((size_t)total), 256, 0, st, params, grads, m1, m2, offs, ntensors, total, lr, beta1, beta2, eps, bc1, bc2);
+  if (step_dev) hipLaunchKernelGGL(k_inc_step, 1, 1, 0, st, step_dev);
+  hipLaunchKernelGGL(k_adam_multi, ew_grid((size_t)total), 256, 0, st, params, grads, m1, m2, offs, ntensors, total, lr, beta1, beta2, eps, bc1, bc2,
+                     (const int*)step_dev);
   return check_launch("adam_multi");
 }
 }  // namespace gp

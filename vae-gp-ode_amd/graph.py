@@ -1,0 +1,56 @@
+"""Replay a whole training step as one HIP graph.
+
+A step of the ELBO loop (experiments/main.py:198-212: zero_grad, compute_loss, backward, optimizer step) is ~250
+kernel launches, half of them a few microseconds long; launched one by one the GPU idles between them.  Every
+op of this package launches on torch's current stream and allocates through torch's caching allocator, so the
+step can be stream-captured once (``torch.cuda.CUDAGraph`` = hipGraph on ROCm) and replayed: same kernels, same
+arguments, one submission.  Requirements met by the package: static gradient storage (``parallel.FlatGrads``),
+device-resident Adam step count (``optim.HipAdam.step_dev``), device-side noise (``DeviceNoise``; its generator
+must be registered so that every replay draws fresh numbers), no host synchronisation inside the step.
+"""
+import torch
+
+
+class GraphedStep:
+    def __init__(self, step_fn, generators=(), warmup=3):
+        """step_fn() -> tensor or tuple of tensors (static outputs, overwritten by every replay)."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):      # lazy initialisation (generators, LDS attributes, allocator pools)
+                step_fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        for g in generators:
+            if g is not None:
+                self.graph.register_generator_state(g)
+        with torch.cuda.graph(self.graph):
+            self.out = step_fn()
+        self.eager_steps = warmup
+
+    def __call__(self):
+        self.graph.replay()
+        return self.out
+
+
+def device_generators(model):
+    """The torch.Generator objects of every DeviceNoise source reachable from ``model``."""
+    from .model.core.noise import DeviceNoise
+    gens, seen = [], set()
+
+    def visit(obj):
+        if id(obj) in seen:
+            return
+        seen.add(id(obj))
+        if isinstance(obj, DeviceNoise):
+            if obj._gen is not None:
+                gens.append(obj._gen)
+            return
+        if isinstance(obj, torch.nn.Module):
+            for v in vars(obj).values():
+                visit(v)
+            for m in obj.children():
+                visit(m)
+    visit(model)
+    return gens

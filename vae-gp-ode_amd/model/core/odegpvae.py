@@ -21,7 +21,7 @@ class ODEGPVAE(nn.Module):
 
     def sample_trajectories(self, z0, T, L=1):
         """L independent function draws, each shared by the whole minibatch (odegpvae.py:37-45)."""
-        ts = self.dt * torch.arange(T, dtype=torch.float).to(z0.device)
+        ts = self.dt * torch.arange(T, dtype=torch.float, device=z0.device)
         return torch.stack([self.flow(z0, ts) for _ in range(L)], 0)
 
     def forward(self, X, L=1, T_custom=None):

@@ -61,7 +61,9 @@ class Encoder(nn.Module):
     def q_dist(self, mu_s, logvar_s, mu_v=None, logvar_v=None):
         if mu_v is not None:
             mu_s, logvar_s = torch.cat((mu_s, mu_v), dim=1), torch.cat((logvar_s, logvar_v), dim=1)
-        return Normal(mu_s, torch.exp(0.5 * logvar_s))
+        # validate_args=False: the default argument check reads a device boolean back to the host (a stream
+        # synchronisation per step, and not capturable into a HIP graph); exp() cannot produce an invalid scale
+        return Normal(mu_s, torch.exp(0.5 * logvar_s), validate_args=False)
 
     @property
     def device(self):
@@ -116,10 +118,10 @@ class VAE(nn.Module):
         super().__init__()
         self.encoder = Encoder(latent_dim, n_filt).to(device)
         self.decoder = Decoder(latent_dim, n_filt, distribution).to(device)
-        self.prior = Normal(torch.zeros(latent_dim).to(device), torch.ones(latent_dim).to(device))
+        self.prior = Normal(torch.zeros(latent_dim).to(device), torch.ones(latent_dim).to(device), validate_args=False)
         if order == 2:
             self.encoder_v = Encoder(latent_dim, n_filt, frames).to(device)
-            self.prior = Normal(torch.zeros(latent_dim * 2).to(device), torch.ones(latent_dim * 2).to(device))
+            self.prior = Normal(torch.zeros(latent_dim * 2).to(device), torch.ones(latent_dim * 2).to(device), validate_args=False)
         self.latent_dim = latent_dim
         self.order = order
 

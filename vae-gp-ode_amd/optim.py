@@ -17,6 +17,9 @@ class HipAdam:
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
         dev = self.params[0].device
+        # device-resident copy of the step count: incremented by the update kernel's launch sequence, so a captured
+        # HIP graph of the whole training step (see graph.py) replays with the right bias correction
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         # persistent gradient storage: views into one flat bucket (all-reduced in place under data parallelism)
@@ -48,4 +51,4 @@ class HipAdam:
         vp = lambda t: ctypes.c_void_p(t.data_ptr())
         _lib.call('gpode_adam_multi', vp(self._p), vp(self._g), vp(self._m), vp(self._v), vp(self._offs), len(self.params),
                   self.total, ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]),
-                  ctypes.c_float(self.eps), self.step_count, _stream())
+                  ctypes.c_float(self.eps), self.step_count, vp(self.step_dev), _stream())
