@@ -314,9 +314,21 @@ def dominant_kernel_roofline(w, dev, reps=20):
     macs = 169 * 32 * 16 * 25  # per image: every input pixel x Cin x Cout x taps (2.163 MMAC)
     flops = 2.0 * macs * B
     ach = flops / (ms * 1e-3) / 1e12
-    return {'bound': 'mfma', 'kernel': 'k_conv_bwd_data<5,2> (decoder decnn.7 forward)', 'achieved': ach, 'peak': PEAK_FP32_TFLOPS,
-            'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_TFLOPS, 'traffic': None, 'ms_per_launch': ms,
-            'note': 'algorithmic flops = 2 x 2.163 MMAC/image x %d images; fp32, priced against the fp32 MFMA peak' % B}
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (tools/gpu_pmc_cycle.sh), which cannot run inside
+    # this process; the committed measurement is used when it was taken at the same image count
+    traffic, tsrc = None, None
+    try:
+        here = os.path.dirname(os.path.abspath(__file__))
+        rec = json.load(open(os.path.join(here, 'profiles', 'r01f_roofline_traffic.json')))
+        if rec.get('images') == B:
+            traffic, tsrc = rec['hbm_bytes_per_launch'], 'profiles/r01f_roofline_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)'
+    except (OSError, ValueError, KeyError):
+        pass
+    return {'bound': 'mfma', 'kernel': 'k_conv_igemm<FwdPolicy<decnn.7>> (decoder decnn.7 forward, v_mfma_f32_16x16x4_f32)',
+            'achieved': ach, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_TFLOPS, 'traffic': traffic,
+            'traffic_source': tsrc, 'algorithmic_bytes': B * (32 * 169 + 16 * 784) * 4 + 32 * 16 * 25 * 4, 'ms_per_launch': ms,
+            'note': 'algorithmic flops = 2 x 2.163 MMAC/image x %d images; exact fp32 on the matrix cores, priced against the '
+                    'dense fp32 MFMA peak (256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz)' % B}
 
 
 def run_integrator(a, w, dev, rank, n_gpus, dist, barrier):

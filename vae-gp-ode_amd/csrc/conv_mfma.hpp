@@ -77,7 +77,7 @@ template <class L, int NCS_> struct FwdPolicy {
     static constexpr int slab_taps = class_tap_offset(CLS);
     static __device__ __forceinline__ int tap_off(int t) { return -(t / ntx) * HP - t % ntx; }
     static __device__ __forceinline__ int pix_addr(int p) { return (qy0 + p / nx + PADL) * HP + qx0 + p % nx + PADL; }
-    static __device__ __forceinline__ int out_off(int p) {
+    static constexpr __host__ __device__ int out_off(int p) {
       return (L::S * (qy0 + p / nx) + py - L::P) * OH + L::S * (qx0 + p % nx) + px - L::P;
     }
   };
@@ -112,7 +112,7 @@ template <class L, int NCS_> struct BwdDataPolicy {
     static constexpr int ntaps = KK, ntx = L::K, npc = L::HI * L::HI, nx = L::HI, slab_taps = 0;
     static __device__ __forceinline__ int tap_off(int t) { return (t / L::K) * HP + t % L::K; }
     static __device__ __forceinline__ int pix_addr(int p) { return L::S * (p / nx) * HP + L::S * (p % nx); }
-    static __device__ __forceinline__ int out_off(int p) { return p; }
+    static constexpr __host__ __device__ int out_off(int p) { return p; }
   };
   // w[ci][co][ky][kx]: a pass over NCS input channels is one contiguous block
   static __device__ __forceinline__ size_t w_src(int e, int n0) { return (size_t)n0 * KC * KK + e; }
@@ -166,8 +166,10 @@ __device__ __forceinline__ void igemm_tile_mma(const float* __restrict__ s_img, 
 extern __shared__ __attribute__((aligned(16))) float igemm_smem[];
 
 // grid.x <= number of CUs; block NTHR.  TG: pixel tiles per job sharing the weight fragments (needs NCJ == NCS / 16);
-// NCJ: channel tiles per job.
-template <class PL, int IPB, int TG, int NCJ, int NTHR>
+// NCJ: channel tiles per job.  PAIR: process the px = 0 / px = 1 classes of a row parity together and store float2
+// (stride-2 layers with an even output width: without it every 64-byte line of y is written twice, half each time --
+// measured 401 MB of HBM writes for a 205 MB output).
+template <class PL, int IPB, int TG, int NCJ, bool PAIR, int NTHR>
 __global__ __launch_bounds__(NTHR) void k_conv_igemm(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y, int B) {
   constexpr int KC = PL::KC, NC = PL::NC, NCS = PL::NCS, NCLS = PL::NCLS, SH = PL::SH, OH = PL::OH, HP = PL::HP, PS = PL::PS;
@@ -254,52 +256,68 @@ __global__ __launch_bounds__(NTHR) void k_conv_igemm(const float* __restrict__ x
 
       // cost (k-steps) of all jobs of the group, and this wavefront's share [lo, hi) of it
       int wtot = 0;
-      static_for<NCLS>([&](auto c) {
-        using G = typename PL::template C<decltype(c)::value>;
-        wtot += ((nimg * G::npc + 15) / 16) * NJ * G::ntaps;
+      // class groups: a class on its own, or (PAIR) the two column-parity classes of one row parity, whose pixels
+      // interleave along x -- computing both for the same pixel tiles lets a lane store two neighbouring floats
+      constexpr int NCG = PAIR ? NCLS / 2 : NCLS;
+      static_for<NCG>([&](auto c) {
+        constexpr int c0 = PAIR ? 2 * decltype(c)::value : decltype(c)::value;
+        using G0 = typename PL::template C<c0>;
+        using G1 = typename PL::template C<PAIR ? c0 + 1 : c0>;
+        wtot += ((nimg * G0::npc + 15) / 16) * NJ * (G0::ntaps + (PAIR ? G1::ntaps : 0));
       });
       const int lo = (wtot * jw) / NW, hi = (wtot * (jw + 1)) / NW;
       int cbase = 0;
-      static_for<NCLS>([&](auto c) {
-        using G = typename PL::template C<decltype(c)::value>;
-        constexpr int ntaps = G::ntaps, npc = G::npc;
+      static_for<NCG>([&](auto c) {
+        constexpr int c0 = PAIR ? 2 * decltype(c)::value : decltype(c)::value;
+        using G = typename PL::template C<c0>;                       // px = 0 class of a pair (odd output columns)
+        using G1 = typename PL::template C<PAIR ? c0 + 1 : c0>;      // px = 1 class (even output columns)
+        static_assert(!PAIR || (G::npc == G1::npc && G::nx == G1::nx), "paired classes cover the same pixel grid");
+        static_assert(!PAIR || (G::out_off(0) == G1::out_off(0) + 1 && G::out_off(G::npc - 1) == G1::out_off(G::npc - 1) + 1 &&
+                                G1::out_off(0) % 2 == 0 && OH % 2 == 0), "paired classes write neighbouring, 8-byte aligned columns");
+        constexpr int ntaps = G::ntaps + (PAIR ? G1::ntaps : 0), npc = G::npc;
         const float* swc = s_w + G::slab_taps * KC * WROW;
+        const float* swc1 = s_w + G1::slab_taps * KC * WROW;
         const int mtot = nimg * npc;
         const int njobs = ((mtot + 15) / 16) * NJ;
-        // job u of this class belongs to the wavefront whose range holds its cost midpoint
+        // job u of this group belongs to the wavefront whose range holds its cost midpoint
         const int nlo = lo - cbase - ntaps / 2, nhi = hi - cbase - ntaps / 2;
         const int ub = min(njobs, nlo <= 0 ? 0 : (nlo + ntaps - 1) / ntaps), ue = min(njobs, nhi <= 0 ? 0 : (nhi + ntaps - 1) / ntaps);
         cbase += njobs * ntaps;
         for (int u0 = ub; u0 < ue; u0 += TG) {
           const int ng = min(TG, ue - u0);
           const int t0 = u0 / NJ, jc = u0 % NJ;      // NJ > 1 implies TG == 1
-          const float* sw = swc + jc * NCJ * 16;
           // B-operand base address of this lane's pixel in each tile (invalid rows alias pixel 0; masked at the store)
-          int abase[TG];
+          int abase[TG], abase1[TG];
 #pragma unroll
           for (int g = 0; g < TG; ++g) {
             int m = (t0 + g) * 16 + lr;
             m = (g < ng && m < mtot) ? m : 0;
             const int im = m / npc, p = m % npc;
             abase[g] = im * IMG + lk * PS + G::pix_addr(p);
+            abase1[g] = im * IMG + lk * PS + G1::pix_addr(p);
           }
-          f32x4 acc[TG][NCJ];
+          f32x4 acc[TG][NCJ], acc1[TG][NCJ];
 #pragma unroll
           for (int g = 0; g < TG; ++g)
 #pragma unroll
-            for (int cc = 0; cc < NCJ; ++cc) acc[g][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int cc = 0; cc < NCJ; ++cc) acc[g][cc] = acc1[g][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
           float bv[NCJ][4];                         // in flight during the MFMAs
 #pragma unroll
           for (int cc = 0; cc < NCJ; ++cc)
 #pragma unroll
             for (int r = 0; r < 4; ++r) bv[cc][r] = bias ? bias[n0 + (jc * NCJ + cc) * 16 + 4 * lk + r] : 0.f;
           PROBE_T(pt_mm);
-          switch (ng) {                              // wave-uniform
-            case 1: igemm_tile_mma<G, 1, TG, NCJ, KC, WROW, PS>(s_img, sw, abase, lk, lr, acc); break;
-            case 2: if constexpr (TG >= 2) igemm_tile_mma<G, 2, TG, NCJ, KC, WROW, PS>(s_img, sw, abase, lk, lr, acc); break;
-            case 3: if constexpr (TG >= 3) igemm_tile_mma<G, 3, TG, NCJ, KC, WROW, PS>(s_img, sw, abase, lk, lr, acc); break;
-            default: if constexpr (TG >= 4) igemm_tile_mma<G, 4, TG, NCJ, KC, WROW, PS>(s_img, sw, abase, lk, lr, acc); break;
-          }
+          auto run = [&](auto gtag, const float* sw, const int (&ab)[TG], f32x4 (&ac)[TG][NCJ]) {
+            using GG = typename decltype(gtag)::type;
+            switch (ng) {                            // wave-uniform
+              case 1: igemm_tile_mma<GG, 1, TG, NCJ, KC, WROW, PS>(s_img, sw, ab, lk, lr, ac); break;
+              case 2: if constexpr (TG >= 2) igemm_tile_mma<GG, 2, TG, NCJ, KC, WROW, PS>(s_img, sw, ab, lk, lr, ac); break;
+              case 3: if constexpr (TG >= 3) igemm_tile_mma<GG, 3, TG, NCJ, KC, WROW, PS>(s_img, sw, ab, lk, lr, ac); break;
+              default: if constexpr (TG >= 4) igemm_tile_mma<GG, 4, TG, NCJ, KC, WROW, PS>(s_img, sw, ab, lk, lr, ac); break;
+            }
+          };
+          run(std::common_type<G>{}, swc + jc * NCJ * 16, abase, acc);
+          if constexpr (PAIR) run(std::common_type<G1>{}, swc1 + jc * NCJ * 16, abase1, acc1);
           PROBE_ADD(3, pt_mm);
           PROBE_T(pt_st);
           // lane: pixel (t0+g)*16 + lr, channels (jc*NCJ + cc)*16 + 4 lk + r
@@ -309,12 +327,16 @@ __global__ __launch_bounds__(NTHR) void k_conv_igemm(const float* __restrict__ x
             if (g < ng && m < mtot) {
               const int im = m / npc, p = m % npc;
               const int ch0 = n0 + jc * NCJ * 16 + 4 * lk;
-              float* yp = y + ((size_t)(b0 + im) * NC + ch0) * (OH * OH) + G::out_off(p);
+              float* yp = y + ((size_t)(b0 + im) * NC + ch0) * (OH * OH) + (PAIR ? G1::out_off(p) : G::out_off(p));
 #pragma unroll
               for (int cc = 0; cc < NCJ; ++cc)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                  yp[(size_t)(cc * 16 + r) * (OH * OH)] = acc[g][cc][r] + bv[cc][r];
+                for (int r = 0; r < 4; ++r) {
+                  if constexpr (PAIR)   // even column from the px = 1 class, the odd one next to it from px = 0
+                    *reinterpret_cast<float2*>(yp + (size_t)(cc * 16 + r) * (OH * OH)) = float2{acc1[g][cc][r] + bv[cc][r], acc[g][cc][r] + bv[cc][r]};
+                  else
+                    yp[(size_t)(cc * 16 + r) * (OH * OH)] = acc[g][cc][r] + bv[cc][r];
+                }
             }
           }
           PROBE_ADD(4, pt_st);

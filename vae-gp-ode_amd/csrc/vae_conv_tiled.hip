@@ -382,12 +382,12 @@ static bool use_mfma() {
 }
 
 // matrix-core path (conv_mfma.hpp): persistent grid of one 512-thread workgroup per CU
-template <class PL, int IPB, int TG, int NCJ>
+template <class PL, int IPB, int TG, int NCJ, bool PAIR = false>
 static int launch_igemm(const float* x, const float* w, const float* bias, float* y, int B, hipStream_t st, const char* what) {
   constexpr int NTHR = 512;
   constexpr size_t lds = igemm_lds_bytes<PL, IPB>();
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto km = k_conv_igemm<PL, IPB, TG, NCJ, NTHR>;
+  auto km = k_conv_igemm<PL, IPB, TG, NCJ, PAIR, NTHR>;
   if (set_max_lds((const void*)km, lds)) return 1;
   const int ngroups = (B + IPB - 1) / IPB;
   hipLaunchKernelGGL(km, ngroups < 256 ? ngroups : 256, NTHR, lds, st, x, w, bias, y, B);
@@ -401,7 +401,9 @@ static int launch_T1(const float* x, const float* w, const float* bias, float* y
   const size_t lds = sizeof(float) * ((size_t)IPB * L::CI * L::HP * L::HP + (size_t)MAXTAPS * L::CI * L::CO);
   if (use_mfma() && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     constexpr int TG = COS >= 64 ? 1 : (COS >= 32 ? 2 : 4);
-    return launch_igemm<FwdPolicy<L, COS>, IPBM, TG, COS / 16>(x, w, bias, y, B, st, "convT_fwd_mfma");
+    // column-parity classes pair up when both cover the same pixel grid: stride 2, (HO + P) even
+    constexpr bool PAIR = L::S == 2 && (L::HO % 2 == 0) && (L::P % 2 == 1);
+    return launch_igemm<FwdPolicy<L, COS>, IPBM, TG, COS / 16, PAIR>(x, w, bias, y, B, st, "convT_fwd_mfma");
   }
   auto kern = k_convT_fwd<L, IPB>;
   if (set_max_lds((const void*)kern, lds)) return 1;
