@@ -19,6 +19,7 @@
 #include "gp_eval.hpp"
 #include "gp_launch.hpp"
 #include "gp_ws.hpp"
+#include "wave_reduce.hpp"
 
 namespace gp {
 
@@ -103,109 +104,118 @@ __global__ __launch_bounds__(64) void k_trinv_diag(const float* __restrict__ Dfa
 }
 
 // ---------------------------------------------------------------------------------------------
-// L^-1, one workgroup per block column k (forward substitution down the block rows)
+// L^-1 by divide and conquer on the block structure:  [A 0; B C]^-1 = [A^-1 0; -C^-1 B A^-1  C^-1].
+// Level l merges neighbouring super-blocks of s = 2^l blocks (32 s rows); every level is two batched tile GEMMs
+// (T = B A^-1, then X21 = -C^-1 T) over all pairs, so the whole inverse is 2 ceil(log2 nbn) launches of wide
+// grids instead of a forward substitution whose critical path is nbn^2 / 2 dependent tile products.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_linv_cols(const float* __restrict__ Lall, size_t batch_stride, int n, int np, int nbn,
-                                                    const float* __restrict__ Dinv_all, size_t dinv_stride,
-                                                    float* __restrict__ Linv_all) {
-  __shared__ float sA[NB][NB + 1], sB[NB][NB + 1];
-  const int k = blockIdx.x, b = blockIdx.y;
-  const float* Lm = Lall + (size_t)b * batch_stride;
-  const float* Dinv = Dinv_all + (size_t)b * dinv_stride;
-  float* Li = Linv_all + (size_t)b * batch_stride;
+__global__ __launch_bounds__(256) void k_linv_init(int np, const float* __restrict__ Dinv_all, size_t dinv_stride,
+                                                    float* __restrict__ Linv_all, size_t batch_stride) {
+  const int i = blockIdx.y, j = blockIdx.x, b = blockIdx.z;
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-  const int c0 = k * NB;
+  float* Li = Linv_all + (size_t)b * batch_stride;
+  const float* Dinv = Dinv_all + (size_t)b * dinv_stride + (size_t)i * NB * NB;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int r = ty + 8 * q;
-    for (int j = 0; j < k; ++j) Li[(size_t)(j * NB + r) * np + c0 + tx] = 0.f;  // above the diagonal block
-    Li[(size_t)(c0 + r) * np + c0 + tx] = Dinv[(size_t)k * NB * NB + r * NB + tx];
+    Li[(size_t)(i * NB + r) * np + j * NB + tx] = (i == j) ? Dinv[r * NB + tx] : 0.f;
   }
-  __threadfence_block();
-  __syncthreads();
-  for (int i = k + 1; i < nbn; ++i) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int j = k; j < i; ++j) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int r = ty + 8 * q;
-        sA[r][tx] = (i * NB + r < n) ? Lm[(size_t)(i * NB + r) * np + j * NB + tx] : 0.f;
-        sB[r][tx] = Li[(size_t)(j * NB + r) * np + c0 + tx];
-      }
-      __syncthreads();
-#pragma unroll 8
-      for (int p = 0; p < NB; ++p) {
-        const float bv = sB[p][tx];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = fmaf(sA[ty + 8 * q][p], bv, acc[q]);
-      }
-      __syncthreads();
-    }
+}
+
+// step 0: T[C,A] = L[C,A] Linv[A,A]      (Linv[A,A] lower triangular: k-blocks >= column block)
+// step 1: Linv[C,A] = -Linv[C,C] T[C,A]  (Linv[C,C] lower triangular: k-blocks <= row block)
+// grid (sb, sb, npairs * batch); A = blocks [2 sb pair, +sb), C = the following <= sb blocks
+__global__ __launch_bounds__(256) void k_linv_dc(int step, int sb, int npairs, int nbn, int n, int np, const float* __restrict__ Lall,
+                                                  float* __restrict__ Linv_all, float* __restrict__ T_all, size_t batch_stride) {
+  __shared__ float sA[NB][NB + 1], sB[NB][NB + 1];
+  const int pair = blockIdx.z % npairs, b = blockIdx.z / npairs;
+  const int a0 = 2 * sb * pair, c0 = a0 + sb;
+  if (c0 >= nbn) return;
+  const int cs = min(sb, nbn - c0), rb = blockIdx.y, cb = blockIdx.x;
+  if (rb >= cs) return;
+  const float* Lm = Lall + (size_t)b * batch_stride;
+  float* Li = Linv_all + (size_t)b * batch_stride;
+  float* T = T_all + (size_t)b * batch_stride;
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  const int row0 = (c0 + rb) * NB, col0 = (a0 + cb) * NB;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int k_lo = step == 0 ? cb : 0, k_hi = step == 0 ? sb : rb + 1;
+  for (int kb = k_lo; kb < k_hi; ++kb) {
+    const int kcol = (step == 0 ? a0 + kb : c0 + kb) * NB;           // P columns / Q rows
+    const float* P = step == 0 ? Lm : Li;
+    const float* Q = step == 0 ? Li : T;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = ty + 8 * q;
-      sB[r][tx] = acc[q];
-      sA[r][tx] = Dinv[(size_t)i * NB * NB + r * NB + tx];
+      sA[r][tx] = (step == 1 || row0 + r < n) ? P[(size_t)(row0 + r) * np + kcol + tx] : 0.f;   // rows >= n of L are not part of the factor
+      sB[r][tx] = Q[(size_t)(kcol + r) * np + col0 + tx];
     }
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = ty + 8 * q;
-      float v = 0.f;
 #pragma unroll 8
-      for (int p = 0; p < NB; ++p) v = fmaf(sA[r][p], sB[p][tx], v);
-      Li[(size_t)(i * NB + r) * np + c0 + tx] = -v;
+    for (int p = 0; p < NB; ++p) {
+      const float bv = sB[p][tx];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = fmaf(sA[ty + 8 * q][p], bv, acc[q]);
     }
-    __threadfence_block();
     __syncthreads();
   }
+  float* out = step == 0 ? T : Li;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) out[(size_t)(row0 + ty + 8 * q) * np + col0 + tx] = step == 0 ? acc[q] : -acc[q];
 }
 
 // ---------------------------------------------------------------------------------------------
 // vectors: q = L^-1 g_nu, a = L^-T q, v = L^-1 p (row n of the factor), r = u - v ; g_Um ; g_p rows
-//   vec layout per batch: [gnu | q | a | r | v | -] each np floats
+//   vec layout per batch: [gnu | q | a | r | v | -] each np floats.  One wavefront per output element.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_vecs(int kernel, int Do, int n, int np, const float* __restrict__ Lall,
-                                              size_t batch_stride, const float* __restrict__ Dfac_all, size_t dfac_stride,
-                                              const float* __restrict__ Linv_all, const float* __restrict__ u,
-                                              float* __restrict__ vec_all, float* __restrict__ g_Um, float* __restrict__ gp_rows) {
-  extern __shared__ float sm[];  // gnu[np], q[np]
-  float* sg = sm;
-  float* sq = sm + np;
-  const int b = blockIdx.x, tid = threadIdx.x;
+__global__ __launch_bounds__(256) void k_vec_q(int n, int np, const float* __restrict__ Linv_all, size_t batch_stride,
+                                               float* __restrict__ vec_all) {
+  const int b = blockIdx.y, nb = gridDim.y, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= np) return;
+  const float* Li = Linv_all + (size_t)b * batch_stride + (size_t)i * np;
+  const float* vg = vec_all + (size_t)(0 * nb + b) * np;
+  float acc = 0.f;
+  if (i < n)
+    for (int j = lane; j <= i; j += 64) acc = fmaf(Li[j], vg[j], acc);
+  const float in1[1] = {acc};
+  float out1[1];
+  wave_sum_multi<1>(in1, out1);
+  if (lane == 0) vec_all[(size_t)(1 * nb + b) * np + i] = out1[0];
+}
+
+__global__ __launch_bounds__(256) void k_vec_a(int kernel, int Do, int n, int np, const float* __restrict__ Lall, size_t batch_stride,
+                                               const float* __restrict__ Dfac_all, size_t dfac_stride, const float* __restrict__ Linv_all,
+                                               const float* __restrict__ u, float* __restrict__ vec_all, float* __restrict__ g_Um,
+                                               float* __restrict__ gp_rows) {
+  const int b = blockIdx.y, nb = gridDim.y, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= np) return;
   const float* Lm = Lall + (size_t)b * batch_stride;
   const float* Li = Linv_all + (size_t)b * batch_stride;
   const float* Dfac = Dfac_all + (size_t)b * dfac_stride;
-  const int nb = gridDim.x;
-  float* vec = vec_all;
-  float* vg = vec + (size_t)(0 * nb + b) * np;
-  float* vq = vec + (size_t)(1 * nb + b) * np;
-  float* va = vec + (size_t)(2 * nb + b) * np;
-  float* vr = vec + (size_t)(3 * nb + b) * np;
-  float* vv = vec + (size_t)(4 * nb + b) * np;
-  for (int j = tid; j < np; j += 256) sg[j] = vg[j];
-  __syncthreads();
-  for (int i = tid; i < np; i += 256) {
-    float acc = 0.f;
-    if (i < n) for (int j = 0; j <= i; ++j) acc = fmaf(Li[(size_t)i * np + j], sg[j], acc);
-    sq[i] = acc;
-    vq[i] = acc;
+  const float* vq = vec_all + (size_t)(1 * nb + b) * np;
+  float acc = 0.f;
+  if (j < n)
+    for (int i = j + lane; i < n; i += 64) acc = fmaf(Li[(size_t)i * np + j], vq[i], acc);
+  const float in1[1] = {acc};
+  float out1[1];
+  wave_sum_multi<1>(in1, out1);
+  if (lane != 0) return;
+  const float a = out1[0];
+  float y = 0.f, rr = 0.f;
+  if (j < n) {
+    const int kl = n / NB, cl = kl * NB;
+    const int u_stride = kernel == 0 ? Do : 1, u_b = kernel == 0 ? b : 0;
+    y = (j < cl) ? Lm[(size_t)n * np + j] : Dfac[(size_t)kl * NB * NB + (n - cl) * NB + (j - cl)];
+    rr = u[(size_t)j * u_stride + u_b] - y;
+    // g_u = q (u element j of batch b lives at u[j*u_stride + u_b]); g_p = -a in the same (M,Do) layout
+    g_Um[(size_t)j * u_stride + u_b] = vq[j];
+    gp_rows[(size_t)j * u_stride + u_b] = -a;
   }
-  __syncthreads();
-  const int kl = n / NB, cl = kl * NB;
-  const int u_stride = kernel == 0 ? Do : 1, u_b = kernel == 0 ? b : 0;
-  for (int j = tid; j < np; j += 256) {
-    float acc = 0.f, y = 0.f, rr = 0.f;
-    if (j < n) {
-      for (int i = j; i < n; ++i) acc = fmaf(Li[(size_t)i * np + j], sq[i], acc);
-      y = (j < cl) ? Lm[(size_t)n * np + j] : Dfac[(size_t)kl * NB * NB + (n - cl) * NB + (j - cl)];
-      rr = u[(size_t)j * u_stride + u_b] - y;
-      // g_u = q (u element j of batch b lives at u[j*u_stride + u_b]); g_p = -a in the same (M,Do) layout
-      g_Um[(size_t)j * u_stride + u_b] = sq[j];
-      gp_rows[(size_t)j * u_stride + u_b] = -acc;
-    }
-    va[j] = acc; vv[j] = y; vr[j] = rr;
-  }
+  vec_all[(size_t)(2 * nb + b) * np + j] = a;
+  vec_all[(size_t)(3 * nb + b) * np + j] = rr;
+  vec_all[(size_t)(4 * nb + b) * np + j] = y;
 }
 
 // g_Us[d, n(n+1)/2 + m] = g_u[n,d] eps_u[m,d]   (svpy.py:94-100 backward)
@@ -512,7 +522,8 @@ __global__ void k_df_gomega(int S, const float* __restrict__ pack, const float* 
     }
 }
 
-// DF step 2: one block.
+// DF step 2: chain rule to the raw parameters.  One workgroup per output scalar (D*D lengthscales, D variances),
+// threads over the summation index, fixed-order reduction; the remaining workgroups assemble g_Z.
 template <int D>
 __global__ __launch_bounds__(256) void k_chain_df(int M, int S, const float* __restrict__ pack, const float* __restrict__ gpack,
                                                    const float* __restrict__ raw_ell, const float* __restrict__ raw_var,
@@ -525,36 +536,55 @@ __global__ __launch_bounds__(256) void k_chain_df(int M, int S, const float* __r
   const size_t rff_f4 = (size_t)SJ * D * RQ * 64, ind_f4 = (size_t)MJ * RQ2 * 64;
   const float* gind = gpack + 4 * rff_f4;
   const float* guni = gpack + 4 * (rff_f4 + ind_f4);
-  const int tid = threadIdx.x;
-  for (int e = tid; e < D * D; e += 256) {
-    const int a = e / D, b = e % D;  // ell[a][b]; omega[k,s,i] = eps/ell[i][k] -> entry (a,b) <- omega[b,s,a]
+  const int tid = threadIdx.x, blk = blockIdx.x;
+  __shared__ float red[4];
+  auto block_sum = [&](float v) {                    // every thread gets the total
+    const float in1[1] = {v};
+    float out1[1];
+    wave_sum_multi<1>(in1, out1);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = out1[0];
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  if (blk < D * D) {
+    const int e = blk, a = e / D, b = e % D;         // ell[a][b]; omega[k,s,i] = eps/ell[i][k] -> entry (a,b) <- omega[b,s,a]
     const float l = softplus_l(raw_ell[e]);
     float g = 0.f;
-    for (int s = 0; s < S; ++s) {
+    for (int s = tid; s < S; s += 256) {
       const size_t base = (size_t)((s >> 6) * D + a) * RQ;                // record (s, i=a), field k=b
       const float om = rec_field(pack, base, s & 63, b) * GP_2PI;         // omega[b,s,a]
       g = fmaf(gom[(size_t)s * D * D + b * D + a], -om / l, g);
     }
-    const float l3 = l * l * l;
-    g = fmaf(guni[e], GP_LOG2E / l3, g);             // wab = -log2e/(2 l^2)
-    g = fmaf(guni[D * D + e], -2.f / l3, g);         // il2 = 1/l^2
-    for (int n = 0; n < M; ++n) g += kpart[(size_t)n * (D + D * D) + D + e];
-    g_raw_ell[e] = g * sigmoid_raw(raw_ell[e]);
-  }
-  for (int j = tid; j < D; j += 256) {
+    float k = 0.f;
+    for (int n = tid; n < M; n += 256) k += kpart[(size_t)n * (D + D * D) + D + e];
+    g = block_sum(g);
+    k = block_sum(k);
+    if (tid == 0) {
+      const float l3 = l * l * l;
+      g = fmaf(guni[e], GP_LOG2E / l3, g);           // wab = -log2e/(2 l^2)
+      g = fmaf(guni[D * D + e], -2.f / l3, g);       // il2 = 1/l^2
+      g_raw_ell[e] = (g + k) * sigmoid_raw(raw_ell[e]);
+    }
+  } else if (blk < D * D + D) {
+    const int j = blk - D * D;
     const float v = softplus_l(raw_var[j]);
-    float g = guni[2 * D * D + j];
-    for (int s = 0; s < S; ++s)
-      for (int i = 0; i < D; ++i) {
-        const size_t base = (size_t)((s >> 6) * D + i) * RQ;
-        g = fmaf(rec_field(gpack, base, s & 63, D + 3 + j), rec_field(pack, base, s & 63, D + 3 + j) / (2.f * v), g);  // bs = B sqrt(v/S)
-      }
-    for (int n = 0; n < M; ++n) g += kpart[(size_t)n * (D + D * D) + j];
-    g_raw_var[j] = g * sigmoid_raw(raw_var[j]);
-  }
-  for (int e = tid; e < M * D; e += 256) {
-    const int m = e / D, i = e % D;
-    g_Z[e] = rec_field(gind, (size_t)(m >> 6) * RQ2, m & 63, i) + vjpZ[e] + gZpart[e];
+    float g = 0.f;
+    for (int q = tid; q < S * D; q += 256) {
+      const int s = q / D, i = q % D;
+      const size_t base = (size_t)((s >> 6) * D + i) * RQ;
+      g = fmaf(rec_field(gpack, base, s & 63, D + 3 + j), rec_field(pack, base, s & 63, D + 3 + j) / (2.f * v), g);  // bs = B sqrt(v/S)
+    }
+    float k = 0.f;
+    for (int n = tid; n < M; n += 256) k += kpart[(size_t)n * (D + D * D) + j];
+    g = block_sum(g);
+    k = block_sum(k);
+    if (tid == 0) g_raw_var[j] = (guni[2 * D * D + j] + g + k) * sigmoid_raw(raw_var[j]);
+  } else {
+    for (int e = (blk - D * D - D) * 256 + tid; e < M * D; e += (gridDim.x - D * D - D) * 256) {
+      const int m = e / D, i = e % D;
+      g_Z[e] = rec_field(gind, (size_t)(m >> 6) * RQ2, m & 63, i) + vjpZ[e] + gZpart[e];
+    }
   }
 }
 
@@ -587,13 +617,15 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
 
   hipLaunchKernelGGL(k_gnu, dim3(cdiv(b.np, 128), b.batch), 128, 0, st, kernel, Di, Do, M, b.n, b.np, gpack_ind, ws + w.var, vec);
   hipLaunchKernelGGL(k_trinv_diag, dim3(b.nbn, b.batch), 64, 0, st, Dfac, dstride, b.n, bws + b.Dinv, dinv_stride);
-  hipLaunchKernelGGL(k_linv_cols, dim3(b.nbn, b.batch), 256, 0, st, Lmat, bstride, b.n, b.np, b.nbn, bws + b.Dinv, dinv_stride, bws + b.Linv);
-  {
-    const size_t lds = 2 * sizeof(float) * b.np;
-    if (set_max_lds((const void*)k_vecs, lds)) return 1;
-    hipLaunchKernelGGL(k_vecs, b.batch, 256, lds, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, bws + b.Linv,
-                       ws + w.u, vec, g_Um, bws + b.gp_rows);
+  hipLaunchKernelGGL(k_linv_init, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, b.np, bws + b.Dinv, dinv_stride, bws + b.Linv, bstride);
+  for (int sb = 1; sb < b.nbn; sb *= 2) {            // T lives in the X buffer (written by k_gemm_phiX only afterwards)
+    const int npairs = cdiv(b.nbn, 2 * sb);
+    hipLaunchKernelGGL(k_linv_dc, dim3(sb, sb, npairs * b.batch), 256, 0, st, 0, sb, npairs, b.nbn, b.n, b.np, Lmat, bws + b.Linv, bws + b.X, bstride);
+    hipLaunchKernelGGL(k_linv_dc, dim3(sb, sb, npairs * b.batch), 256, 0, st, 1, sb, npairs, b.nbn, b.n, b.np, Lmat, bws + b.Linv, bws + b.X, bstride);
   }
+  hipLaunchKernelGGL(k_vec_q, dim3(cdiv(b.np, 4), b.batch), 256, 0, st, b.n, b.np, bws + b.Linv, bstride, vec);
+  hipLaunchKernelGGL(k_vec_a, dim3(cdiv(b.np, 4), b.batch), 256, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, bws + b.Linv,
+                     ws + w.u, vec, g_Um, bws + b.gp_rows);
   if (check_launch("cache bwd: solves")) return 1;
   {
     const size_t P = (size_t)M * (M + 1) / 2 * Do;
@@ -619,7 +651,7 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
     hipLaunchKernelGGL(k_Kbwd_df<D_>, M, 64, 0, st, M, b.np, Z, ws + w.ell, ws + w.var, bws + b.S, bws + b.gZpart,         \
                        bws + b.kpart);                                                                                     \
     hipLaunchKernelGGL(k_df_gomega<D_>, cdiv(S, 64), 64, 0, st, S, pack, gpack, ws + w.var, bws + b.gom);                  \
-    hipLaunchKernelGGL(k_chain_df<D_>, 1, 256, 0, st, M, S, pack, gpack, raw_ell, raw_var, bws + b.gom, bws + b.vjpZ,      \
+    hipLaunchKernelGGL(k_chain_df<D_>, D_ * D_ + D_ + cdiv(M * D_, 256), 256, 0, st, M, S, pack, gpack, raw_ell, raw_var, bws + b.gom, bws + b.vjpZ,      \
                        bws + b.gZpart, bws + b.kpart, g_raw_ell, g_raw_var, g_Z);                                          \
     return check_launch("cache bwd: chain df");                                                                            \
   }
