@@ -41,7 +41,26 @@ template <class L> void runb(const char* name, int B) {
   }
   hipFree(gy); hipFree(w); hipFree(gx);
 }
+template <class L> void runw(const char* name, int B) {
+  using namespace gp;
+  float *x, *gy, *gw, *scr;
+  hipMalloc(&gy, sizeof(float) * B * L::CO * L::HO * L::HO); hipMalloc(&x, sizeof(float) * B * L::CI * L::HI * L::HI);
+  hipMalloc(&gw, sizeof(float) * L::CI * L::CO * L::K * L::K); hipMalloc(&scr, sizeof(float) * 300 * L::CI * L::CO * L::K * L::K);
+  hipMemset(gy, 0, sizeof(float) * B * L::CO * L::HO * L::HO); hipMemset(x, 0, sizeof(float) * B * L::CI * L::HI * L::HI);
+  for (int rep = 0; rep < 3; ++rep) {
+    unsigned long long z[8] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z));
+    tiled_bwd_weight(gy, x, gw, scr, B, L::CO, L::HO, L::HO, L::CI, L::K, L::S, L::P, L::HI, L::HI, 0);
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(z, HIP_SYMBOL(g_probe), sizeof(z));
+    if (rep == 2) printf("%s B=%d cycles: barrier %llu scatter %llu mma %llu total %llu\n", name, B, z[1], z[2], z[3], z[5]);
+  }
+  hipFree(gy); hipFree(x); hipFree(gw); hipFree(scr);
+}
 int main() {
+  runw<gp::Dec7>("dec7 wgrad", 4096);
+  runw<gp::Dec4>("dec4 wgrad", 4096);
+  runw<gp::Dec1>("dec1 wgrad", 4096);
   run<gp::Dec7>("dec7", 4096);
   run<gp::Dec4>("dec4", 4096);
   run<gp::Dec1>("dec1", 4096);

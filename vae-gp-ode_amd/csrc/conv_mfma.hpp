@@ -391,6 +391,7 @@ __global__ __launch_bounds__(NTHR) void k_convT_wgrad_mfma(const float* __restri
   const int wm = wave % WM, wn = (wave / WM) % WN, wt = wave / (WM * WN);
   const int ngroups = (B + IPB - 1) / IPB;
 
+  PROBE_T(pt_all);
   for (int e = tid; e < IPB * (IMGX + IMGG) / 4; e += NTHR) reinterpret_cast<float4*>(igemm_smem)[e] = float4{0.f, 0.f, 0.f, 0.f};
 
   // LDS offsets of this wavefront's taps (wave-uniform)
@@ -427,7 +428,10 @@ __global__ __launch_bounds__(NTHR) void k_convT_wgrad_mfma(const float* __restri
   if ((int)blockIdx.x < ngroups) prefetch(blockIdx.x);
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int nimg = min(IPB, B - grp * IPB);
+    PROBE_T(pt_b1);
     __syncthreads();                                 // previous group's MFMAs have read the planes; zero fill done
+    PROBE_ADD(1, pt_b1);
+    PROBE_T(pt_sc);
 #pragma unroll
     for (int i = 0; i < NLX; ++i) {
       const int f = tid + NTHR * i;
@@ -453,7 +457,9 @@ __global__ __launch_bounds__(NTHR) void k_convT_wgrad_mfma(const float* __restri
       }
     }
     __syncthreads();
+    PROBE_ADD(2, pt_sc);
     if (grp + (int)gridDim.x < ngroups) prefetch(grp + gridDim.x);
+    PROBE_T(pt_mm);
 
     // k loop over (image, 4-pixel step), operands of step s+1 in flight while the MFMAs of step s issue
     const int nsteps = nimg * NKS;
@@ -498,8 +504,10 @@ __global__ __launch_bounds__(NTHR) void k_convT_wgrad_mfma(const float* __restri
         mma(afA, bfA);
       }
     }
+    PROBE_ADD(3, pt_mm);
   }
-  // D[m = ci][n = co]: lane holds co = lr, ci = 4 lk + r of each tile
+  // D[m = ci][n = co]: lane holds co = lr, ci = 4 lk + r of each tile.  The partial sums leave in the accumulator
+  // layout part[blockIdx.x][tap][mt][nt][r][lane] (64 consecutive floats per store); k_sum_splits_wgrad undoes it.
   float* pp = part + (size_t)blockIdx.x * CI * CO * KK;
 #pragma unroll
   for (int j = 0; j < NTAPW; ++j) {
@@ -510,16 +518,42 @@ __global__ __launch_bounds__(NTHR) void k_convT_wgrad_mfma(const float* __restri
 #pragma unroll
         for (int b = 0; b < NTW; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int ci = (wm * MTW + a) * 16 + 4 * lk + r, co = (wn * NTW + b) * 16 + lr;
-            pp[((size_t)ci * CO + co) * KK + t] = acc[a][b][j][r];
-          }
+          for (int r = 0; r < 4; ++r)
+            pp[((((size_t)t * MT + wm * MTW + a) * NT + wn * NTW + b) * 4 + r) * 64 + lane] = acc[a][b][j][r];
     }
   }
+  PROBE_ADD(5, pt_all);
 }
 
 template <class L, int IPB> constexpr size_t wgrad_lds_bytes() {
   return sizeof(float) * (size_t)IPB * (WgradGeo<L>::IMGX + WgradGeo<L>::IMGG);
+}
+
+// gw[ci][co][tap] = sum_s part[s][tap][mt][nt][r][lane] (the accumulator layout of k_convT_wgrad_mfma), fixed order.
+// grid = ceil(n / 64), block = 1024 (64 elements x 16 split groups).
+__global__ __launch_bounds__(1024) void k_sum_splits_wgrad(const float* __restrict__ part, int nsplit, int MT, int NT, int KK,
+                                                            float* __restrict__ gw) {
+  __shared__ float red[16][64];
+  const int ex = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const size_t n = (size_t)KK * MT * NT * 256;
+  const size_t e = (size_t)blockIdx.x * 64 + ex;
+  float acc = 0.f;
+  if (e < n) {
+#pragma unroll 8
+    for (int s = sg; s < nsplit; s += 16) acc += part[(size_t)s * n + e];
+  }
+  red[sg][ex] = acc;
+  __syncthreads();
+  if (sg == 0 && e < n) {
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v += red[g][ex];
+    const int lane = (int)(e & 63), r = (int)(e >> 6) & 3;
+    const size_t tile = e >> 8;                      // (tap * MT + mt) * NT + nt
+    const int nt = (int)(tile % NT), mt = (int)((tile / NT) % MT), t = (int)(tile / ((size_t)NT * MT));
+    const int ci = mt * 16 + 4 * (lane >> 4) + r, co = nt * 16 + (lane & 15);
+    gw[((size_t)ci * (NT * 16) + co) * KK + t] = v;
+  }
 }
 
 // out[e] = sum_s part[s][e] in a fixed order: 16 interleaved partial sums per element, combined through LDS.

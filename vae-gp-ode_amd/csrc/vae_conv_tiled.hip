@@ -437,7 +437,7 @@ static int launch_T3(const float* x, const float* gy, float* gw, float* scratch,
     const int nwg = ngroups < 256 ? ngroups : 256;
     hipLaunchKernelGGL(km, nwg, 512, ldsm, st, x, gy, scratch, B);
     const size_t n = (size_t)L::CI * L::CO * L::K * L::K;
-    hipLaunchKernelGGL(k_sum_splits4, (unsigned)((n + 63) / 64), 1024, 0, st, scratch, nwg, n, gw);
+    hipLaunchKernelGGL(k_sum_splits_wgrad, (unsigned)((n + 63) / 64), 1024, 0, st, scratch, nwg, L::CI / 16, L::CO / 16, L::K * L::K, gw);
     return check_launch("convT_wgrad_mfma");
   }
   constexpr int NT = L::CI * (COW / 4), PSPLIT = 256 / NT, KK = L::K * L::K;
@@ -505,7 +505,7 @@ int tiled_fwd(const float* x, const float* w, const float* bias, float* y, int B
 int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch, int B, int Ci, int H, int W, int Co, int K, int S,
                      int P, int Ho, int Wo, hipStream_t st) {
   if (H != W || Ho != Wo) return -1;
-  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec7, 16, 1, 1, 1, 8, true>(gy, x, gw, scratch, B, st);
+  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec7, 16, 2, 1, 1, 8, true>(gy, x, gw, scratch, B, st);
   if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec4, 16, 2, 4, 2, 1, false>(gy, x, gw, scratch, B, st);
   if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec1, 32, 8, 2, 4, 1, true>(gy, x, gw, scratch, B, st);
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P) && use_mfma() &&
