@@ -65,10 +65,11 @@ def test_batchnorm_running_statistics():
     assert int(bn.num_batches_tracked) == 3
 
 
-@pytest.mark.parametrize('B', [3, 256])
+@pytest.mark.parametrize('B', [3, 256, 1030])   # >= 256 rows take the fan-out kernels of the decoder's fc layer
 def test_linear_act_loglik(B):
     from vae_gp_ode_amd import vae_ops as V
     check(V.linear, F.linear, (B, 6), (512, 6), (512,))
+    check(V.linear, F.linear, (B, 12), (192, 12), (192,))
     check(V.linear, F.linear, (B, 512), (12, 512), (12,))
     check(V.relu, F.relu, (B, 33))
     check(V.sigmoid, torch.sigmoid, (B, 33))

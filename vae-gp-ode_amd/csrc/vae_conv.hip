@@ -184,6 +184,60 @@ __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ 
   if (lane == 0) { if (i < In) gw[(size_t)o * In + i] = out1[0]; else if (gb) gb[o] = out1[0]; }
 }
 
+// ---- small fan-in (In <= 16, Out a multiple of 64): the decoder's fc layer (latent -> 512, vae.py:66) on all
+//      batch*T latent states.  Threads run along Out (coalesced rows of y / gy); the few weights per output live in
+//      registers.
+constexpr int LIN_MAXIN = 16;
+__global__ __launch_bounds__(256) void k_linear_fwd_fanout(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int B, int In, int Out,
+                                                            int rows_per_block) {
+  const int b0 = blockIdx.x * rows_per_block, b1 = min(B, b0 + rows_per_block);
+  for (int o = threadIdx.x; o < Out; o += 256) {
+    float wr[LIN_MAXIN];
+#pragma unroll
+    for (int i = 0; i < LIN_MAXIN; ++i) wr[i] = i < In ? w[(size_t)o * In + i] : 0.f;
+    const float bo = bias ? bias[o] : 0.f;
+    for (int b = b0; b < b1; ++b) {
+      const float* xr = x + (size_t)b * In;          // wave-uniform
+      float acc = bo;
+#pragma unroll
+      for (int i = 0; i < LIN_MAXIN; ++i)
+        if (i < In) acc = fmaf(xr[i], wr[i], acc);
+      y[(size_t)b * Out + o] = acc;
+    }
+  }
+}
+// gx[b][i] = sum_o gy[b][o] w[o][i]: one wavefront per row b, lanes along o
+template <int OPL>  // outputs per lane = Out / 64
+__global__ __launch_bounds__(256) void k_linear_bwd_x_fanout(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx,
+                                                              int B, int In) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = gridDim.x * 4;
+  constexpr int Out = OPL * 64;
+  float wr[OPL][LIN_MAXIN];
+#pragma unroll
+  for (int k = 0; k < OPL; ++k)
+#pragma unroll
+    for (int i = 0; i < LIN_MAXIN; ++i) wr[k][i] = i < In ? w[(size_t)(lane + 64 * k) * In + i] : 0.f;
+  for (int b = blockIdx.x * 4 + wave; b < B; b += nw) {
+    float acc[LIN_MAXIN];
+#pragma unroll
+    for (int i = 0; i < LIN_MAXIN; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < OPL; ++k) {
+      const float g = gy[(size_t)b * Out + lane + 64 * k];
+#pragma unroll
+      for (int i = 0; i < LIN_MAXIN; ++i) acc[i] = fmaf(g, wr[k][i], acc[i]);
+    }
+    float tot[LIN_MAXIN];
+    wave_sum_all<LIN_MAXIN>(acc, tot);
+    if (lane < In) {
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < LIN_MAXIN; ++i) v = (lane == i) ? tot[i] : v;
+      gx[(size_t)b * In + lane] = v;
+    }
+  }
+}
 // Bernoulli log-likelihood (vae.py:136-153, no epsilon -- SURVEY F9): ll = log(z) X + log(1-z) (1-X).
 // z has `reps` copies of X's extent (X.repeat([L,...])): X index = e % nX.
 __global__ void k_loglik_fwd(const float* __restrict__ X, const float* __restrict__ z, float* __restrict__ ll, size_t n, size_t nX) {
@@ -312,10 +366,27 @@ int act_bwd(const float* y, const float* gy, float* gx, size_t n, int mode, hipS
 }
 
 int linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, hipStream_t st) {
+  if (In <= LIN_MAXIN && Out % 64 == 0 && B >= 256) {
+    const int rows = 8;
+    hipLaunchKernelGGL(k_linear_fwd_fanout, (B + rows - 1) / rows, 256, 0, st, x, w, bias, y, B, In, Out, rows);
+    return check_launch("linear_fwd_fanout");
+  }
   hipLaunchKernelGGL(k_linear_fwd, (unsigned)(((size_t)B * Out + 255) / 256), 256, 0, st, x, w, bias, y, B, In, Out);
   return check_launch("linear_fwd");
 }
 int linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out, hipStream_t st) {
+  if (In <= LIN_MAXIN && Out % 64 == 0 && Out <= 512 && B >= 256) {
+    const int nb = B / 4 < 256 ? (B + 3) / 4 : 256;
+    if (gx) {
+      switch (Out / 64) {
+#define X(k) case k: hipLaunchKernelGGL(k_linear_bwd_x_fanout<k>, nb, 256, 0, st, gy, w, gx, B, In); break;
+        X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+#undef X
+      }
+    }
+    if (gw) hipLaunchKernelGGL(k_linear_bwd_w, (unsigned)(((size_t)Out * (In + 1) * 64 + 255) / 256), 256, 0, st, x, gy, gw, gb, B, In, Out);
+    return check_launch("linear_bwd_fanout");
+  }
   if (gx) hipLaunchKernelGGL(k_linear_bwd_x, (unsigned)(((size_t)B * In + 255) / 256), 256, 0, st, gy, w, gx, B, In, Out);
   if (gw) hipLaunchKernelGGL(k_linear_bwd_w, (unsigned)(((size_t)Out * (In + 1) * 64 + 255) / 256), 256, 0, st, x, gy, gw, gb, B, In, Out);
   return check_launch("linear_bwd");
