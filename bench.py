@@ -174,6 +174,7 @@ def main():
     ap.add_argument('--mode', default='elbo', choices=['elbo', 'integrator'])
     ap.add_argument('--seed', type=int, default=121)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-overlap', action='store_true', help='keep the GP cache build / cache backward on the main stream')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel of the step eagerly instead of replaying a captured HIP graph')
     a = ap.parse_args()
 
@@ -218,10 +219,14 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
     sync = GradAllReduce(opt.flat_grads, dist) if dist is not None else None
     last = {}
 
+    from vae_gp_ode_amd import ops
+    ops.set_overlap(not a.no_overlap)   # GP cache build / cache backward on a side stream, next to the encoder's kernels
+
     def fwd_bwd():
         opt.zero_grad()
         loss, nl, klr, klu = compute_loss(model, Xd, 1)
         loss.backward()
+        ops.join_side_stream()
         return loss
 
     def eager_step():
@@ -281,7 +286,7 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': w['desc'] + '; step = full ELBO training step (encoder, GP draw, rk4 rollout, decoder, ELBO, backward, Adam), L=1',
                    'global_batch': w['batch'] * n_gpus, 'solver': 'rk4 (3/8 rule)', 'parallelism': 'dp%d' % n_gpus,
-                   'hip_graph': graphed},
+                   'hip_graph': graphed, 'gp_side_stream': not a.no_overlap},
         'elbo_step_ms': el / a.steps * 1e3,
         'roofline': roof,
     }
@@ -379,7 +384,7 @@ def run_integrator(a, w, dev, rank, n_gpus, dist, barrier):
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': w['desc'] + '; step = GP draw (K_uu, Cholesky, nu) + rk4 rollout, L=1 [integrator fwd]',
                    'global_batch': w['batch'] * n_gpus, 'solver': 'rk4 (3/8 rule)', 'parallelism': 'dp%d' % n_gpus,
-                   'hip_graph': graphed},
+                   'hip_graph': graphed, 'gp_side_stream': not a.no_overlap},
         'roofline': {'bound': 'mfma', 'kernel': 'rollout_kernel', 'achieved': achieved, 'peak': PEAK_FP32_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS, 'traffic': None,
                      'ms_per_launch': roll_ms,

@@ -96,7 +96,10 @@ def test_graph_replay_equals_eager_steps():
     eps = torch.randn(16, 6, device='cuda')
     enc = m.vae.encoder
 
-    def run(use_graph):
+    from vae_gp_ode_amd import ops
+
+    def run(use_graph, overlap=False):
+        ops.set_overlap(overlap)
         m.load_state_dict(init)
         opt = HipAdam(m.parameters(), lr=1e-3)
 
@@ -117,8 +120,12 @@ def test_graph_replay_equals_eager_steps():
         assert int(opt.step_dev.item()) == 3
         return [p.detach().clone() for p in m.parameters()], [b.detach().clone() for b in m.buffers()]
     pe, be = run(False)
-    pg, bg = run(True)
-    for a, b in zip(pe, pg):
-        assert torch.equal(a, b)
-    for a, b in zip(be, bg):   # BatchNorm running statistics advance in the replayed steps too
-        assert torch.equal(a, b)
+    try:
+        for use_graph, overlap in ((True, False), (False, True), (True, True)):   # overlap: GP chains on the side stream
+            pg, bg = run(use_graph, overlap)
+            for a, b in zip(pe, pg):
+                assert torch.equal(a, b), (use_graph, overlap)
+            for a, b in zip(be, bg):   # BatchNorm running statistics advance in the replayed steps too
+                assert torch.equal(a, b), (use_graph, overlap)
+    finally:
+        ops.set_overlap(False)

@@ -29,6 +29,9 @@ class ODEGPVAE(nn.Module):
         if T_custom:
             T = T_custom
         enc = self.vae.encoder
+        gp = self.flow.odefunc.diffeq
+        if L == 1 and hasattr(gp, 'prebuild_cache'):
+            gp.prebuild_cache()                      # overlap mode only: the draw's cache builds next to the encoder
         s0_mu, s0_logv = enc(X[:, 0])
         z0 = enc.sample(mu=s0_mu, logvar=s0_logv)
         v0_mu = v0_logv = None

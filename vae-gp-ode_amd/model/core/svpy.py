@@ -74,6 +74,24 @@ class SVGP_Layer(torch.nn.Module):
         k._set_cache(self.cache, nz)
         return self.cache
 
+    def prebuild_cache(self):
+        """Overlap mode (ops.set_overlap): draw the noise now and build the cache on the side stream, so that the
+        Cholesky chain runs next to the encoder; Flow.forward picks it up with take_prebuilt_cache()."""
+        if not ops.overlap_enabled():
+            return
+        nz = self._take_noise()                     # drawn (and allocated) on the current stream
+        side = ops.fork_side_stream()
+        with ops.launch_on(side):
+            self._prebuilt = self.build_cache(noise=nz)
+
+    def take_prebuilt_cache(self):
+        cache = getattr(self, '_prebuilt', None)
+        if cache is None:
+            return None
+        self._prebuilt = None
+        torch.cuda.current_stream().wait_stream(ops.side_stream())
+        return cache
+
     def forward(self, x):
         """f(x) = f_prior(x) + K(x,Z) nu for the cached draw (svpy.py:123-142)."""
         if self.cache is None:

@@ -27,8 +27,73 @@ def _chk(t, name, shape=None):
     return t.contiguous()
 
 
+# ---------------------------------------------------------------------------------------------
+# Launch stream.  By default every kernel goes to torch's current stream.  In overlap mode (set_overlap(True)) the
+# two serial, few-workgroup chains of the GP -- the cache build (Cholesky of K_uu, forward) and the cache backward
+# (triangular inverse, chain rule to the raw parameters) -- are launched on a side stream, where they run next to
+# the encoder's forward / backward kernels instead of in front of them.  Memory is always allocated on the current
+# stream; buffers a side-stream kernel touches are kept referenced until join_side_stream().
+# ---------------------------------------------------------------------------------------------
+_launch_override = []          # stack of torch streams that _stream() returns instead of the current stream
+_overlap = {'on': False, 'side': None, 'pending': [], 'forked': False}
+
+
 def _stream():
+    if _launch_override:
+        return ctypes.c_void_p(_launch_override[-1].cuda_stream)
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class launch_on:
+    """Context: kernels of this package launch on ``stream`` (torch's current stream, and so allocation, unchanged)."""
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        _launch_override.append(self.stream)
+
+    def __exit__(self, *exc):
+        _launch_override.pop()
+
+
+def set_overlap(on):
+    """Run the GP cache build / cache backward on a side stream (see above).  Gradients of the GP parameters are then
+    completed by join_side_stream(), which the optimiser and the gradient all-reduce of this package call themselves."""
+    _overlap['on'] = bool(on)
+
+
+def overlap_enabled():
+    return _overlap['on']
+
+
+def side_stream():
+    if _overlap['side'] is None:
+        _overlap['side'] = torch.cuda.Stream()
+    return _overlap['side']
+
+
+def fork_side_stream():
+    """The side stream waits for everything queued so far on the current stream; returns it."""
+    side = side_stream()
+    side.wait_stream(torch.cuda.current_stream())
+    _overlap['forked'] = True
+    return side
+
+
+def join_side_stream():
+    """Current stream waits for the side stream; deferred parameter gradients are accumulated."""
+    if not _overlap['forked'] and not _overlap['pending']:
+        return
+    torch.cuda.current_stream().wait_stream(side_stream())
+    _overlap['forked'] = False
+    pend, _overlap['pending'] = _overlap['pending'], []
+    with torch.no_grad():
+        for params, grads, _keep in pend:
+            for p, g in zip(params, grads):
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.add_(g)
 
 
 def cache_sizes(kernel, Di, Do, M, S):
@@ -196,7 +261,10 @@ class _Flow(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z0, ts, raw_ell, raw_var, Z, Um, Us, gp, order, method):
-        cache = gp.build_cache()
+        cache = gp.take_prebuilt_cache() if hasattr(gp, 'take_prebuilt_cache') else None
+        if cache is None:
+            cache = gp.build_cache()
+        ctx.params = (raw_ell, raw_var, Z, Um, Us)
         need = any(ctx.needs_input_grad)
         if need:
             zt, xs = rollout(cache, z0, ts, order, method, save_stages=True)
@@ -212,6 +280,16 @@ class _Flow(torch.autograd.Function):
         c = ctx.cache
         gz0, ast = rollout_bwd(c, xs, gzt.contiguous(), ts, ctx.order, ctx.method)
         if not any(ctx.needs_input_grad[2:7]):
+            return (gz0,) + (None,) * 9
+        leaves = all(p.is_leaf and p.requires_grad for p in ctx.params) and all(ctx.needs_input_grad[2:7])
+        if _overlap['on'] and leaves:
+            # parameter gradients on the side stream, next to the encoder's backward; join_side_stream() adds them
+            side = fork_side_stream()
+            with launch_on(side):
+                gpack = param_grad(c, xs.reshape(-1, c.Di), ast.reshape(-1, c.Do))
+                g = cache_build_bwd(c, raw_ell, raw_var, Z, gpack)
+            grads = [g['raw_ell'], g['raw_var'], g['Z'], g['Um'], g['Us']]
+            _overlap['pending'].append((ctx.params, [gg.view_as(p) for gg, p in zip(grads, ctx.params)], (g, gpack, xs, ast, c)))
             return (gz0,) + (None,) * 9
         gpack = param_grad(c, xs.reshape(-1, c.Di), ast.reshape(-1, c.Do))
         g = cache_build_bwd(c, raw_ell, raw_var, Z, gpack)
@@ -238,4 +316,5 @@ def cache_build_bwd(cache, raw_ell, raw_var, Z, gpack):
               _ptr(_chk(raw_ell, 'raw_ell')), _ptr(_chk(raw_var, 'raw_var')), _ptr(_chk(Z, 'Z')), _ptr(c.noise['eps_u']),
               _ptr(c.pack), _ptr(c.ws), _ptr(gpack), _ptr(bws),
               _ptr(out['raw_ell']), _ptr(out['raw_var']), _ptr(out['Z']), _ptr(out['Um']), _ptr(out['Us']), _stream())
+    out['_workspace'] = bws   # referenced by the caller for as long as a side stream may still be writing it
     return out

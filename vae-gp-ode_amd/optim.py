@@ -5,6 +5,7 @@ import ctypes
 import torch
 
 from . import _lib
+from . import ops
 from .ops import _stream
 from .parallel import FlatGrads
 
@@ -43,6 +44,7 @@ class HipAdam:
         fg.zero()
 
     def step(self):
+        ops.join_side_stream()                       # overlap mode: deferred GP parameter gradients land in .grad here
         cur = [p.grad.data_ptr() for p in self.params]
         if cur != self._gptrs:  # a gradient tensor was replaced: refresh the table
             self._g = torch.tensor(cur, dtype=torch.int64, device=self._offs.device)

@@ -52,6 +52,9 @@ class GradAllReduce:
         self.avg = dist.get_backend() == 'nccl' and weight is None
 
     def all_reduce_grads(self):
+        if self.fg.flat.is_cuda:
+            from . import ops
+            ops.join_side_stream()                   # overlap mode: the GP parameter gradients must be in the bucket first
         if self.avg:
             self.dist.all_reduce(self.fg.flat, op=self.dist.ReduceOp.AVG)
         else:
