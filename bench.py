@@ -215,7 +215,7 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
     Xd = X.to(dev)
     # lr 1e-4: with the reference's lr = 1e-3 = initial diag(Us_sqrt), Adam's first step lands some diagonal entries
     # on exactly 0 under random-noise images (log 0 in the inducing KL); the update kernel does the same work.
-    opt = HipAdam(model.parameters(), lr=1e-4)
+    opt = HipAdam(model.parameters(), lr=1e-4, bucketed=dist is not None)   # one GPU: no gradient bucket to all-reduce
     sync = GradAllReduce(opt.flat_grads, dist) if dist is not None else None
     last = {}
 

@@ -98,10 +98,10 @@ def test_graph_replay_equals_eager_steps():
 
     from vae_gp_ode_amd import ops
 
-    def run(use_graph, overlap=False):
+    def run(use_graph, overlap=False, bucketed=True):
         ops.set_overlap(overlap)
         m.load_state_dict(init)
-        opt = HipAdam(m.parameters(), lr=1e-3)
+        opt = HipAdam(m.parameters(), lr=1e-3, bucketed=bucketed)
 
         def step():
             enc.next_eps = eps
@@ -121,11 +121,12 @@ def test_graph_replay_equals_eager_steps():
         return [p.detach().clone() for p in m.parameters()], [b.detach().clone() for b in m.buffers()]
     pe, be = run(False)
     try:
-        for use_graph, overlap in ((True, False), (False, True), (True, True)):   # overlap: GP chains on the side stream
-            pg, bg = run(use_graph, overlap)
+        # overlap: GP chains on the side stream; bucketed=False: gradients handed over by autograd, no flat bucket
+        for use_graph, overlap, bucketed in ((True, False, True), (False, True, True), (True, True, True), (False, False, False), (True, True, False)):
+            pg, bg = run(use_graph, overlap, bucketed)
             for a, b in zip(pe, pg):
-                assert torch.equal(a, b), (use_graph, overlap)
+                assert torch.equal(a, b), (use_graph, overlap, bucketed)
             for a, b in zip(be, bg):   # BatchNorm running statistics advance in the replayed steps too
-                assert torch.equal(a, b), (use_graph, overlap)
+                assert torch.equal(a, b), (use_graph, overlap, bucketed)
     finally:
         ops.set_overlap(False)

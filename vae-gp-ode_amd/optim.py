@@ -11,7 +11,11 @@ from .parallel import FlatGrads
 
 
 class HipAdam:
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, bucketed=True):
+        """bucketed=True: every ``.grad`` is a persistent view into one flat buffer (what the data-parallel all-reduce
+        needs); autograd then ADDS each produced gradient into it (one small kernel per parameter).  bucketed=False
+        (single GPU): ``zero_grad`` drops the gradients, autograd hands over the tensors the backward kernels wrote,
+        and the update reads them through a pointer table -- no zero fill, no per-parameter add."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params or not all(p.is_cuda and p.dtype == torch.float32 for p in self.params):
             raise _lib.GpodeError('HipAdam needs float32 CUDA/HIP parameters')
@@ -24,7 +28,9 @@ class HipAdam:
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         # persistent gradient storage: views into one flat bucket (all-reduced in place under data parallelism)
-        self.flat_grads = FlatGrads(self.params)
+        self.bucketed = bucketed
+        self.flat_grads = FlatGrads(self.params) if bucketed else None
+        self._zero = {}
         offs, tot = [], 0
         for p in self.params:
             offs.append(tot)
@@ -32,11 +38,17 @@ class HipAdam:
         self.total = tot
         tab = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)
         self._p, self._m, self._v = tab(self.params), tab(self.exp_avg), tab(self.exp_avg_sq)
-        self._g = tab([p.grad for p in self.params])
-        self._gptrs = [p.grad.data_ptr() for p in self.params]
+        # gradient pointer table: refreshed through a pinned staging buffer (an async copy, legal inside graph capture)
+        self._g = torch.zeros(len(self.params), dtype=torch.int64, device=dev)
+        self._g_host = torch.zeros(len(self.params), dtype=torch.int64).pin_memory()
+        self._gptrs = None
         self._offs = torch.tensor(offs, dtype=torch.int64, device=dev)
 
     def zero_grad(self):
+        if not self.bucketed:
+            for p in self.params:
+                p.grad = None
+            return
         fg = self.flat_grads
         for p, o in zip(fg.params, fg.offsets):
             if p.grad is None or p.grad.data_ptr() != fg.flat.data_ptr() + 4 * o:
@@ -45,9 +57,19 @@ class HipAdam:
 
     def step(self):
         ops.join_side_stream()                       # overlap mode: deferred GP parameter gradients land in .grad here
-        cur = [p.grad.data_ptr() for p in self.params]
+        cur = []
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is None:                            # parameter not reached by this backward
+                g = self._zero.get(i)
+                if g is None:
+                    g = self._zero[i] = torch.zeros_like(p)
+            elif not g.is_contiguous() or g.dtype != torch.float32:
+                raise _lib.GpodeError('HipAdam: gradients must be contiguous float32')
+            cur.append(g.data_ptr())
         if cur != self._gptrs:  # a gradient tensor was replaced: refresh the table
-            self._g = torch.tensor(cur, dtype=torch.int64, device=self._offs.device)
+            self._g_host.copy_(torch.tensor(cur, dtype=torch.int64))
+            self._g.copy_(self._g_host, non_blocking=True)
             self._gptrs = cur
         self.step_count += 1
         vp = lambda t: ctypes.c_void_p(t.data_ptr())
