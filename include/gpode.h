@@ -129,14 +129,15 @@ size_t gpode_conv_wgrad_scratch(int B, int Ci, int Co, int K);
 int gpode_conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci, int H, int W,
                             int Co, int K, int S, int P, int Ho, int Wo, void* stream);
 /* nn.BatchNorm2d in TRAINING mode (batch statistics), optional fused ReLU (vae.py:55-59,113-120).
- * running_* may be NULL (no update). */
+ * running_* may be NULL (no update).  gx_chansum (optional, C floats): per-channel sum of gx, i.e. the bias gradient of the
+ * convolution that feeds this BatchNorm, produced while gx is written instead of by a separate pass. */
 size_t gpode_bn_scratch(int B, int C);
 int gpode_bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
                  float* running_mean, float* running_var, float momentum, float eps, int B, int C, int HW, int relu,
                  float* scratch, void* stream);
 int gpode_bn_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
-                 const float* save_invstd, float* gx, float* ggamma, float* gbeta, int B, int C, int HW, int relu,
-                 float* scratch, void* stream);
+                 const float* save_invstd, float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW,
+                 int relu, float* scratch, void* stream);
 /* out[c] = sum_{b,hw} v[b,c,hw] (bias gradients); scratch: gpode_bn_scratch(B,C) floats. */
 int gpode_chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, void* stream);
 /* mode 0: ReLU, 1: sigmoid (vae.py:60,121).  Backward takes the forward OUTPUT y. */

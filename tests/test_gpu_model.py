@@ -86,3 +86,17 @@ def test_loss_and_gradients_match_reference(name, kw, L):
     for k, ref in gr.items():
         if k in errs:
             assert errs[k] < base + 3 * relerr(ref, sd64[k].grad), (k, errs[k])
+
+
+def test_bias_gradients_ride_on_the_batchnorm_backward():
+    """The per-channel sums of a BatchNorm backward's output are the bias gradient of the convolution in front of it;
+    they are produced while that output is written and handed to the convolution's backward (no separate pass).
+    Every BatchNorm of the model (2 encoder + 3 decoder layers) must deliver one."""
+    from vae_gp_ode_amd import vae_ops as V
+    from vae_gp_ode_amd.model.create_model import compute_loss
+    name, kw, L = CASES[0]
+    m, g = make_model(name, kw, L)
+    before = V.fused_bias_grads
+    loss, *_ = compute_loss(m, g['X'].cuda(), L)
+    loss.backward()
+    assert V.fused_bias_grads - before == 5

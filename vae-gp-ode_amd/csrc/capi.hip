@@ -138,11 +138,11 @@ int gpode_bn_fwd(const float* x, const float* gamma, const float* beta, float* y
   return gp::bn_fwd(x, gamma, beta, y, save_mean, save_invstd, running_mean, running_var, momentum, eps, B, C, HW, relu, scratch, GP_ST);
 }
 int gpode_bn_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
-                 const float* save_invstd, float* gx, float* ggamma, float* gbeta, int B, int C, int HW, int relu,
-                 float* scratch, void* stream) {
+                 const float* save_invstd, float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW,
+                 int relu, float* scratch, void* stream) {
   if (!x || !gy || !gamma || !beta || !save_mean || !save_invstd || !gx || !ggamma || !gbeta || !scratch)
     return gp::set_error("gpode_bn_bwd: null pointer");
-  return gp::bn_bwd(x, gy, gamma, beta, save_mean, save_invstd, gx, ggamma, gbeta, B, C, HW, relu, scratch, GP_ST);
+  return gp::bn_bwd(x, gy, gamma, beta, save_mean, save_invstd, gx, ggamma, gbeta, gx_chansum, B, C, HW, relu, scratch, GP_ST);
 }
 int gpode_chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, void* stream) {
   if (!v || !out || !scratch) return gp::set_error("gpode_chan_sum: null pointer");

@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                        const float* __restrict__ beta, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ part, int nsplit,
                                                        float count, float* __restrict__ ggamma, float* __restrict__ gbeta,
-                                                       float* __restrict__ gx, int B, int C, int HW, int bps, int relu) {
+                                                       float* __restrict__ gx, float* __restrict__ part_gx, int B, int C, int HW, int bps,
+                                                       int relu) {
   const int c = blockIdx.x, b0 = blockIdx.y * bps, nb = min(B, b0 + bps) - b0;
   const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
   float sa, sb;                                      // sum g, sum g * xhat over all splits: also the affine gradients
@@ -179,14 +180,24 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     if (relu && !(__fmaf_rn(xh, g, bt) > 0.f)) gv = 0.f;
     return sc * (gv - ca - xh * cb);
   };
+  float s0 = 0.f, t0 = 0.f;                          // channel sum of gx = the bias gradient of the layer that produced x
   chan_slab(C, HW, c, b0, nb,
             [&](size_t i) {
               const float4 v = *reinterpret_cast<const float4*>(x + i), w = *reinterpret_cast<const float4*>(gy + i);
               float4 o;
               o.x = one(v.x, w.x); o.y = one(v.y, w.y); o.z = one(v.z, w.z); o.w = one(v.w, w.w);
               *reinterpret_cast<float4*>(gx + i) = o;
+              s0 += o.x; t0 += o.y; s0 += o.z; t0 += o.w;
             },
-            [&](size_t i) { gx[i] = one(x[i], gy[i]); });
+            [&](size_t i) {
+              const float o = one(x[i], gy[i]);
+              gx[i] = o;
+              s0 += o;
+            });
+  if (part_gx) {
+    const float in2[2] = {s0 + t0, 0.f};
+    block_sum_store<2>(in2, part_gx + ((size_t)blockIdx.y * C + c) * 2);
+  }
 }
 
 // part[split][c] = {sum v, 0}
@@ -222,8 +233,8 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-// floats: part[64][C][2], (unused [C][2]), shift[C]
-size_t bn_scratch(int B, int C) { return (size_t)(B < 64 ? B : 64) * C * 2 + (size_t)C * 3; }
+// floats: part[64][C][2], (unused [C][2]), shift[C], part_gx[64][C][2]
+size_t bn_scratch(int B, int C) { return (size_t)(B < 64 ? B : 64) * C * 4 + (size_t)C * 3; }
 
 int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
            float* running_mean, float* running_var, float momentum, float eps, int B, int C, int HW, int relu,
@@ -239,13 +250,15 @@ int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, floa
 
 // the forward output is not needed: the ReLU mask is recomputed from x (same pinned arithmetic as k_bn_apply)
 int bn_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
-           const float* save_invstd, float* gx, float* ggamma, float* gbeta, int B, int C, int HW, int relu, float* scratch,
-           hipStream_t st) {
+           const float* save_invstd, float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW, int relu,
+           float* scratch, hipStream_t st) {
   if ((HW & 3) == 0 && !(aligned16(x) && aligned16(gy) && aligned16(gx))) return set_error("gpode_bn_bwd: x / gy / gx must be 16-byte aligned");
   const Split sp = pick(B);
   hipLaunchKernelGGL(k_bn_bwd_sums, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, save_mean, save_invstd, B, C, HW, sp.bps, relu, scratch);
+  float* part_gx = gx_chansum ? scratch + (size_t)sp.ns * C * 2 + (size_t)C * 3 : nullptr;
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, save_mean, save_invstd, scratch, sp.used, (float)B * HW,
-                     ggamma, gbeta, gx, B, C, HW, sp.bps, relu);
+                     ggamma, gbeta, gx, part_gx, B, C, HW, sp.bps, relu);
+  if (gx_chansum) hipLaunchKernelGGL(k_reduce_chan, C, 64, 0, st, part_gx, sp.used, C, gx_chansum);
   return check_launch("bn_bwd");
 }
 

@@ -24,6 +24,18 @@ def _bn_scratch(B, C, like):
     return _scratch(_lib.load().gpode_bn_scratch(B, C), like)
 
 
+fused_bias_grads = 0   # how many bias gradients arrived ready-made from a BatchNorm backward (see _BatchNormTrain.backward)
+
+
+def _fused_chansum(gy, C):
+    global fused_bias_grads
+    cs = getattr(gy, '_gpode_chansum', None)
+    if cs is None or tuple(cs.shape) != (C,):
+        return None
+    fused_bias_grads += 1
+    return cs
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad):
@@ -48,9 +60,12 @@ class _Conv2d(torch.autograd.Function):
             _lib.call('gpode_conv2d_bwd_data', _ptr(gy), _ptr(w), _ptr(None), _ptr(gx), B, Ci, H, W, Co, K, S, P, Ho, Wo, _stream())
         if ctx.needs_input_grad[1]:
             gw = _new(w.shape, x)
-            gb = _new((Co,), x) if has_b else None
+            pre = _fused_chansum(gy, Co) if has_b else None     # bias gradient already produced by the BatchNorm backward
+            gb = _new((Co,), x) if (has_b and pre is None) else None
             _lib.call('gpode_conv2d_bwd_weight', _ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), _ptr(_wgrad_scratch(B, Ci, Co, K, x)),
                       B, Ci, H, W, Co, K, S, P, Ho, Wo, _stream())
+            if pre is not None:
+                gb = pre
         return gx, gw, gb, None, None
 
 
@@ -84,8 +99,10 @@ class _ConvT2d(torch.autograd.Function):
             _lib.call('gpode_conv2d_bwd_weight', _ptr(gy), _ptr(x), _ptr(gw), _ptr(None), _ptr(_wgrad_scratch(B, Cout, Cin, K, x)),
                       B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, _stream())
             if has_b:
-                gb = _new((Cout,), x)
-                _lib.call('gpode_chan_sum', _ptr(gy), _ptr(gb), B, Cout, Ht * Wt, _ptr(_bn_scratch(B, Cout, x)), _stream())
+                gb = _fused_chansum(gy, Cout)
+                if gb is None:
+                    gb = _new((Cout,), x)
+                    _lib.call('gpode_chan_sum', _ptr(gy), _ptr(gb), B, Cout, Ht * Wt, _ptr(_bn_scratch(B, Cout, x)), _stream())
         return gx, gw, gb, None, None, None
 
 
@@ -109,9 +126,11 @@ class _BatchNormTrain(torch.autograd.Function):
         x, gamma, beta, mean, invstd = ctx.saved_tensors
         B, C = x.shape[0], x.shape[1]
         HW = x[0, 0].numel()
-        gx, gg, gb = _new(x.shape, x), _new((C,), x), _new((C,), x)
+        gx, gg, gb, cs = _new(x.shape, x), _new((C,), x), _new((C,), x), _new((C,), x)
         _lib.call('gpode_bn_bwd', _ptr(x), _ptr(gy.contiguous()), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(gx), _ptr(gg),
-                  _ptr(gb), B, C, HW, ctx.relu, _ptr(_bn_scratch(B, C, x)), _stream())
+                  _ptr(gb), _ptr(cs), B, C, HW, ctx.relu, _ptr(_bn_scratch(B, C, x)), _stream())
+        # the channel sums of gx ride along with it: the convolution that produced x needs exactly these as its bias gradient
+        gx._gpode_chansum = cs
         return gx, gg, gb, None, None, None, None, None
 
 
