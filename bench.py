@@ -183,16 +183,25 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    # GPODE_BENCH_REHEARSE=1: all ranks share the visible card(s) and talk over gloo -- a rehearsal of the N > 1 code path
+    # (sharded minibatch, gradient bucket, all-reduce between graph replays) on a one-GPU box; not a measurement
+    rehearse = os.environ.get('GPODE_BENCH_REHEARSE') == '1'
+    if rehearse:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if rehearse:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
     n_gpus = world
     w = WORKLOADS[a.workload]
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()

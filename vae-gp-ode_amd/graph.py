@@ -25,7 +25,9 @@ class GraphedStep:
         for g in generators:
             if g is not None:
                 self.graph.register_generator_state(g)
-        with torch.cuda.graph(self.graph):
+        # thread_local: other threads of the process (e.g. the RCCL watchdog polling its events) may keep calling the
+        # runtime while this thread captures
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.out = step_fn()
         self.eager_steps = warmup
 
