@@ -138,6 +138,10 @@ int gpode_bn_fwd(const float* x, const float* gamma, const float* beta, float* y
 int gpode_bn_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
                  const float* save_invstd, float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW,
                  int relu, float* scratch, void* stream);
+/* nn.BatchNorm2d in EVALUATION mode (running statistics; main.py:157-163 puts the pre-trained VAE in eval()).
+ * gy == NULL: out = y = relu?(affine(x)); gy != NULL: out = d/dx (frozen layer: no affine gradients). */
+int gpode_bn_eval(const float* x, const float* gy, const float* gamma, const float* beta, const float* running_mean,
+                  const float* running_var, float eps, float* out, int B, int C, int HW, int relu, void* stream);
 /* out[c] = sum_{b,hw} v[b,c,hw] (bias gradients); scratch: gpode_bn_scratch(B,C) floats. */
 int gpode_chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, void* stream);
 /* mode 0: ReLU, 1: sigmoid (vae.py:60,121).  Backward takes the forward OUTPUT y. */

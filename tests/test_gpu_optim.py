@@ -68,6 +68,20 @@ def test_main_training_loop_runs(tmp_path, monkeypatch):
     assert 'flow.odefunc.diffeq.Us_sqrt.optvar' in sd and all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
     rel = os.path.relpath(os.path.dirname(ck[0]), tmp_path)
     M.main(common + ['--Nepoch', '1', '--save', 'results/u', '--continue_training', 'True', '--model_path', rel])
+    # --pretrained (main.py:157-170): VAE weights from encoder.pt / decoder.pt, frozen, BatchNorm on running statistics;
+    # only the GP parameters train
+    from vae_gp_ode_amd.model.create_model import build_model
+    args = M.make_parser().parse_args(common)
+    args.device = 'cuda'
+    vae = build_model(args).cuda().vae
+    os.makedirs(tmp_path / 'vae', exist_ok=True)
+    vae.save(str(tmp_path / 'vae' / 'encoder.pt'), str(tmp_path / 'vae' / 'decoder.pt'))
+    M.main(common + ['--Nepoch', '1', '--save', 'results/p', '--pretrained', 'True', '--vae_path', str(tmp_path / 'vae')])
+    ck = glob.glob(str(tmp_path / 'results' / 'p_*' / 'odegpvae_mnist.pth'))
+    sd = torch.load(ck[0])
+    ref = torch.load(tmp_path / 'vae' / 'decoder.pt')
+    assert torch.equal(sd['vae.decoder.decnn.7.weight'].cpu(), ref['decnn.7.weight'].cpu())            # frozen
+    assert torch.equal(sd['vae.decoder.decnn.8.running_mean'].cpu(), ref['decnn.8.running_mean'].cpu())  # eval mode: untouched
 
 
 def test_graph_replay_equals_eager_steps():

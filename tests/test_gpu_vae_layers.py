@@ -53,6 +53,26 @@ def test_batchnorm_train_relu(shape):
           lambda x, g, b: F.relu(F.batch_norm(x, None, None, g, b, True, 0.1, 1e-5)), shape, (C,), (C,))
 
 
+@pytest.mark.parametrize('shape,relu', [((4, 8, 14, 14), 1), ((130, 32, 13, 13), 1), ((65, 16, 28, 28), 0)])
+def test_batchnorm_eval_mode(shape, relu):
+    """module.eval(): running statistics; output and input gradient against torch (frozen affine parameters)."""
+    from vae_gp_ode_amd import vae_ops as V
+    C = shape[1]
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(shape, generator=g) * 1.5 + 0.3
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    rm, rv = torch.randn(C, generator=g) * 0.3, torch.rand(C, generator=g) + 0.4
+    gy = torch.randn(shape, generator=g)
+    xr = x.double().requires_grad_(True)
+    yr = F.batch_norm(xr, rm.double(), rv.double(), gam.double(), bet.double(), False, 0.1, 1e-5)
+    yr = F.relu(yr) if relu else yr
+    yr.backward(gy.double())
+    xg = x.cuda().requires_grad_(True)
+    y = V._BatchNormEval.apply(xg, gam.cuda(), bet.cuda(), rm.cuda(), rv.cuda(), 1e-5, relu)
+    y.backward(gy.cuda())
+    assert relerr(y, yr) < 1e-5 and relerr(xg.grad, xr.grad) < 1e-5
+
+
 def test_batchnorm_running_statistics():
     from vae_gp_ode_amd import vae_ops as V
     bn = torch.nn.BatchNorm2d(16).cuda()

@@ -144,6 +144,11 @@ int gpode_bn_bwd(const float* x, const float* gy, const float* gamma, const floa
     return gp::set_error("gpode_bn_bwd: null pointer");
   return gp::bn_bwd(x, gy, gamma, beta, save_mean, save_invstd, gx, ggamma, gbeta, gx_chansum, B, C, HW, relu, scratch, GP_ST);
 }
+int gpode_bn_eval(const float* x, const float* gy, const float* gamma, const float* beta, const float* running_mean,
+                  const float* running_var, float eps, float* out, int B, int C, int HW, int relu, void* stream) {
+  if (!x || !gamma || !beta || !running_mean || !running_var || !out) return gp::set_error("gpode_bn_eval: null pointer");
+  return gp::bn_eval(x, gy, gamma, beta, running_mean, running_var, eps, out, B, C, HW, relu, GP_ST);
+}
 int gpode_chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, void* stream) {
   if (!v || !out || !scratch) return gp::set_error("gpode_chan_sum: null pointer");
   return gp::chan_sum(v, out, B, C, HW, scratch, GP_ST);

@@ -82,6 +82,8 @@ int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, floa
            float* scratch, hipStream_t st);
 int bn_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
            float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW, int relu, float* scratch, hipStream_t st);
+int bn_eval(const float* x, const float* gy, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+            float eps, float* out, int B, int C, int HW, int relu, hipStream_t st);
 int chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, hipStream_t st);
 int act_fwd(const float* x, float* y, size_t n, int mode, hipStream_t st);
 int act_bwd(const float* y, const float* gy, float* gx, size_t n, int mode, hipStream_t st);

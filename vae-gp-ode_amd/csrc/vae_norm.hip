@@ -200,6 +200,31 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   }
 }
 
+// evaluation mode (module.eval(): the --pretrained path of main.py:157-163 freezes the VAE this way): running statistics,
+// y = relu?((x - rm) rsqrt(rv + eps) gamma + beta); backward w.r.t. x only (gx = g gamma invstd under the same mask)
+__global__ __launch_bounds__(256) void k_bn_eval(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, const float* __restrict__ rmean,
+                                                  const float* __restrict__ rvar, float eps, float* __restrict__ out, int B, int C, int HW,
+                                                  int bps, int relu) {
+  const int c = blockIdx.x, b0 = blockIdx.y * bps, nb = min(B, b0 + bps) - b0;
+  const float m = rmean[c], is = rsqrtf(rvar[c] + eps), g = gamma[c], bt = beta[c];
+  const float lo = relu ? 0.f : -INFINITY, sc = g * is;
+  auto one = [&](float xv, float gv) {
+    const float v = bn_affine(xv, m, is, g, bt);
+    if (!gy) return fmaxf(v, lo);
+    return (relu && !(v > 0.f)) ? 0.f : sc * gv;
+  };
+  chan_slab(C, HW, c, b0, nb,
+            [&](size_t i) {
+              const float4 v = *reinterpret_cast<const float4*>(x + i);
+              const float4 w = gy ? *reinterpret_cast<const float4*>(gy + i) : float4{0.f, 0.f, 0.f, 0.f};
+              float4 o;
+              o.x = one(v.x, w.x); o.y = one(v.y, w.y); o.z = one(v.z, w.z); o.w = one(v.w, w.w);
+              *reinterpret_cast<float4*>(out + i) = o;
+            },
+            [&](size_t i) { out[i] = one(x[i], gy ? gy[i] : 0.f); });
+}
+
 // part[split][c] = {sum v, 0}
 __global__ __launch_bounds__(256) void k_chan_sum(const float* __restrict__ v, int B, int C, int HW, int bps, float* __restrict__ part) {
   const int c = blockIdx.x, b0 = blockIdx.y * bps, nb = min(B, b0 + bps) - b0;
@@ -260,6 +285,15 @@ int bn_bwd(const float* x, const float* gy, const float* gamma, const float* bet
                      ggamma, gbeta, gx, part_gx, B, C, HW, sp.bps, relu);
   if (gx_chansum) hipLaunchKernelGGL(k_reduce_chan, C, 64, 0, st, part_gx, sp.used, C, gx_chansum);
   return check_launch("bn_bwd");
+}
+
+// gy == nullptr: forward (out = y); otherwise out = gx
+int bn_eval(const float* x, const float* gy, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+            float eps, float* out, int B, int C, int HW, int relu, hipStream_t st) {
+  if ((HW & 3) == 0 && !(aligned16(x) && aligned16(out) && (!gy || aligned16(gy)))) return set_error("gpode_bn_eval: tensors must be 16-byte aligned");
+  const Split sp = pick(B);
+  hipLaunchKernelGGL(k_bn_eval, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, running_mean, running_var, eps, out, B, C, HW, sp.bps, relu);
+  return check_launch("bn_eval");
 }
 
 // out[c] = sum over (b, hw) of v[b,c,hw]   (bias gradient of ConvTranspose2d / Conv2d)

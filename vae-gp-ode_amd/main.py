@@ -129,8 +129,14 @@ def main(argv=None):
     model = build_model(args).to(args.device)
     model = initialize_and_fix_kernel_parameters(model, lengthscale_value=args.lengthscale, variance_value=args.variance, fix=False)
     logger.info(model)
-    if args.pretrained:
-        raise NotImplementedError('--pretrained freezes the VAE in eval mode; eval-mode BatchNorm is not built (DESIGN.md)')
+    if args.pretrained:     # main.py:157-170: load the pre-trained VAE, freeze it, encoder / decoder in eval mode
+        model.vae.encoder.load_state_dict(torch.load(args.vae_path + '/encoder.pt', map_location=args.device))
+        model.vae.decoder.load_state_dict(torch.load(args.vae_path + '/decoder.pt', map_location=args.device))
+        for var in model.vae.parameters():
+            var.requires_grad = False
+        model.vae.encoder.eval()
+        model.vae.decoder.eval()
+        logger.info('***** Loaded pretrained VAE from {} ********'.format(args.vae_path))
     logger.info('********** Model Built {} ODE **********'.format(args.ode))
     if args.continue_training:
         fname = os.path.join(os.path.abspath(os.getcwd()), args.model_path, 'odegpvae_mnist.pth')

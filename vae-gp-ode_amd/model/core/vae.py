@@ -18,9 +18,8 @@ from ... import vae_ops as V
 
 
 def _bn(x, bn, relu):
-    if not bn.training:
-        raise NotImplementedError('eval-mode BatchNorm is outside the accelerated path (the reference trains and '
-                                  'evaluates with batch statistics, SURVEY F11)')
+    if not bn.training:     # module.eval(): the frozen pre-trained VAE of main.py:157-163, VAE.test
+        return V.batch_norm_eval(x, bn, relu)
     return V.batch_norm_train(x, bn, relu)
 
 EPSILON = 1e-3

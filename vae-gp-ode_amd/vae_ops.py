@@ -134,6 +134,34 @@ class _BatchNormTrain(torch.autograd.Function):
         return gx, gg, gb, None, None, None, None, None
 
 
+class _BatchNormEval(torch.autograd.Function):
+    """nn.BatchNorm2d under module.eval(): running statistics, gradient w.r.t. the input only."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, relu):
+        x = _chk(x, 'x')
+        B, C = x.shape[0], x.shape[1]
+        HW = x[0, 0].numel()
+        y = _new(x.shape, x)
+        _lib.call('gpode_bn_eval', _ptr(x), _ptr(None), _ptr(_chk(gamma, 'gamma')), _ptr(_chk(beta, 'beta')), _ptr(running_mean),
+                  _ptr(running_var), ctypes.c_float(eps), _ptr(y), B, C, HW, int(relu), _stream())
+        ctx.save_for_backward(x, gamma, beta, running_mean, running_var)
+        ctx.eps, ctx.relu = eps, int(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise _lib.GpodeError('eval-mode BatchNorm is built for frozen layers (main.py:160-161 sets requires_grad=False)')
+        x, gamma, beta, rm, rv = ctx.saved_tensors
+        B, C = x.shape[0], x.shape[1]
+        HW = x[0, 0].numel()
+        gx = _new(x.shape, x)
+        _lib.call('gpode_bn_eval', _ptr(x), _ptr(gy.contiguous()), _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), ctypes.c_float(ctx.eps),
+                  _ptr(gx), B, C, HW, ctx.relu, _stream())
+        return gx, None, None, None, None, None, None
+
+
 class _Act(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mode):
@@ -228,6 +256,11 @@ def batch_norm_train(x, bn, relu):
     y = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean if bn.training else None,
                               bn.running_var if bn.training else None, bn.momentum, bn.eps, relu)
     return y
+
+
+def batch_norm_eval(x, bn, relu):
+    """nn.BatchNorm2d in evaluation mode on the module's running statistics."""
+    return _BatchNormEval.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu)
 
 
 def relu(x):
