@@ -16,7 +16,7 @@
  *
  *  kernel: 0 = RBF dimwise  (kernels.py:29-195),  1 = divergence-free (kernels.py:201-393, Di==Do)
  *  order : 1 | 2            (flow.py:27-45)
- *  method: 0 = euler, 1 = rk4 (torchdiffeq fixed-grid 3/8 rule; flow.py:76-85)
+ *  method: 0 = euler, 1 = rk4 (torchdiffeq fixed-grid 3/8 rule; flow.py:76-85), 2 = midpoint (y1 = y + dt f(y + dt/2 f(y)))
  */
 #ifndef GPODE_H
 #define GPODE_H

@@ -258,6 +258,7 @@ def odeint_fixed(f, y0, ts, method):
     y1 = y0 + dt*f(y0).  'rk4' = 3/8 rule (torchdiffeq rk4_alt_step_func):
       k1=f(y0); k2=f(y0+dt*k1/3); k3=f(y0+dt*(k2-k1/3)); k4=f(y0+dt*(k1-k2+k3));
       y1 = y0 + (k1+3*(k2+k3)+k4)*dt*0.125.
+    'midpoint': y1 = y0 + dt*f(y0 + dt/2*f(y0)).
     NOT pinned by reference code (torchdiffeq absent)."""
     ys = [y0]
     y = y0
@@ -272,6 +273,8 @@ def odeint_fixed(f, y0, ts, method):
             k3 = f(y + dt * (k2 - k1 * third))
             k4 = f(y + dt * (k1 - k2 + k3))
             dy = (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
+        elif method == 'midpoint':       # torchdiffeq Midpoint._step_func: dt * f(t0 + dt/2, y0 + f(t0, y0) * dt/2)
+            dy = dt * f(y + k1 * (0.5 * dt))
         else:
             raise ValueError(method)
         y = y + dy

@@ -140,3 +140,32 @@ def test_flow_autograd_matches_reference(name, kernel, order, method):
         assert err < tol, (short, err, tol)
     assert relerr(z0.grad, gr['z0']) < 5e-4 + 3 * relerr(gr['z0'], z64.grad)
     print(name, method, {k: '%.1e/%.1e' % v for k, v in worst.items()})
+
+
+@pytest.mark.parametrize('name,kernel,order', GP_CASES[:3])
+def test_midpoint_solver_forward_and_backward(name, kernel, order):
+    """'midpoint' (flow.py:76-85 hands the solver name to torchdiffeq; fixed-grid y1 = y + dt f(y + dt/2 f(y))).
+    No reference fixture holds it (the integrator is restated), so the check is against the oracle:
+    |hip - oracle32| <= base + 3 |oracle32 - oracle64| for the trajectory and every gradient."""
+    g = load_golden(name)
+    method = 'midpoint'
+    flow, gp = make_layer(g, kernel, order, method)
+    z0 = g['z0'].cuda().requires_grad_(True)
+    zt = flow(z0, g['ts'].cuda())
+    (zt * g['gw'].cuda()).sum().backward()
+    assert int(flow.num_evals()) == 2 * (g['ts'].shape[0] - 1)
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        p = {k: v.to(dt).clone().requires_grad_(True) for k, v in O.gp_params_from_state_dict(sub(g, 'sd.')).items()}
+        c = O.build_cache(p, O.to_dtype(sub(g, 'noise.'), dt), kernel)
+        z = g['z0'].to(dt).clone().requires_grad_(True)
+        out = O.flow_forward(z, g['ts'].to(dt), c, order, method)
+        (out * g['gw'].to(dt)).sum().backward()
+        res[dt] = dict({k: v.grad for k, v in p.items()}, z0=z.grad, zt=out.detach())
+    r32, r64 = res[torch.float32], res[torch.float64]
+    assert relerr(zt, r32['zt']) < 1e-4 + 3 * relerr(r32['zt'], r64['zt'])
+    got = {'raw_ell': gp.kern.unconstrained_lengthscales.grad, 'raw_var': gp.kern.unconstrained_variance.grad,
+           'Z': gp.inducing_loc.optvar.grad, 'Um': gp.Um.optvar.grad, 'Us': gp.Us_sqrt.optvar.grad, 'z0': z0.grad}
+    for k, v in got.items():
+        tol = 1e-3 + 3 * relerr(r32[k], r64[k])
+        assert relerr(v, r32[k]) < tol, (k, relerr(v, r32[k]), tol)

@@ -101,3 +101,21 @@ def test_full_model_loss_and_grads(name, kernel, order, L, method):
             assert sd[k].grad.abs().max().item() <= 1e-3 * wscale + 1e-6, k
             continue
         _close(sd[k].grad, ref, 2e-3, 1e-6, 'd ' + k)
+
+
+@pytest.mark.parametrize('method,order_of_accuracy', [('euler', 1), ('midpoint', 2), ('rk4', 4)])
+def test_fixed_grid_solvers_on_a_linear_ode(method, order_of_accuracy):
+    """The integrator is a restatement of torchdiffeq's fixed-grid solvers (absent here): check the stage
+    algebra against the exact solution of y' = A y (a rotation with decay) and its order of convergence."""
+    import math
+    A = torch.tensor([[-0.3, 1.0], [-1.0, -0.3]], dtype=torch.float64)
+    y0 = torch.tensor([[1.0, 0.5]], dtype=torch.float64)
+    f = lambda y: y @ A.T
+    exact = y0 @ torch.linalg.matrix_exp(A * 1.0).T
+    errs = []
+    for n in (10, 20, 40):
+        ts = torch.linspace(0, 1, n + 1, dtype=torch.float64)
+        yT = O.odeint_fixed(f, y0, ts, method)[-1]
+        errs.append((yT - exact).abs().max().item())
+    rate = math.log2(errs[1] / errs[2])
+    assert abs(rate - order_of_accuracy) < 0.25, (errs, rate)

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void rollout_bwd_team_kernel(const float* __re
                                                                 const float* __restrict__ xstage, const float* __restrict__ gzt,
                                                                 const float* __restrict__ ts, int N, int T,
                                                                 float* __restrict__ gz0, float* __restrict__ astage) {
-  constexpr int NS = METHOD == 0 ? 1 : 4;
+  constexpr int NS = METHOD == 0 ? 1 : (METHOD == 1 ? 4 : 2);
   __shared__ float slots[2 * TEAM * TeamCombine::DP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   EV ev;
@@ -77,6 +77,19 @@ __global__ __launch_bounds__(256) void rollout_bwd_team_kernel(const float* __re
         if (wave == 0) store_vec<DO>(at, af, lane);
 #pragma unroll
         for (int i = 0; i < DI; ++i) lam[i] += g[i];
+      } else if (METHOD == 2) {
+        // midpoint: y1 = y + dt k2, k2 = f(x2), x2 = y + dt/2 k1, k1 = f(y)
+        float a1[DI], a2[DI], ay[DI];
+#pragma unroll
+        for (int i = 0; i < DI; ++i) { a2[i] = dt * lam[i]; x[i] = xt[DI + i]; }
+        ode_vjp<EV, DI, DO, ORDER>(ev, x, a2, g, af);
+        if (wave == 0) store_vec<DO>(at + DO, af, lane);
+#pragma unroll
+        for (int i = 0; i < DI; ++i) { ay[i] = lam[i] + g[i]; a1[i] = 0.5f * dt * g[i]; x[i] = xt[i]; }
+        ode_vjp<EV, DI, DO, ORDER>(ev, x, a1, g, af);
+        if (wave == 0) store_vec<DO>(at, af, lane);
+#pragma unroll
+        for (int i = 0; i < DI; ++i) lam[i] = ay[i] + g[i];
       } else {
         // y1 = y + (k1 + 3(k2+k3) + k4) dt/8 ;  x2 = y + dt k1/3 ; x3 = y + dt(k2 - k1/3) ; x4 = y + dt(k1 - k2 + k3)
         float a1[DI], a2[DI], a3[DI], a4[DI], ay[DI];
@@ -344,17 +357,19 @@ static int bwd_rbf_dispatch(int order, int method, const float* pack, int M, int
   if constexpr (DI == DO) {
     if (order == 1 && method == 0) return launch_bwd_rbf<DI, DO, 1, 0>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
     if (order == 1 && method == 1) return launch_bwd_rbf<DI, DO, 1, 1>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
+    if (order == 1 && method == 2) return launch_bwd_rbf<DI, DO, 1, 2>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
   }
   if constexpr (DI == 2 * DO) {
     if (order == 2 && method == 0) return launch_bwd_rbf<DI, DO, 2, 0>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
     if (order == 2 && method == 1) return launch_bwd_rbf<DI, DO, 2, 1>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
+    if (order == 2 && method == 2) return launch_bwd_rbf<DI, DO, 2, 2>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
   }
   return set_error("gpode_rollout_bwd: order=%d needs Di == order*Do (Di=%d Do=%d)", order, DI, DO);
 }
 
 int rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S, const float* pack, const float* xstage,
                 const float* gzt, const float* ts, int N, int T, float* gz0, float* astage, hipStream_t st) {
-  if (method != 0 && method != 1) return set_error("gpode_rollout_bwd: method %d", method);
+  if (method < 0 || method > 2) return set_error("gpode_rollout_bwd: method %d", method);
   if (kernel == 0) {
 #define X(a, b) if (Di == a && Do == b) return bwd_rbf_dispatch<a, b>(order, method, pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
     GP_BWD_RBF_DIMS(X)
@@ -362,7 +377,8 @@ int rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S,
   } else {
     if (order != 1) return set_error("gpode_rollout_bwd: DF kernel is first-order only");
 #define X(a) if (Di == a && Do == a) return method == 0 ? launch_bwd_df<a, 0>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st) \
-                                                          : launch_bwd_df<a, 1>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
+                                            : method == 1 ? launch_bwd_df<a, 1>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st) \
+                                                          : launch_bwd_df<a, 2>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
     GP_BWD_DF_DIMS(X)
 #undef X
   }

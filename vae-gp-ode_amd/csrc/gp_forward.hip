@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const float* __restrict__ 
                                const float* __restrict__ z0, const float* __restrict__ ts, int N, int T,
                                float* __restrict__ zt, float* __restrict__ xstage) {
   static_assert(DI == ORDER * DO, "state dim = order * D_out");
-  constexpr int NS = METHOD == 0 ? 1 : 4;
+  constexpr int NS = METHOD == 0 ? 1 : (METHOD == 1 ? 4 : 2);
   if (USE_LDS) stage_pack_lds(pack, lds_f4);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
@@ -226,6 +226,14 @@ __global__ __launch_bounds__(256) void rollout_kernel(const float* __restrict__ 
       if (METHOD == 0) {
 #pragma unroll
         for (int i = 0; i < DI; ++i) y[i] = y[i] + dt * k1[i];
+      } else if (METHOD == 2) {                      // midpoint: y1 = y + dt f(y + dt/2 f(y))
+        float k2[DI], xs[DI];
+#pragma unroll
+        for (int i = 0; i < DI; ++i) xs[i] = y[i] + 0.5f * dt * k1[i];
+        if (xs_out) store_state<DI>(xs_out + (size_t)(t * NS + 1) * DI, xs, lane);
+        ode_rhs<EV, DI, DO, ORDER>(ev, xs, k2);
+#pragma unroll
+        for (int i = 0; i < DI; ++i) y[i] = y[i] + dt * k2[i];
       } else {
         float k2[DI], k3[DI], k4[DI], xs[DI];
 #pragma unroll
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(256) void rollout_team_kernel(const float* __restri
                                                             const float* __restrict__ z0, const float* __restrict__ ts,
                                                             int N, int T, float* __restrict__ zt, float* __restrict__ xstage) {
   static_assert(DI == ORDER * DO, "state dim = order * D_out");
-  constexpr int NS = METHOD == 0 ? 1 : 4;
+  constexpr int NS = METHOD == 0 ? 1 : (METHOD == 1 ? 4 : 2);
   __shared__ float slots[2 * TEAM * TeamCombine::DP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   EV ev;
@@ -310,6 +318,14 @@ __global__ __launch_bounds__(256) void rollout_team_kernel(const float* __restri
       if (METHOD == 0) {
 #pragma unroll
         for (int i = 0; i < DI; ++i) y[i] = y[i] + dt * k1[i];
+      } else if (METHOD == 2) {                      // midpoint
+        float k2[DI], xs[DI];
+#pragma unroll
+        for (int i = 0; i < DI; ++i) xs[i] = y[i] + 0.5f * dt * k1[i];
+        if (xs_out) store_state<DI>(xs_out + (size_t)(t * NS + 1) * DI, xs, lane);
+        ode_rhs_mut<EV, DI, DO, ORDER>(ev, xs, k2);
+#pragma unroll
+        for (int i = 0; i < DI; ++i) y[i] = y[i] + dt * k2[i];
       } else {
         float k2[DI], k3[DI], k4[DI], xs[DI];
 #pragma unroll
@@ -476,17 +492,19 @@ static int rollout_rbf_dispatch(int order, int method, const float* pack, int M,
   if constexpr (DI == DO) {
     if (order == 1 && method == 0) return launch_rollout_rbf<DI, DO, 1, 0>(pack, M, S, z0, ts, N, T, zt, xstage, st);
     if (order == 1 && method == 1) return launch_rollout_rbf<DI, DO, 1, 1>(pack, M, S, z0, ts, N, T, zt, xstage, st);
+    if (order == 1 && method == 2) return launch_rollout_rbf<DI, DO, 1, 2>(pack, M, S, z0, ts, N, T, zt, xstage, st);
   }
   if constexpr (DI == 2 * DO) {
     if (order == 2 && method == 0) return launch_rollout_rbf<DI, DO, 2, 0>(pack, M, S, z0, ts, N, T, zt, xstage, st);
     if (order == 2 && method == 1) return launch_rollout_rbf<DI, DO, 2, 1>(pack, M, S, z0, ts, N, T, zt, xstage, st);
+    if (order == 2 && method == 2) return launch_rollout_rbf<DI, DO, 2, 2>(pack, M, S, z0, ts, N, T, zt, xstage, st);
   }
   return set_error("gpode_rollout_fwd: order=%d needs Di == order*Do (Di=%d Do=%d)", order, DI, DO);
 }
 
 int rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, int S, const float* pack,
                 const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st) {
-  if (method != 0 && method != 1) return set_error("gpode_rollout_fwd: method %d (0 euler, 1 rk4)", method);
+  if (method < 0 || method > 2) return set_error("gpode_rollout_fwd: method %d (0 euler, 1 rk4, 2 midpoint)", method);
   if (kernel == 0) {
 #define X(a, b) if (Di == a && Do == b) return rollout_rbf_dispatch<a, b>(order, method, pack, M, S, z0, ts, N, T, zt, xstage, st);
     GP_RBF_DIMS(X)
@@ -494,7 +512,8 @@ int rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, int S,
   } else {
     if (order != 1) return set_error("gpode_rollout_fwd: DF kernel is first-order only (kernels.py:259-262)");
 #define X(a) if (Di == a && Do == a) return method == 0 ? launch_rollout_df<a, 0>(pack, M, S, z0, ts, N, T, zt, xstage, st) \
-                                                          : launch_rollout_df<a, 1>(pack, M, S, z0, ts, N, T, zt, xstage, st);
+                                            : method == 1 ? launch_rollout_df<a, 1>(pack, M, S, z0, ts, N, T, zt, xstage, st) \
+                                                          : launch_rollout_df<a, 2>(pack, M, S, z0, ts, N, T, zt, xstage, st);
     GP_DF_DIMS(X)
 #undef X
   }

@@ -3,14 +3,14 @@
 The reference hands ``ODEfunc`` to torchdiffeq, which calls it 1 (euler) or 4 (rk4) times per step
 from Python.  Here ``Flow.forward`` is ONE persistent HIP kernel per MC draw (csrc/gp_forward.hip):
 each wavefront integrates one trajectory over the whole grid.  Fixed-grid methods only ('euler',
-'rk4' = torchdiffeq's 3/8 rule, 'midpoint' is not built yet); adaptive solvers are out of scope.
+'rk4' = torchdiffeq's 3/8 rule, 'midpoint'); adaptive solvers are out of scope.
 """
 import torch
 import torch.nn as nn
 
 from ... import ops
 
-EVALS_PER_STEP = {'euler': 1, 'rk4': 4}
+EVALS_PER_STEP = {'euler': 1, 'rk4': 4, 'midpoint': 2}
 
 
 class ODEfunc(nn.Module):
@@ -52,7 +52,7 @@ class Flow(nn.Module):
     def forward(self, z0, ts):
         """z0 (N,D), ts (T,) -> zt (N,T,D) for a fresh function draw (flow.py:68-86)."""
         if self.solver not in EVALS_PER_STEP:
-            raise ValueError("solver '%s': this build integrates on the fixed grid with 'euler' or 'rk4' only" % self.solver)
+            raise ValueError("solver '%s': this build integrates on the fixed grid with 'euler', 'midpoint' or 'rk4' only" % self.solver)
         gp = self.odefunc.diffeq
         self.odefunc._num_evals.fill_(0)
         zt = ops.flow(gp, z0, ts, self.odefunc.order, self.solver)

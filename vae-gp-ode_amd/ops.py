@@ -10,7 +10,7 @@ import torch
 from . import _lib
 
 KERNEL_ID = {'RBF': 0, 'DF': 1}
-METHOD_ID = {'euler': 0, 'rk4': 1}
+METHOD_ID = {'euler': 0, 'rk4': 1, 'midpoint': 2}
 
 
 def _ptr(t):
@@ -162,14 +162,14 @@ def rhs(cache, x, mode=0):
     return f
 
 
-NSTAGE = {'euler': 1, 'rk4': 4}
+NSTAGE = {'euler': 1, 'rk4': 4, 'midpoint': 2}
 
 
 def rollout(cache, z0, ts, order, method, save_stages=False):
     """Flow.forward (flow.py:68-86) for a built cache: z0 (N,D), ts (T,) -> zt (N,T,D).
     save_stages=True also returns the inputs of all RHS evaluations (N,T-1,NS,D) for the reverse sweep."""
     if method not in METHOD_ID:
-        raise _lib.GpodeError("solver '%s' is not a fixed-grid method of this build (euler, rk4)" % method)
+        raise _lib.GpodeError("solver '%s' is not a fixed-grid method of this build (euler, rk4, midpoint)" % method)
     z0 = _chk(z0, 'z0'); ts = _chk(ts, 'ts')
     N, D = z0.shape
     if D != cache.Di or D != order * cache.Do:
