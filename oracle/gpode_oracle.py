@@ -182,9 +182,17 @@ def df_f_update(x, Z, nu, ell, var):
 # ----------------------------------------------------------------------------
 # SVGP layer   model/core/svpy.py
 # ----------------------------------------------------------------------------
+def is_q_diag(Us, Um):
+    """q_diag=True stores Us_sqrt.optvar as the raw (M,Do) softplus scale (svpy.py:79-82); otherwise (Do, M(M+1)/2)."""
+    M, Do = Um.shape
+    return tuple(Us.shape) == (M, Do) and (M, Do) != (Do, M * (M + 1) // 2)
+
+
 def sample_inducing(Us_packed, eps_u, Um):
-    """svpy.py:88-101 (q_diag=False) -> (M,Do)"""
+    """svpy.py:88-101 -> (M,Do); q_diag (svpy.py:95-96): softplus(raw) * eps"""
     M = Um.shape[0]
+    if is_q_diag(Us_packed, Um):
+        return softplus(Us_packed) * eps_u + Um
     Ls = tril_unpack(Us_packed, M)
     return torch.einsum('dnm, md->nd', Ls, eps_u) + Um
 
@@ -230,13 +238,17 @@ def gp_forward(x, c):
 
 
 def svgp_kl(Um, Us_packed):
-    """svpy.py:144-175 (q_diag=False)"""
+    """svpy.py:144-175"""
     M = Um.shape[0]
-    Lq = torch.tril(tril_unpack(Us_packed, M))
-    Lq_diag = torch.diagonal(Lq, dim1=1, dim2=2).t()
+    if is_q_diag(Us_packed, Um):                 # svpy.py:153-154,165-166
+        Lq = Lq_diag = softplus(Us_packed)
+        trace = torch.pow(Lq, 2).sum(dim=0, keepdim=True)
+    else:
+        Lq = torch.tril(tril_unpack(Us_packed, M))
+        Lq_diag = torch.diagonal(Lq, dim1=1, dim2=2).t()
+        trace = torch.pow(Lq, 2).sum(dim=(1, 2)).unsqueeze(0)
     mahalanobis = torch.pow(Um, 2).sum(dim=0, keepdim=True)
     logdet_qcov = torch.log(torch.pow(Lq_diag, 2)).sum(dim=0, keepdim=True)
-    trace = torch.pow(Lq, 2).sum(dim=(1, 2)).unsqueeze(0)
     twoKL = 0.0 - logdet_qcov + mahalanobis + trace + (-torch.tensor(M))
     return 0.5 * twoKL.sum()
 

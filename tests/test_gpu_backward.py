@@ -106,7 +106,8 @@ def make_layer(g, kernel, order, method):
     Do, Di = sd['kern.unconstrained_lengthscales'].shape
     M = sd['inducing_loc.optvar'].shape[0]
     S = g['noise.rff_eps'].shape[1]
-    gp = SVGP_Layer(Di, Do, M, S, kernel=kernel).cuda()
+    q_diag = tuple(sd['Us_sqrt.optvar'].shape) == (M, Do) and (M, Do) != (Do, M * (M + 1) // 2)
+    gp = SVGP_Layer(Di, Do, M, S, q_diag=q_diag, kernel=kernel).cuda()
     gp.load_state_dict(sd)
     flow = Flow(gp, order=order, solver=method).cuda()
     gp.set_noise({k: v.cuda() for k, v in sub(g, 'noise.').items()})
@@ -169,3 +170,32 @@ def test_midpoint_solver_forward_and_backward(name, kernel, order):
     for k, v in got.items():
         tol = 1e-3 + 3 * relerr(r32[k], r64[k])
         assert relerr(v, r32[k]) < tol, (k, relerr(v, r32[k]), tol)
+
+
+@pytest.mark.parametrize('name,kernel', [('gp_rbf1_tiny_qdiag', 'RBF'), ('gp_df1_tiny_qdiag', 'DF')])
+@pytest.mark.parametrize('method', ['euler', 'rk4'])
+def test_q_diag_variant_matches_reference(name, kernel, method):
+    """SVGP_Layer(q_diag=True) (svpy.py:79-82,95-96,153-167): diagonal inducing scale under a softplus.  Trajectory, KL
+    and every parameter gradient (incl. the raw diagonal scale) against fixtures captured from the reference."""
+    g = load_golden(name)
+    flow, gp = make_layer(g, kernel, 1, method)
+    assert gp.q_diag and tuple(gp.Us_sqrt.optvar.shape) == (gp.M, gp.D_out)
+    z0 = g['z0'].cuda().requires_grad_(True)
+    zt = flow(z0, g['ts'].cuda())
+    kl = gp.kl()
+    (zt * g['gw'].cuda()).sum().backward()
+    p64 = {k: v.double().clone().requires_grad_(True) for k, v in O.gp_params_from_state_dict(sub(g, 'sd.')).items()}
+    c64 = O.build_cache(p64, O.to_dtype(sub(g, 'noise.'), torch.float64), kernel)
+    z64 = g['z0'].double().clone().requires_grad_(True)
+    zt64 = O.flow_forward(z64, g['ts'].double(), c64, 1, method)
+    (zt64 * g['gw'].double()).sum().backward()
+    assert relerr(zt, g['zt_' + method]) < 2e-4 + 3 * relerr(g['zt_' + method], zt64)
+    assert abs(kl.item() - g['kl_u'].item()) < 1e-5 * abs(g['kl_u'].item())
+    gr = sub(g, 'grad_%s.' % method)
+    got = {'raw_ell': gp.kern.unconstrained_lengthscales.grad, 'raw_var': gp.kern.unconstrained_variance.grad,
+           'Z': gp.inducing_loc.optvar.grad, 'Um': gp.Um.optvar.grad, 'Us': gp.Us_sqrt.optvar.grad}
+    for short, key in O.GP_KEYS.items():
+        ref = gr[key[len('flow.'):]]
+        tol = 1e-3 + 3 * relerr(ref, p64[short].grad)
+        assert relerr(got[short], ref) < tol, (short, relerr(got[short], ref), tol)
+    assert relerr(z0.grad, gr['z0']) < 5e-4 + 3 * relerr(gr['z0'], z64.grad)

@@ -10,6 +10,7 @@ from oracle import gpode_oracle as O
 GP_CASES = [('gp_rbf1_tiny', 'RBF', 1), ('gp_rbf2_tiny', 'RBF', 2), ('gp_df1_tiny', 'DF', 1),
             ('gp_df1_tiny_q4', 'DF', 1), ('gp_rbf1_cfg1', 'RBF', 1), ('gp_df1_cfg2', 'DF', 1),
             ('gp_rbf2_cfg3', 'RBF', 2)]
+QDIAG_CASES = [('gp_rbf1_tiny_qdiag', 'RBF', 1), ('gp_df1_tiny_qdiag', 'DF', 1)]   # q_diag=True (svpy.py:79-82)
 
 
 def _close(a, b, rtol, atol, what):
@@ -20,7 +21,7 @@ def _close(a, b, rtol, atol, what):
     assert err <= atol + rtol * scale, '%s: max|diff|=%.3e scale=%.3e' % (what, err, scale)
 
 
-@pytest.mark.parametrize('name,kernel,order', GP_CASES)
+@pytest.mark.parametrize('name,kernel,order', GP_CASES + QDIAG_CASES)
 def test_cache_and_rhs_match_reference(name, kernel, order):
     g = load_golden(name)
     p = O.gp_params_from_state_dict(sub(g, 'sd.'))
@@ -30,7 +31,10 @@ def test_cache_and_rhs_match_reference(name, kernel, order):
         assert torch.equal(c[k], g[k]), k
     for k in ('Ku', 'u_prior'):
         _close(c[k], g[k], 2e-6, 0, k)
-    assert torch.equal(O.tril_unpack(p['Us'], p['Um'].shape[0]), g['Us_dense'])
+    if O.is_q_diag(p['Us'], p['Um']):
+        assert torch.equal(O.softplus(p['Us']), g['Us_dense'])
+    else:
+        assert torch.equal(O.tril_unpack(p['Us'], p['Um'].shape[0]), g['Us_dense'])
     # cholesky / solves go through LAPACK in both: allow last-bit differences
     # (bit-exact at equal thread count; K_uu has cond ~2e4 so blocking changes move nu by ~1e-4)
     _close(c['Lu'], g['Lu'], 5e-5, 0, 'Lu')
@@ -45,7 +49,7 @@ def test_cache_and_rhs_match_reference(name, kernel, order):
     _close(O.svgp_kl(p['Um'], p['Us']), g['kl_u'], 1e-6, 0, 'kl_u')
 
 
-@pytest.mark.parametrize('name,kernel,order', GP_CASES)
+@pytest.mark.parametrize('name,kernel,order', GP_CASES + QDIAG_CASES)
 @pytest.mark.parametrize('method', ['euler', 'rk4'])
 def test_flow_matches_reference(name, kernel, order, method):
     g = load_golden(name)
@@ -55,7 +59,7 @@ def test_flow_matches_reference(name, kernel, order, method):
     _close(zt, g['zt_' + method], 5e-4 if 'cfg' in name else 2e-5, 0, 'zt')
 
 
-@pytest.mark.parametrize('name,kernel,order', GP_CASES[:4])
+@pytest.mark.parametrize('name,kernel,order', GP_CASES[:4] + QDIAG_CASES)
 @pytest.mark.parametrize('method', ['euler', 'rk4'])
 def test_flow_gradients_match_reference(name, kernel, order, method):
     g = load_golden(name)

@@ -27,8 +27,6 @@ class SVGP_Layer(torch.nn.Module):
             self.dimwise = False  # as the reference (svpy.py:62-64)
         else:
             raise SystemExit('Invalid kernel selection')
-        if q_diag:
-            raise NotImplementedError('q_diag=True is outside the accelerated path (SURVEY 8f rank 3)')
         self.kernel_n = kernel
         self.q_diag = q_diag
         self.D_out, self.D_in, self.M, self.S = D_out, D_in, M, S
@@ -36,12 +34,28 @@ class SVGP_Layer(torch.nn.Module):
         # initial values exactly as svpy.py:76-86 (global numpy RNG, same draw order)
         self.inducing_loc = Param(np.random.normal(size=(M, D_in)), name='Inducing locations')
         self.Um = Param(np.random.normal(size=(M, D_out)) * 1e-1, name='Inducing distribution (mean)')
-        self.Us_sqrt = Param(np.stack([np.eye(M)] * D_out) * 1e-3,
-                             transform=transforms.LowerTriangular(M, D_out, device=self.device),
-                             name='Inducing distribution (scale)')
+        if q_diag:   # svpy.py:79-82: diagonal scale (M,D_out) under a softplus
+            self.Us_sqrt = Param(np.ones(shape=(M, D_out)) * 1e-3, transform=transforms.SoftPlus(),
+                                 name='Inducing distribution (scale)')
+            self._diag_index = torch.tensor([n * (n + 1) // 2 + n for n in range(M)], dtype=torch.long)
+        else:
+            self.Us_sqrt = Param(np.stack([np.eye(M)] * D_out) * 1e-3,
+                                 transform=transforms.LowerTriangular(M, D_out, device=self.device),
+                                 name='Inducing distribution (scale)')
         self.noise_source = NumpyNoise()
         self._next_noise = []
         self.cache = None
+
+    def us_packed(self):
+        """The inducing scale in the packed lower-triangular layout (D_out, M(M+1)/2) the kernels consume.  q_diag=False:
+        the parameter itself.  q_diag=True (svpy.py:95-96,153-167): softplus(raw) scattered onto the packed diagonal --
+        the triangular mat-vec, its gradient and the KL then reduce to the diagonal formulas of the reference."""
+        if not self.q_diag:
+            return self.Us_sqrt.optvar
+        raw = self.Us_sqrt.optvar                                   # (M, D_out)
+        idx = self._diag_index.to(raw.device)
+        packed = torch.zeros(self.D_out, self.M * (self.M + 1) // 2, dtype=raw.dtype, device=raw.device)
+        return packed.index_copy(1, idx, (torch.nn.functional.softplus(raw) + 1e-12).t())
 
     # -- randomness ---------------------------------------------------------------------------
     def set_noise(self, *noises):
@@ -68,7 +82,7 @@ class SVGP_Layer(torch.nn.Module):
         nz = self._take_noise()
         k = self.kern
         self.cache = ops.cache_build(self.kernel_n, k.unconstrained_lengthscales.detach(), k.unconstrained_variance.detach(),
-                                     self.inducing_loc.optvar.detach(), self.Um.optvar.detach(), self.Us_sqrt.optvar.detach(),
+                                     self.inducing_loc.optvar.detach(), self.Um.optvar.detach(), self.us_packed().detach(),
                                      nz['eps_u'], nz['rff_w'], nz['rff_eps'], nz['rff_u'], want_Lu=want_Lu)
         self.cache.noise = nz
         k._set_cache(self.cache, nz)
@@ -100,4 +114,4 @@ class SVGP_Layer(torch.nn.Module):
 
     def kl(self):
         """KL(q(u) || N(0,I)) in whitened form (svpy.py:144-175)."""
-        return ops.svgp_kl(self.Um.optvar, self.Us_sqrt.optvar, self.M)
+        return ops.svgp_kl(self.Um.optvar, self.us_packed(), self.M)

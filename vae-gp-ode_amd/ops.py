@@ -299,7 +299,7 @@ class _Flow(torch.autograd.Function):
 def flow(gp, z0, ts, order, method):
     k = gp.kern
     return _Flow.apply(z0, ts, k.unconstrained_lengthscales, k.unconstrained_variance, gp.inducing_loc.optvar,
-                       gp.Um.optvar, gp.Us_sqrt.optvar, gp, order, method)
+                       gp.Um.optvar, gp.us_packed() if hasattr(gp, 'us_packed') else gp.Us_sqrt.optvar, gp, order, method)
 
 
 def cache_build_bwd(cache, raw_ell, raw_var, Z, gpack):
