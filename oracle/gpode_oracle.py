@@ -197,9 +197,24 @@ def sample_inducing(Us_packed, eps_u, Um):
     return torch.einsum('dnm, md->nd', Ls, eps_u) + Um
 
 
+def broadcast_shared(p, noise):
+    """dimwise=False RBF (kernels.py:45-46,81-96,108-110,118-124,131-132,164-181): one lengthscale vector (D_in,), one
+    variance (1,), one frequency / phase set (D_in,S) / (1,S) shared by every output, one Cholesky of the single (M,M)
+    K_uu.  Formula by formula this is the dimwise=True case with the hyper-parameters and frequencies repeated along the
+    output axis (the D_out factorisations are then identical), so the restatement repeats them; the fixtures
+    gp_rbf*_tiny_shared, captured from the reference with dimwise=False, pin the equivalence."""
+    if p['raw_ell'].dim() != 1:
+        return p, noise
+    Do = p['Um'].shape[1]
+    p = dict(p, raw_ell=p['raw_ell'].unsqueeze(0).expand(Do, -1), raw_var=p['raw_var'].expand(Do))
+    noise = dict(noise, rff_eps=noise['rff_eps'].unsqueeze(-1).expand(-1, -1, Do), rff_u=noise['rff_u'].unsqueeze(-1).expand(-1, -1, Do))
+    return p, noise
+
+
 def build_cache(p, noise, kernel):
     """svpy.py:103-121.  p: dict(raw_ell, raw_var, Z, Um, Us) of optvars;
     noise: dict(eps_u, rff_w, rff_eps, rff_u).  Returns the per-draw cache."""
+    p, noise = broadcast_shared(p, noise)
     ell, var = softplus(p['raw_ell']), softplus(p['raw_var'])
     S = noise['rff_eps'].shape[1]
     omega = rff_omega(noise['rff_eps'], ell)

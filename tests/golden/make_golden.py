@@ -116,21 +116,21 @@ class Args:
     pass
 
 
-def make_args(kernel, order, M, S, q, solver, Ndata=360, q_diag=False):
+def make_args(kernel, order, M, S, q, solver, Ndata=360, q_diag=False, dimwise=True):
     a = Args()
     a.D_in = q * order
     a.D_out = q
     a.num_inducing, a.num_features = M, S
-    a.dimwise, a.q_diag, a.device, a.kernel = True, q_diag, 'cpu', kernel
+    a.dimwise, a.q_diag, a.device, a.kernel = dimwise, q_diag, 'cpu', kernel
     a.ode, a.solver, a.use_adjoint = order, solver, False
     a.frames, a.n_filt, a.latent_dim, a.Ndata, a.dt = 5, 8, q, Ndata, 0.1
     return a
 
 
-def build(kernel, order, M, S, q, solver, seed, uniform_hyper, spread=0.25, q_diag=False):
+def build(kernel, order, M, S, q, solver, seed, uniform_hyper, spread=0.25, q_diag=False, dimwise=True):
     np.random.seed(seed)
     torch.manual_seed(seed)
-    model = rcm.build_model(make_args(kernel, order, M, S, q, solver, q_diag=q_diag))
+    model = rcm.build_model(make_args(kernel, order, M, S, q, solver, q_diag=q_diag, dimwise=dimwise))
     initialize_and_fix_kernel_parameters(model, lengthscale_value=2.0, variance_value=1.0)
     gp = model.flow.odefunc.diffeq
     g = torch.Generator().manual_seed(seed + 1)
@@ -152,12 +152,12 @@ def npy(t):
     return t.detach().cpu().numpy()
 
 
-def gp_case(name, kernel, order, N, M, S, q, T, seed, uniform_hyper=False, spread=0.25, q_diag=False):
+def gp_case(name, kernel, order, N, M, S, q, T, seed, uniform_hyper=False, spread=0.25, q_diag=False, dimwise=True):
     """GP layer + flow goldens (no images)."""
     out = {}
     Di = q * order
     for solver in ('euler', 'rk4'):
-        model = build(kernel, order, M, S, q, solver, seed, uniform_hyper, spread, q_diag)
+        model = build(kernel, order, M, S, q, solver, seed, uniform_hyper, spread, q_diag, dimwise)
         gp = model.flow.odefunc.diffeq
         rec = Recorder(seed + 7)
         patch(rec)
@@ -272,6 +272,9 @@ if __name__ == '__main__':
     # q_diag=True: diagonal inducing covariance, Us_sqrt.optvar (M,Do) under a softplus (svpy.py:79-82,95-96,153-167)
     gp_case('gp_rbf1_tiny_qdiag', 'RBF', 1, N=4, M=16, S=32, q=6, T=5, seed=105, q_diag=True)
     gp_case('gp_df1_tiny_qdiag', 'DF', 1, N=4, M=16, S=32, q=6, T=5, seed=106, q_diag=True)
+    # dimwise=False: one lengthscale vector / variance / frequency set shared by all outputs (kernels.py:81-96,108-110,164-181)
+    gp_case('gp_rbf1_tiny_shared', 'RBF', 1, N=4, M=16, S=32, q=6, T=5, seed=107, dimwise=False)
+    gp_case('gp_rbf2_tiny_shared', 'RBF', 2, N=4, M=16, S=32, q=3, T=5, seed=108, dimwise=False)
     # BASELINE configs cfg1/cfg2/cfg3 at the CPU-runnable batch of 32, README hyper-parameters
     gp_case('gp_rbf1_cfg1', 'RBF', 1, N=32, M=100, S=256, q=6, T=16, seed=121, uniform_hyper=True)
     gp_case('gp_df1_cfg2', 'DF', 1, N=32, M=100, S=256, q=6, T=16, seed=122, uniform_hyper=True)

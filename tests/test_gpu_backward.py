@@ -103,11 +103,13 @@ def make_layer(g, kernel, order, method):
     from vae_gp_ode_amd.model.core.flow import Flow
     from vae_gp_ode_amd.model.core.svpy import SVGP_Layer
     sd = sub(g, 'sd.flow.odefunc.diffeq.')
-    Do, Di = sd['kern.unconstrained_lengthscales'].shape
+    Do, Di = (sd['kern.unconstrained_lengthscales'].shape if sd['kern.unconstrained_lengthscales'].dim() == 2 else (0, 0))
     M = sd['inducing_loc.optvar'].shape[0]
     S = g['noise.rff_eps'].shape[1]
     q_diag = tuple(sd['Us_sqrt.optvar'].shape) == (M, Do) and (M, Do) != (Do, M * (M + 1) // 2)
-    gp = SVGP_Layer(Di, Do, M, S, q_diag=q_diag, kernel=kernel).cuda()
+    if sd['kern.unconstrained_lengthscales'].dim() == 1:      # dimwise=False fixture: lengthscales (D_in,), Um tells D_out
+        Di, Do = sd['kern.unconstrained_lengthscales'].shape[0], sd['Um.optvar'].shape[1]
+    gp = SVGP_Layer(Di, Do, M, S, q_diag=q_diag, dimwise=sd['kern.unconstrained_lengthscales'].dim() == 2, kernel=kernel).cuda()
     gp.load_state_dict(sd)
     flow = Flow(gp, order=order, solver=method).cuda()
     gp.set_noise({k: v.cuda() for k, v in sub(g, 'noise.').items()})
@@ -193,6 +195,41 @@ def test_q_diag_variant_matches_reference(name, kernel, method):
     assert abs(kl.item() - g['kl_u'].item()) < 1e-5 * abs(g['kl_u'].item())
     gr = sub(g, 'grad_%s.' % method)
     got = {'raw_ell': gp.kern.unconstrained_lengthscales.grad, 'raw_var': gp.kern.unconstrained_variance.grad,
+           'Z': gp.inducing_loc.optvar.grad, 'Um': gp.Um.optvar.grad, 'Us': gp.Us_sqrt.optvar.grad}
+    for short, key in O.GP_KEYS.items():
+        ref = gr[key[len('flow.'):]]
+        tol = 1e-3 + 3 * relerr(ref, p64[short].grad)
+        assert relerr(got[short], ref) < tol, (short, relerr(got[short], ref), tol)
+    assert relerr(z0.grad, gr['z0']) < 5e-4 + 3 * relerr(gr['z0'], z64.grad)
+
+
+@pytest.mark.parametrize('name,order', [('gp_rbf1_tiny_shared', 1), ('gp_rbf2_tiny_shared', 2)])
+@pytest.mark.parametrize('method', ['euler', 'rk4'])
+def test_shared_hyperparameter_rbf_matches_reference(name, order, method):
+    """RBF(dimwise=False) (kernels.py:45-46,81-96,108-110,118-132,164-181): one lengthscale vector / variance / frequency
+    set for all outputs.  Cached attributes in the reference's layouts, K, the trajectory and every gradient (the shared
+    lengthscales receive the sum over outputs) against fixtures captured from the reference's non-dimwise code path."""
+    g = load_golden(name)
+    flow, gp = make_layer(g, 'RBF', order, method)
+    k = gp.kern
+    assert not k.dimwise and tuple(k.unconstrained_lengthscales.shape) == (gp.D_in,) and tuple(k.unconstrained_variance.shape) == (1,)
+    z0 = g['z0'].cuda().requires_grad_(True)
+    zt = flow(z0, g['ts'].cuda())
+    (zt * g['gw'].cuda()).sum().backward()
+    p64 = {kk: v.double().clone().requires_grad_(True) for kk, v in O.gp_params_from_state_dict(sub(g, 'sd.')).items()}
+    c64 = O.build_cache(p64, O.to_dtype(sub(g, 'noise.'), torch.float64), 'RBF')
+    z64 = g['z0'].double().clone().requires_grad_(True)
+    zt64 = O.flow_forward(z64, g['ts'].double(), c64, order, method)
+    (zt64 * g['gw'].double()).sum().backward()
+    assert tuple(k.rff_omega.shape) == tuple(g['omega'].shape) and relerr(k.rff_omega, g['omega']) < 1e-6
+    assert tuple(k.rff_phase.shape) == tuple(g['phase'].shape) and relerr(k.rff_phase, g['phase']) < 1e-6
+    assert tuple(k.nu.shape) == tuple(g['nu'].shape)
+    assert relerr(k.nu, g['nu']) < 2e-4 + 3 * relerr(g['nu'], c64['nu'].squeeze(2).T)
+    Z = gp.inducing_loc.optvar.detach()
+    assert relerr(k.K(Z), g['Ku']) < 1e-5 and relerr(k.K(Z, g['x'].cuda()), g['Kzx']) < 1e-5
+    assert relerr(zt, g['zt_' + method]) < 2e-4 + 3 * relerr(g['zt_' + method], zt64)
+    gr = sub(g, 'grad_%s.' % method)
+    got = {'raw_ell': k.unconstrained_lengthscales.grad, 'raw_var': k.unconstrained_variance.grad,
            'Z': gp.inducing_loc.optvar.grad, 'Um': gp.Um.optvar.grad, 'Us': gp.Us_sqrt.optvar.grad}
     for short, key in O.GP_KEYS.items():
         ref = gr[key[len('flow.'):]]

@@ -10,6 +10,7 @@ from oracle import gpode_oracle as O
 GP_CASES = [('gp_rbf1_tiny', 'RBF', 1), ('gp_rbf2_tiny', 'RBF', 2), ('gp_df1_tiny', 'DF', 1),
             ('gp_df1_tiny_q4', 'DF', 1), ('gp_rbf1_cfg1', 'RBF', 1), ('gp_df1_cfg2', 'DF', 1),
             ('gp_rbf2_cfg3', 'RBF', 2)]
+SHARED_CASES = [('gp_rbf1_tiny_shared', 'RBF', 1), ('gp_rbf2_tiny_shared', 'RBF', 2)]   # dimwise=False (kernels.py:81-96)
 QDIAG_CASES = [('gp_rbf1_tiny_qdiag', 'RBF', 1), ('gp_df1_tiny_qdiag', 'DF', 1)]   # q_diag=True (svpy.py:79-82)
 
 
@@ -49,7 +50,30 @@ def test_cache_and_rhs_match_reference(name, kernel, order):
     _close(O.svgp_kl(p['Um'], p['Us']), g['kl_u'], 1e-6, 0, 'kl_u')
 
 
-@pytest.mark.parametrize('name,kernel,order', GP_CASES + QDIAG_CASES)
+@pytest.mark.parametrize('name,kernel,order', SHARED_CASES)
+def test_shared_hyperparameter_rbf_matches_reference(name, kernel, order):
+    """dimwise=False: the oracle evaluates it as dimwise=True with repeated hyper-parameters / frequencies; every cached
+    quantity must agree with what the reference's non-dimwise code path produced."""
+    g = load_golden(name)
+    p = O.gp_params_from_state_dict(sub(g, 'sd.'))
+    c = O.build_cache(p, sub(g, 'noise.'), kernel)
+    Do = p['Um'].shape[1]
+    for d in range(Do):
+        assert torch.equal(c['ell'][d], g['ell']) and torch.equal(c['var'][d], g['var'][0])
+        assert torch.equal(c['omega'][..., d], g['omega']) and torch.equal(c['phase'][..., d], g['phase'])
+        _close(c['Ku'][d], g['Ku'], 2e-6, 0, 'Ku')
+        _close(c['Lu'][d], g['Lu'], 5e-5, 0, 'Lu')
+    _close(c['u_prior'], g['u_prior'], 2e-6, 0, 'u_prior')
+    _close(c['nu'].squeeze(2).T, g['nu'], 5e-4, 0, 'nu')                       # reference layout (M, D_out)
+    x = g['x']
+    _close(O.gp_prior(x, c), g['f_prior_x'], 2e-6, 0, 'f_prior_x')
+    c_ref = dict(c, nu=g['nu'].T.unsqueeze(2))
+    _close(O.gp_update(x, c_ref), g['f_update_x'], 2e-6, 0, 'f_update_x')
+    _close(O.gp_forward(x, c_ref), g['f_x'], 2e-6, 0, 'f_x')
+    _close(O.rbf_K(c['Z'], x, c['ell'], c['var'])[0], g['Kzx'], 2e-6, 0, 'Kzx')
+
+
+@pytest.mark.parametrize('name,kernel,order', GP_CASES + QDIAG_CASES + SHARED_CASES)
 @pytest.mark.parametrize('method', ['euler', 'rk4'])
 def test_flow_matches_reference(name, kernel, order, method):
     g = load_golden(name)
@@ -59,7 +83,7 @@ def test_flow_matches_reference(name, kernel, order, method):
     _close(zt, g['zt_' + method], 5e-4 if 'cfg' in name else 2e-5, 0, 'zt')
 
 
-@pytest.mark.parametrize('name,kernel,order', GP_CASES[:4] + QDIAG_CASES)
+@pytest.mark.parametrize('name,kernel,order', GP_CASES[:4] + QDIAG_CASES + SHARED_CASES)
 @pytest.mark.parametrize('method', ['euler', 'rk4'])
 def test_flow_gradients_match_reference(name, kernel, order, method):
     g = load_golden(name)

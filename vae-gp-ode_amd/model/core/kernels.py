@@ -24,11 +24,10 @@ class RBF(nn.Module):
         super().__init__()
         self.D_in = D_in
         self.D_out = D_in if D_out is None else D_out
-        if not dimwise:
-            raise NotImplementedError('dimwise=False RBF is outside the accelerated path (SURVEY 8f rank 3)')
         self.dimwise = dimwise
-        self.unconstrained_lengthscales = nn.Parameter(torch.ones(self.D_out, self.D_in))
-        self.unconstrained_variance = nn.Parameter(torch.ones(self.D_out))
+        # dimwise=False (kernels.py:45-46): one lengthscale vector and one variance shared by all outputs
+        self.unconstrained_lengthscales = nn.Parameter(torch.ones(self.D_out, self.D_in) if dimwise else torch.ones(self.D_in))
+        self.unconstrained_variance = nn.Parameter(torch.ones(self.D_out) if dimwise else torch.ones(1))
         with torch.no_grad():  # class defaults of the reference (kernels.py:52-54)
             self.unconstrained_lengthscales.fill_(invsoftplus(torch.tensor(0.2)).item())
             self.unconstrained_variance.fill_(invsoftplus(torch.tensor(0.1)).item())
@@ -42,13 +41,24 @@ class RBF(nn.Module):
     def variance(self):
         return softplus(self.unconstrained_variance)
 
+    def raw_dimwise(self):
+        """(raw lengthscales (D_out,D_in), raw variances (D_out,)) as the kernels consume them.  The shared-parameter
+        kernel is evaluated as the per-output kernel with the parameters repeated along the output axis (formula by
+        formula the same arithmetic; autograd sums the per-output gradients back onto the shared parameters)."""
+        if self.dimwise or self.kernel_id != 'RBF':
+            return self.unconstrained_lengthscales, self.unconstrained_variance
+        return (self.unconstrained_lengthscales.unsqueeze(0).expand(self.D_out, -1).contiguous(),
+                self.unconstrained_variance.expand(self.D_out).contiguous())
+
     # -- cached per-draw state (set by SVGP_Layer.build_cache) ---------------------------------
     def _set_cache(self, cache, noise):
         self._cache = cache
         self.rff_weights = noise['rff_w']
-        self.rff_omega = cache.omega
-        self.rff_phase = cache.phase
-        self.nu = cache.nu
+        if self.dimwise or self.kernel_id != 'RBF':
+            self.rff_omega, self.rff_phase, self.nu = cache.omega, cache.phase, cache.nu
+        else:   # attribute layouts of the reference's non-dimwise branch (kernels.py:118-132,164-172)
+            self.rff_omega, self.rff_phase = cache.omega[..., 0], cache.phase[..., 0]
+            self.nu = cache.nu.reshape(self.D_out, -1).t()
 
     def _need_cache(self):
         if self._cache is None:
@@ -68,8 +78,9 @@ class RBF(nn.Module):
 
     def K(self, X, X2=None):
         """K(X, X2): (D_out,N,M) for RBF, (N*D, M*D) for DF (kernels.py:98-110 / :289-303)."""
-        return ops.kernel_matrix(self.kernel_id, self.unconstrained_lengthscales.detach(),
-                                 self.unconstrained_variance.detach(), X, X2)
+        ell, var = self.raw_dimwise()
+        Kd = ops.kernel_matrix(self.kernel_id, ell.detach(), var.detach(), X, X2)
+        return Kd if (self.dimwise or self.kernel_id != 'RBF') else Kd[0]
 
 
 class DivergenceFreeKernel(RBF):

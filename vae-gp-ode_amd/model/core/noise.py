@@ -16,7 +16,9 @@ import numpy as np
 import torch
 
 
-def draw_shapes(kernel, Di, Do, M, S):
+def draw_shapes(kernel, Di, Do, M, S, dimwise=True):
+    if kernel == 'RBF' and not dimwise:   # shared frequencies (kernels.py:118-119,131)
+        return dict(rff_w=(S, Do), rff_eps=(Di, S), rff_u=(1, S), eps_u=(M, Do))
     return dict(rff_w=(S if kernel == 'RBF' else 2 * S, Do), rff_eps=(Di, S, Do), rff_u=(1, S, Do), eps_u=(M, Do))
 
 
@@ -24,8 +26,8 @@ class NumpyNoise:
     def __init__(self, unseeded_rff=True):
         self.unseeded_rff = unseeded_rff
 
-    def draw(self, kernel, Di, Do, M, S, device):
-        sh = draw_shapes(kernel, Di, Do, M, S)
+    def draw(self, kernel, Di, Do, M, S, device, dimwise=True):
+        sh = draw_shapes(kernel, Di, Do, M, S, dimwise)
         fresh = np.random.RandomState() if self.unseeded_rff else np.random
         out = dict(rff_w=fresh.normal(size=sh['rff_w']))
         fresh = np.random.RandomState() if self.unseeded_rff else np.random
@@ -41,11 +43,11 @@ class DeviceNoise:
         self._gen = None
         self._device = device
 
-    def draw(self, kernel, Di, Do, M, S, device):
+    def draw(self, kernel, Di, Do, M, S, device, dimwise=True):
         if self._gen is None or self._gen.device != torch.device(device):
             self._gen = torch.Generator(device=device)
             self._gen.manual_seed(self.seed)
-        sh = draw_shapes(kernel, Di, Do, M, S)
+        sh = draw_shapes(kernel, Di, Do, M, S, dimwise)
         g = self._gen
         return dict(rff_w=torch.randn(sh['rff_w'], generator=g, device=device),
                     rff_eps=torch.randn(sh['rff_eps'], generator=g, device=device),

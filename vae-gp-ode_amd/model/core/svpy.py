@@ -67,7 +67,8 @@ class SVGP_Layer(torch.nn.Module):
         if self._next_noise:
             nz = self._next_noise.pop(0)
             return {k: v.to(dev) for k, v in nz.items()}
-        return self.noise_source.draw(self.kernel_n, self.D_in, self.D_out, self.M, self.S, dev)
+        return self.noise_source.draw(self.kernel_n, self.D_in, self.D_out, self.M, self.S, dev,
+                                      **({} if self.dimwise or self.kernel_n != 'RBF' else {'dimwise': False}))
 
     # -- reference API ------------------------------------------------------------------------
     def sample_inducing(self):
@@ -81,7 +82,11 @@ class SVGP_Layer(torch.nn.Module):
             self._next_noise.insert(0, noise)
         nz = self._take_noise()
         k = self.kern
-        self.cache = ops.cache_build(self.kernel_n, k.unconstrained_lengthscales.detach(), k.unconstrained_variance.detach(),
+        if nz['rff_eps'].dim() == 2:   # dimwise=False draws one frequency / phase set (kernels.py:118-124,131-132): repeat it per output
+            nz = dict(nz, rff_eps=nz['rff_eps'].unsqueeze(-1).expand(-1, -1, self.D_out).contiguous(),
+                      rff_u=nz['rff_u'].unsqueeze(-1).expand(-1, -1, self.D_out).contiguous())
+        raw_ell, raw_var = k.raw_dimwise()
+        self.cache = ops.cache_build(self.kernel_n, raw_ell.detach(), raw_var.detach(),
                                      self.inducing_loc.optvar.detach(), self.Um.optvar.detach(), self.us_packed().detach(),
                                      nz['eps_u'], nz['rff_w'], nz['rff_eps'], nz['rff_u'], want_Lu=want_Lu)
         self.cache.noise = nz

@@ -298,7 +298,8 @@ class _Flow(torch.autograd.Function):
 
 def flow(gp, z0, ts, order, method):
     k = gp.kern
-    return _Flow.apply(z0, ts, k.unconstrained_lengthscales, k.unconstrained_variance, gp.inducing_loc.optvar,
+    raw_ell, raw_var = k.raw_dimwise() if hasattr(k, 'raw_dimwise') else (k.unconstrained_lengthscales, k.unconstrained_variance)
+    return _Flow.apply(z0, ts, raw_ell, raw_var, gp.inducing_loc.optvar,
                        gp.Um.optvar, gp.us_packed() if hasattr(gp, 'us_packed') else gp.Us_sqrt.optvar, gp, order, method)
 
 
