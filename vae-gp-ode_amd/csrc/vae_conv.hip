@@ -184,6 +184,24 @@ __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ 
   if (lane == 0) { if (i < In) gw[(size_t)o * In + i] = out1[0]; else if (gb) gb[o] = out1[0]; }
 }
 
+// ---- wide fan-in, few outputs (the encoder's fc layer, 512 -> 2q on the minibatch, vae.py:62): one wavefront per output
+//      element, lanes along the reduction
+__global__ __launch_bounds__(256) void k_linear_fwd_fanin(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int B, int In, int Out) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= B * Out) return;
+  const int b = e / Out, o = e % Out;
+  const float* xr = x + (size_t)b * In;
+  const float* wr = w + (size_t)o * In;
+  float acc = 0.f;
+  for (int i = lane; i < In; i += 64) acc = fmaf(xr[i], wr[i], acc);
+  const float in1[1] = {acc};
+  float out1[1];
+  wave_sum_multi<1>(in1, out1);
+  if (lane == 0) y[e] = out1[0] + (bias ? bias[o] : 0.f);
+}
+
 // ---- small fan-in (In <= 16, Out a multiple of 64): the decoder's fc layer (latent -> 512, vae.py:66) on all
 //      batch*T latent states.  Threads run along Out (coalesced rows of y / gy); the few weights per output live in
 //      registers.
@@ -370,6 +388,10 @@ int linear_fwd(const float* x, const float* w, const float* bias, float* y, int 
     const int rows = 8;
     hipLaunchKernelGGL(k_linear_fwd_fanout, (B + rows - 1) / rows, 256, 0, st, x, w, bias, y, B, In, Out, rows);
     return check_launch("linear_fwd_fanout");
+  }
+  if (In >= 128 && (size_t)B * Out <= (size_t)1 << 22) {
+    hipLaunchKernelGGL(k_linear_fwd_fanin, (unsigned)(((size_t)B * Out + 3) / 4), 256, 0, st, x, w, bias, y, B, In, Out);
+    return check_launch("linear_fwd_fanin");
   }
   hipLaunchKernelGGL(k_linear_fwd, (unsigned)(((size_t)B * Out + 255) / 256), 256, 0, st, x, w, bias, y, B, In, Out);
   return check_launch("linear_fwd");

@@ -44,6 +44,11 @@ using Dec1 = CTLayer<32, 64, 4, 6, 0, 3, 1, 0>;
 using Dec4 = CTLayer<64, 32, 6, 13, 0>;
 using Dec7 = CTLayer<32, 16, 13, 28, 1>;
 using Dec10 = CTLayer<16, 1, 28, 28, 0, 5, 1, 2>;
+// the encoder's Conv2d layers, described as the transposed convolutions they are the adjoint of (vae.py:52-59: k5 s2 p2):
+// cnn.3 8 -> 16 ch, 14 -> 7 and cnn.6 16 -> 32 ch, 7 -> 4.  Only the directions whose channel counts fill MFMA tiles
+// (source channels % 4, output channels % 16) take the matrix-core engine; cnn.0 (1 or 5 input channels) stays generic.
+using Enc3 = CTLayer<16, 8, 7, 14, 1, 5, 2, 2>;
+using Enc6 = CTLayer<32, 16, 4, 7, 0, 5, 2, 2>;
 
 extern __shared__ __attribute__((aligned(16))) float tsm[];
 
@@ -425,21 +430,25 @@ static int launch_T2(const float* gy, const float* w, float* gx, int B, hipStrea
   return check_launch("convT_bwd_data_tiled");
 }
 
+template <class L, int IPBM, int WM, int WN, int WT, bool PIPE>
+static int launch_wgrad_mfma(const float* x, const float* gy, float* gw, float* scratch, int B, hipStream_t st) {
+  constexpr size_t ldsm = wgrad_lds_bytes<L, IPBM>();
+  static_assert(ldsm <= 160 * 1024, "LDS budget");
+  auto km = k_convT_wgrad_mfma<L, IPBM, WM, WN, WT, PIPE, 512>;
+  if (set_max_lds((const void*)km, ldsm)) return 1;
+  const int ngroups = (B + IPBM - 1) / IPBM;
+  const int nwg = ngroups < 256 ? ngroups : 256;
+  hipLaunchKernelGGL(km, nwg, 512, ldsm, st, x, gy, scratch, B);
+  const size_t n = (size_t)L::CI * L::CO * L::K * L::K;
+  hipLaunchKernelGGL(k_sum_splits_wgrad, (unsigned)((n + 63) / 64), 1024, 0, st, scratch, nwg, L::CI / 16, L::CO / 16, L::K * L::K, gw);
+  return check_launch("convT_wgrad_mfma");
+}
+
 // IPBM / WM x WN x WT: images per group and wavefront split (ci tiles, co tiles, taps) of the MFMA kernel
 template <class L, int COW, int IPBM, int WM, int WN, int WT, bool PIPE>
 static int launch_T3(const float* x, const float* gy, float* gw, float* scratch, int B, hipStream_t st) {
-  if (use_mfma() && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0) {
-    constexpr size_t ldsm = wgrad_lds_bytes<L, IPBM>();
-    static_assert(ldsm <= 160 * 1024, "LDS budget");
-    auto km = k_convT_wgrad_mfma<L, IPBM, WM, WN, WT, PIPE, 512>;
-    if (set_max_lds((const void*)km, ldsm)) return 1;
-    const int ngroups = (B + IPBM - 1) / IPBM;
-    const int nwg = ngroups < 256 ? ngroups : 256;
-    hipLaunchKernelGGL(km, nwg, 512, ldsm, st, x, gy, scratch, B);
-    const size_t n = (size_t)L::CI * L::CO * L::K * L::K;
-    hipLaunchKernelGGL(k_sum_splits_wgrad, (unsigned)((n + 63) / 64), 1024, 0, st, scratch, nwg, L::CI / 16, L::CO / 16, L::K * L::K, gw);
-    return check_launch("convT_wgrad_mfma");
-  }
+  if (use_mfma() && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0)
+    return launch_wgrad_mfma<L, IPBM, WM, WN, WT, PIPE>(x, gy, gw, scratch, B, st);
   constexpr int NT = L::CI * (COW / 4), PSPLIT = 256 / NT, KK = L::K * L::K;
   size_t fl = (size_t)L::HI * L::HI * L::CI + (size_t)L::GP_ * L::GP_ * COW;
   const size_t red = PSPLIT > 1 ? (size_t)PSPLIT * NT * KK * 4 : 0;
@@ -464,6 +473,8 @@ int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx
   if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec7, 3, 2, 16>(gy, w, bias, gx, B, st);
   if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec4, 3, 2, 16>(gy, w, bias, gx, B, st);
   if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec1, 8, 8, 64>(gy, w, bias, gx, B, st);
+  if (matches<Enc6>(Ci, Co, H, Ho, K, S, P) && use_mfma() && (reinterpret_cast<uintptr_t>(gy) & 15) == 0)   // d/d input of the encoder's cnn.6
+    return launch_igemm<FwdPolicy<Enc6, 16>, 8, 4, 1>(gy, w, bias, gx, B, st, "enc_conv6_bwd_data_mfma");
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) {
     if (use_mfma()) {
       const size_t ldsm = sizeof(float) * dec10::KK * dec10::PST;
@@ -484,10 +495,16 @@ int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx
 // ConvTranspose2d d/d input (conv geometry: x := grad_output (B,Ci,H,W) -> y (B,Co,Ho,Wo)), no bias
 int tiled_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S, int P,
               int Ho, int Wo, hipStream_t st) {
-  if (H != W || Ho != Wo || bias) return -1;
+  if (H != W || Ho != Wo) return -1;
+  if (use_mfma() && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {   // encoder Conv2d layers (with their bias)
+    if (matches<Enc3>(Ci, Co, H, Ho, K, S, P)) return launch_igemm<BwdDataPolicy<Enc3, 16>, 4, 4, 1>(x, w, bias, y, B, st, "enc_conv3_fwd_mfma");
+    if (matches<Enc6>(Ci, Co, H, Ho, K, S, P)) return launch_igemm<BwdDataPolicy<Enc6, 32>, 8, 1, 2>(x, w, bias, y, B, st, "enc_conv6_fwd_mfma");
+  }
+  if (bias) return -1;
   if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec7, 2, 8, 2, 32, 2, 2>(x, w, y, B, st);
   if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec4, 3, 8, 2, 32, 1, 1>(x, w, y, B, st);
   if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec1, 8, 32, 6, 32, 1, 1>(x, w, y, B, st);
+
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) {
     if (use_mfma() && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
       constexpr int IPB = 8;
@@ -508,6 +525,8 @@ int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch,
   if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec7, 16, 2, 1, 1, 8, true>(gy, x, gw, scratch, B, st);
   if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec4, 16, 2, 4, 2, 1, false>(gy, x, gw, scratch, B, st);
   if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec1, 32, 8, 2, 4, 1, true>(gy, x, gw, scratch, B, st);
+  if (matches<Enc6>(Ci, Co, H, Ho, K, S, P) && use_mfma() && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0)
+    return launch_wgrad_mfma<Enc6, 8, 2, 1, 4, true>(gy, x, gw, scratch, B, st);   // d/d weight of the encoder's cnn.6
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P) && use_mfma() &&
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0) {
     constexpr int IPB = 1;
