@@ -95,7 +95,10 @@ int gpode_cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, size_t* bws_
 int gpode_cache_build_bwd(int kernel, int Di, int Do, int M, int S,
                           const float* raw_ell, const float* raw_var, const float* Z, const float* eps_u,
                           const float* pack, const float* ws, float* gpack, float* bws,
-                          float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, void* stream);
+                          float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, int prepared, void* stream);
+/* The gradient-independent part of the above (L^-1 from the factor in ws, written into bws).  Optional: call it any time
+ * after gpode_cache_build_fwd -- e.g. on a side stream while the decoder runs -- and pass prepared = 1 with the same bws. */
+int gpode_cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, const float* ws, float* bws, void* stream);
 
 /* Factorisation status of the last gpode_cache_build_fwd on `ws` (bit 0: K_uu + jitter I not positive
  * definite -- torch.linalg.cholesky raises there, kernels.py:163/:384).  Copies one int to the host and

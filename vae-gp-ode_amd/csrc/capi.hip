@@ -105,11 +105,15 @@ int gpode_cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, size_t* bws_
 int gpode_cache_build_bwd(int kernel, int Di, int Do, int M, int S,
                           const float* raw_ell, const float* raw_var, const float* Z, const float* eps_u,
                           const float* pack, const float* ws, float* gpack, float* bws,
-                          float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, void* stream) {
+                          float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, int prepared, void* stream) {
   if (!raw_ell || !raw_var || !Z || !eps_u || !pack || !ws || !gpack || !bws || !g_raw_ell || !g_raw_var || !g_Z || !g_Um || !g_Us)
     return gp::set_error("gpode_cache_build_bwd: null pointer");
   return gp::cache_build_bwd(kernel, Di, Do, M, S, raw_ell, raw_var, Z, eps_u, pack, ws, gpack, bws,
-                             g_raw_ell, g_raw_var, g_Z, g_Um, g_Us, (hipStream_t)stream);
+                             g_raw_ell, g_raw_var, g_Z, g_Um, g_Us, prepared, (hipStream_t)stream);
+}
+int gpode_cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, const float* ws, float* bws, void* stream) {
+  if (!ws || !bws) return gp::set_error("gpode_cache_bwd_prepare: null pointer");
+  return gp::cache_bwd_prepare(kernel, Di, Do, M, S, ws, bws, (hipStream_t)stream);
 }
 
 // ---- conv VAE blocks -----------------------------------------------------------------------

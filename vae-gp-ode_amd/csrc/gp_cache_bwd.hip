@@ -598,9 +598,30 @@ int cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, size_t* bws_floats
   return 0;
 }
 
+// The gradient-independent part of the cache backward: L^-1 from the factor the forward left in ws.  It needs nothing
+// from the backward pass, so a caller may run it any time after the forward (e.g. on a side stream under the decoder)
+// and pass prepared = 1 to cache_build_bwd with the same bws.
+int cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, const float* ws, float* bws, hipStream_t st) {
+  size_t pf = 0;
+  if (cache_sizes(kernel, Di, Do, M, S, &pf, nullptr)) return 1;
+  const WsLayout w = ws_layout(kernel, Di, Do, M, S);
+  const BwsLayout b = bws_layout(kernel, Di, Do, M, S, pf);
+  const float* Lmat = ws + w.Lmat;
+  const float* Dfac = ws + w.Dfac;
+  const size_t bstride = (size_t)w.np * w.np, dstride = (size_t)w.nblk * NB * NB, dinv_stride = (size_t)b.nbn * NB * NB;
+  hipLaunchKernelGGL(k_trinv_diag, dim3(b.nbn, b.batch), 64, 0, st, Dfac, dstride, b.n, bws + b.Dinv, dinv_stride);
+  hipLaunchKernelGGL(k_linv_init, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, b.np, bws + b.Dinv, dinv_stride, bws + b.Linv, bstride);
+  for (int sb = 1; sb < b.nbn; sb *= 2) {            // T lives in the X buffer (written by k_gemm_phiX only afterwards)
+    const int npairs = cdiv(b.nbn, 2 * sb);
+    hipLaunchKernelGGL(k_linv_dc, dim3(sb, sb, npairs * b.batch), 256, 0, st, 0, sb, npairs, b.nbn, b.n, b.np, Lmat, bws + b.Linv, bws + b.X, bstride);
+    hipLaunchKernelGGL(k_linv_dc, dim3(sb, sb, npairs * b.batch), 256, 0, st, 1, sb, npairs, b.nbn, b.n, b.np, Lmat, bws + b.Linv, bws + b.X, bstride);
+  }
+  return check_launch("cache bwd: L^-1");
+}
+
 int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_ell, const float* raw_var, const float* Z,
                     const float* eps_u, const float* pack, const float* ws, float* gpack, float* bws,
-                    float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, hipStream_t st) {
+                    float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, int prepared, hipStream_t st) {
   size_t pf = 0;
   if (cache_sizes(kernel, Di, Do, M, S, &pf, nullptr)) return 1;
   if (Di > 16 || Do > 16) return set_error("gpode_cache_build_bwd: D <= 16");
@@ -616,13 +637,7 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
   (void)MJ;
 
   hipLaunchKernelGGL(k_gnu, dim3(cdiv(b.np, 128), b.batch), 128, 0, st, kernel, Di, Do, M, b.n, b.np, gpack_ind, ws + w.var, vec);
-  hipLaunchKernelGGL(k_trinv_diag, dim3(b.nbn, b.batch), 64, 0, st, Dfac, dstride, b.n, bws + b.Dinv, dinv_stride);
-  hipLaunchKernelGGL(k_linv_init, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, b.np, bws + b.Dinv, dinv_stride, bws + b.Linv, bstride);
-  for (int sb = 1; sb < b.nbn; sb *= 2) {            // T lives in the X buffer (written by k_gemm_phiX only afterwards)
-    const int npairs = cdiv(b.nbn, 2 * sb);
-    hipLaunchKernelGGL(k_linv_dc, dim3(sb, sb, npairs * b.batch), 256, 0, st, 0, sb, npairs, b.nbn, b.n, b.np, Lmat, bws + b.Linv, bws + b.X, bstride);
-    hipLaunchKernelGGL(k_linv_dc, dim3(sb, sb, npairs * b.batch), 256, 0, st, 1, sb, npairs, b.nbn, b.n, b.np, Lmat, bws + b.Linv, bws + b.X, bstride);
-  }
+  if (!prepared && cache_bwd_prepare(kernel, Di, Do, M, S, ws, bws, st)) return 1;
   hipLaunchKernelGGL(k_vec_q, dim3(cdiv(b.np, 4), b.batch), 256, 0, st, b.n, b.np, bws + b.Linv, bstride, vec);
   hipLaunchKernelGGL(k_vec_a, dim3(cdiv(b.np, 4), b.batch), 256, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, bws + b.Linv,
                      ws + w.u, vec, g_Um, bws + b.gp_rows);

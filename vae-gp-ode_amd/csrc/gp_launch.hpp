@@ -66,7 +66,8 @@ int svgp_kl_bwd(int M, int Do, const float* Um, const float* Us, const float* g,
 int cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, size_t* bws_floats);
 int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_ell, const float* raw_var, const float* Z,
                     const float* eps_u, const float* pack, const float* ws, float* gpack, float* bws,
-                    float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, hipStream_t st);
+                    float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, int prepared, hipStream_t st);
+int cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, const float* ws, float* bws, hipStream_t st);
 
 // conv VAE blocks (vae_conv.hip)
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S,

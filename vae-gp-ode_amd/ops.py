@@ -266,6 +266,13 @@ class _Flow(torch.autograd.Function):
             cache = gp.build_cache()
         ctx.params = (raw_ell, raw_var, Z, Um, Us)
         need = any(ctx.needs_input_grad)
+        ctx.prepared = None
+        if _overlap['on'] and any(ctx.needs_input_grad[2:7]):
+            # L^-1 for the cache backward depends on the forward factor only: start it now on the side stream, where it
+            # runs under the rollout / decoder instead of at the exposed end of the backward pass
+            side = fork_side_stream()
+            with launch_on(side):
+                ctx.prepared = cache_bwd_prepare(cache)
         if need:
             zt, xs = rollout(cache, z0, ts, order, method, save_stages=True)
         else:
@@ -287,12 +294,14 @@ class _Flow(torch.autograd.Function):
             side = fork_side_stream()
             with launch_on(side):
                 gpack = param_grad(c, xs.reshape(-1, c.Di), ast.reshape(-1, c.Do))
-                g = cache_build_bwd(c, raw_ell, raw_var, Z, gpack)
+                g = cache_build_bwd(c, raw_ell, raw_var, Z, gpack, prepared=ctx.prepared)
             grads = [g['raw_ell'], g['raw_var'], g['Z'], g['Um'], g['Us']]
             _overlap['pending'].append((ctx.params, [gg.view_as(p) for gg, p in zip(grads, ctx.params)], (g, gpack, xs, ast, c)))
             return (gz0,) + (None,) * 9
+        if ctx.prepared is not None:
+            torch.cuda.current_stream().wait_stream(side_stream())
         gpack = param_grad(c, xs.reshape(-1, c.Di), ast.reshape(-1, c.Do))
-        g = cache_build_bwd(c, raw_ell, raw_var, Z, gpack)
+        g = cache_build_bwd(c, raw_ell, raw_var, Z, gpack, prepared=ctx.prepared)
         return (gz0, None, g['raw_ell'], g['raw_var'], g['Z'], g['Um'], g['Us'], None, None, None)
 
 
@@ -303,19 +312,31 @@ def flow(gp, z0, ts, order, method):
                        gp.Um.optvar, gp.us_packed() if hasattr(gp, 'us_packed') else gp.Us_sqrt.optvar, gp, order, method)
 
 
-def cache_build_bwd(cache, raw_ell, raw_var, Z, gpack):
+def cache_bwd_prepare(cache):
+    """The gradient-independent part of cache_build_bwd (L^-1 of the draw's factor), into a workspace that is returned
+    and later handed to cache_build_bwd(..., prepared=ws)."""
+    c = cache
+    bw = ctypes.c_size_t(0)
+    _lib.call('gpode_cache_bwd_sizes', KERNEL_ID[c.kernel], c.Di, c.Do, c.M, c.S, ctypes.byref(bw))
+    bws = torch.empty(bw.value, dtype=torch.float32, device=c.pack.device)
+    _lib.call('gpode_cache_bwd_prepare', KERNEL_ID[c.kernel], c.Di, c.Do, c.M, c.S, _ptr(c.ws), _ptr(bws), _stream())
+    return bws
+
+
+def cache_build_bwd(cache, raw_ell, raw_var, Z, gpack, prepared=None):
     """Pack-layout gradient -> gradients of the five raw GP parameter tensors (state_dict layouts)."""
     c = cache
     bw = ctypes.c_size_t(0)
     _lib.call('gpode_cache_bwd_sizes', KERNEL_ID[c.kernel], c.Di, c.Do, c.M, c.S, ctypes.byref(bw))
     dev = gpack.device
     new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-    bws = new(bw.value)
+    bws = prepared if prepared is not None else new(bw.value)
     out = dict(raw_ell=new(c.Do, c.Di), raw_var=new(c.Do), Z=new(c.M, c.Di), Um=new(c.M, c.Do),
                Us=new(c.Do, c.M * (c.M + 1) // 2))
     _lib.call('gpode_cache_build_bwd', KERNEL_ID[c.kernel], c.Di, c.Do, c.M, c.S,
               _ptr(_chk(raw_ell, 'raw_ell')), _ptr(_chk(raw_var, 'raw_var')), _ptr(_chk(Z, 'Z')), _ptr(c.noise['eps_u']),
               _ptr(c.pack), _ptr(c.ws), _ptr(gpack), _ptr(bws),
-              _ptr(out['raw_ell']), _ptr(out['raw_var']), _ptr(out['Z']), _ptr(out['Um']), _ptr(out['Us']), _stream())
+              _ptr(out['raw_ell']), _ptr(out['raw_var']), _ptr(out['Z']), _ptr(out['Um']), _ptr(out['Us']),
+              int(prepared is not None), _stream())
     out['_workspace'] = bws   # referenced by the caller for as long as a side stream may still be writing it
     return out
