@@ -393,7 +393,7 @@ def run_integrator(a, w, dev, rank, n_gpus, dist, barrier):
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': w['desc'] + '; step = GP draw (K_uu, Cholesky, nu) + rk4 rollout, L=1 [integrator fwd]',
                    'global_batch': w['batch'] * n_gpus, 'solver': 'rk4 (3/8 rule)', 'parallelism': 'dp%d' % n_gpus,
-                   'hip_graph': graphed, 'gp_side_stream': not a.no_overlap},
+                   'hip_graph': False},
         'roofline': {'bound': 'mfma', 'kernel': 'rollout_kernel', 'achieved': achieved, 'peak': PEAK_FP32_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS, 'traffic': None,
                      'ms_per_launch': roll_ms,
