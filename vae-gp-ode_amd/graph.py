@@ -11,14 +11,25 @@ must be registered so that every replay draws fresh numbers), no host synchronis
 import torch
 
 
+def _detached(out):
+    """Outputs without their autograd graph: a graph kept alive from an earlier iteration pins its AccumulateGrad nodes to
+    the stream of that iteration, and the next backward would then accumulate outside the stream being captured."""
+    if torch.is_tensor(out):
+        return out.detach()
+    if isinstance(out, (tuple, list)):
+        return type(out)(_detached(o) for o in out)
+    return out
+
+
 class GraphedStep:
     def __init__(self, step_fn, generators=(), warmup=3):
         """step_fn() -> tensor or tuple of tensors (static outputs, overwritten by every replay)."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        self.warm_out = None
         with torch.cuda.stream(side):
             for _ in range(warmup):      # lazy initialisation (generators, LDS attributes, allocator pools)
-                step_fn()
+                self.warm_out = _detached(step_fn())   # these are real steps; the last one's outputs stay readable here
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
@@ -28,7 +39,7 @@ class GraphedStep:
         # thread_local: other threads of the process (e.g. the RCCL watchdog polling its events) may keep calling the
         # runtime while this thread captures
         with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-            self.out = step_fn()
+            self.out = _detached(step_fn())
         self.eager_steps = warmup
 
     def __call__(self):

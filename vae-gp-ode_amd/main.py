@@ -48,12 +48,17 @@ FLAGS = [
     ('model_path', str, 'None', 'path from where to load previous model, should be of the form results/mnist_*/*.pth'),
     ('Troll', int, 2, 'rollout'),
 ]
+# extensions of this build (not in the reference): off by default so that a run is the reference's loop kernel by kernel
+EXT_FLAGS = [
+    ('hip_graph', eval, False, 'replay each training step as one captured HIP graph, GP chains on a side stream, GP noise drawn '
+                               'on the device (INTEGRATION.md); the reference draws GP noise from host numpy generators'),
+]
 CHOICES = {'kernel': KERNELS, 'solver': SOLVERS}  # default 'euler' is accepted only as a default, as in the reference
 
 
 def make_parser():
     p = argparse.ArgumentParser('Learning latent dyanmics with OdeVaeGP')
-    for name, typ, default, hlp in FLAGS:
+    for name, typ, default, hlp in FLAGS + EXT_FLAGS:
         kw = dict(type=typ, default=default, help=hlp)
         if name in CHOICES:
             kw['choices'] = CHOICES[name]
@@ -146,19 +151,51 @@ def main(argv=None):
     meters = {k: RunningAverage(10) for k in ('elbo', 'nll', 'reg_kl', 'inducing_kl')}
     optimizer = HipAdam(model.parameters(), lr=args.lr)
     kern = model.flow.odefunc.diffeq.kern
+    graphs = {}     # --hip_graph: one captured step per (L, batch shape), replayed on a static input buffer
+    if args.hip_graph:
+        from . import ops
+        from .graph import GraphedStep, device_generators
+        from .model.core.noise import DeviceNoise
+        model.flow.odefunc.diffeq.noise_source = DeviceNoise(args.seed + 1)
+        ops.set_overlap(True)
+
+    def graphed_step(minibatch, L):
+        key = (L, tuple(minibatch.shape))
+        if key not in graphs:
+            buf = torch.empty_like(minibatch)
+
+            def step():
+                optimizer.zero_grad()
+                out = compute_loss(model, buf, L)
+                out[0].backward()
+                optimizer.step()
+                return out
+            buf.copy_(minibatch)
+            gp = model.flow.odefunc.diffeq
+            gp.noise_source.draw(gp.kernel_n, gp.D_in, gp.D_out, gp.M, gp.S, minibatch.device)   # creates the generator
+            graphs[key] = (buf, GraphedStep(step, generators=device_generators(model), warmup=1))
+            return graphs[key][1].warm_out           # the capture warm-up already took this minibatch's (eager) step
+        buf, g = graphs[key]
+        buf.copy_(minibatch, non_blocking=True)
+        return g()
+
     logger.info('********** Started Training **********')
     begin = time.time()
     for ep in range(args.Nepoch):
         L = 1 if ep < args.Nepoch // 2 else 5
         for itr, (local_batch,) in enumerate(trainset):
             minibatch = local_batch.to(args.device)
-            loss, nlhood, kl_reg, kl_u = compute_loss(model, minibatch, L)
+            if args.hip_graph:
+                loss, nlhood, kl_reg, kl_u = graphed_step(minibatch, L)
+            else:
+                loss, nlhood, kl_reg, kl_u = compute_loss(model, minibatch, L)
             if torch.isnan(loss):
                 logger.info('************** Obtained nan Loss at Epoch:{:4d}/{:4d}*************'.format(ep, args.Nepoch))
                 sys.exit()
-            optimizer.zero_grad()
-            loss.backward()
-            optimizer.step()
+            if not args.hip_graph:
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
             for k, v in zip(('elbo', 'nll', 'reg_kl', 'inducing_kl'), (loss, nlhood, kl_reg, kl_u)):
                 meters[k].update(v.item())
             if itr % args.log_freq == 0:
