@@ -1,15 +1,16 @@
-// vae_conv_tiled.hip -- LDS-resident, register-blocked kernels for the two FLOP-dominant decoder layers
-//   decnn.4  ConvTranspose2d(64 -> 32, k5, s2, p1)        6x6  -> 13x13      1.843 MMAC / image
-//   decnn.7  ConvTranspose2d(32 -> 16, k5, s2, p1, op1)   13x13 -> 28x28     2.163 MMAC / image
-// (87 % of the decoder's 4.6 MMAC/image, vae.py:114-118), forward, d/d input and d/d weight.
+// vae_conv_tiled.hip -- layer-specialised kernels and dispatch for the VAE's convolutions (vae.py:52-59, 64-84).
 //
-// Common shape: a workgroup stages a few whole images (zero-padded, so taps never branch) and a slab of
-// weights in LDS; a thread owns ONE pixel x 16 channels of output in registers.  Per (input channel, tap)
-// it reads one input value (ds_read_b32, lane = pixel -> conflict-free) and 16 weights (4 x ds_read_b128
-// from a [tap][ci][co] slab: every lane of a channel group reads the same address -> broadcast) and issues
-// 16 FMAs.  fp32 FMA throughout: fp32 MFMA has the same peak as the vector FMA on gfx950, the limiter here
-// is LDS operand traffic, which the 16-wide register block keeps at ~1 LDS cycle per FMA-cycle.
+// The production path is on the fp32 matrix cores: the implicit-GEMM engine of conv_mfma.hpp (decnn.1/4/7 forward, d/d input,
+// d/d weight; the encoder's cnn.3 / cnn.6 where the channel counts fill MFMA tiles) and conv_dec10_mfma.hpp (decnn.10 with
+// the 25 taps as the GEMM dimension).  This file holds the layer geometry (CTLayer), the dispatch by geometry
+// (tiled_fwd / tiled_bwd_data / tiled_bwd_weight; -1 = no specialisation, the caller falls back to the generic direct
+// kernels of vae_conv.hip) and the earlier LDS-resident VALU kernels, kept selectable with GPODE_CONV_VALU=1 as the
+// A/B baseline the MFMA numbers in DESIGN.md are quoted against:
 //
+//   a workgroup stages a few whole images (zero-padded, so taps never branch) and a slab of weights in LDS; a thread
+//   owns ONE pixel x 16 channels of output in registers.  Per (input channel, tap) it reads one input value
+//   (ds_read_b32, lane = pixel -> conflict-free) and 16 weights (4 x ds_read_b128 from a [tap][ci][co] slab: every
+//   lane of a channel group reads the same address -> broadcast) and issues 16 FMAs.
 //   T1 convT_fwd   gather form, one stride-parity class of output pixels at a time: inside a class every
 //                  pixel sees the same taps, so the weight reads are wave-uniform
 //   T2 convT_bwd   d/d input = ordinary strided convolution of grad_output with the same weights
