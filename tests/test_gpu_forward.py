@@ -153,3 +153,26 @@ def test_wave_and_team_mappings_agree(name, kernel, order):
                        w=g['noise.rff_w'], var=c.var.cpu(), S=c.S,
                        Z=g['sd.flow.odefunc.diffeq.inducing_loc.optvar'], nu=c.nu.cpu(), ell=c.ell.cpu()), torch.float64))
     assert relerr(f_wave, ref) < 5e-5
+
+
+@pytest.mark.parametrize('name,kernel,order', GP_CASES[:3])
+def test_degenerate_batches_and_grids(name, kernel, order):
+    """Edge shapes the reference handles implicitly: an empty minibatch (N = 0 -> empty trajectories), a single time point
+    (T = 1 -> the initial state, no RHS evaluation), one trajectory, and a batch that is not a multiple of anything."""
+    from vae_gp_ode_amd import ops
+    g = load_golden(name)
+    c = build(g, kernel, want_Lu=False)
+    z0, ts = g['z0'].cuda(), g['ts'].cuda()
+    D = z0.shape[1]
+    zt = ops.rollout(c, z0[:0], ts, order, 'rk4')
+    assert tuple(zt.shape) == (0, ts.shape[0], D)
+    assert tuple(ops.rhs(c, g['x'].cuda()[:0], mode=0).shape) == (0, c.Do)
+    zt1 = ops.rollout(c, z0, ts[:1], order, 'rk4')
+    assert tuple(zt1.shape) == (z0.shape[0], 1, D) and torch.equal(zt1[:, 0], z0)
+    full = ops.rollout(c, z0, ts, order, 'rk4')
+    assert torch.equal(ops.rollout(c, z0[:1], ts, order, 'rk4'), full[:1])          # trajectories are independent given the draw
+    rep = z0.repeat(67, 1)[:259]                                                    # 259 rows: ragged against every tile size
+    out = ops.rollout(c, rep, ts, order, 'rk4')
+    assert torch.equal(out[:z0.shape[0]], full) and torch.equal(out[-1], full[(259 - 1) % z0.shape[0]])
+    zs, xs = ops.rollout(c, z0, ts[:1], order, 'rk4', save_stages=True)
+    assert xs.shape[1] == 0

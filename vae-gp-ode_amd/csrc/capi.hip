@@ -43,27 +43,27 @@ int gpode_cache_info(const float* ws, int* host_info, void* stream) {
 
 int gpode_rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack,
                   const float* x, int N, float* f, int mode, void* stream) {
-  if (!pack || !x || !f) return gp::set_error("gpode_rhs_fwd: null pointer");
   if (N < 0 || mode < 0 || mode > 2) return gp::set_error("gpode_rhs_fwd: N=%d mode=%d", N, mode);
-  if (N == 0) return 0;
+  if (N == 0) return 0;                              // empty minibatch: nothing to do (empty tensors carry null pointers)
+  if (!pack || !x || !f) return gp::set_error("gpode_rhs_fwd: null pointer");
   return gp::rhs_fwd(kernel, Di, Do, M, S, pack, x, N, f, mode, (hipStream_t)stream);
 }
 
 int gpode_rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, int S,
                       const float* pack, const float* z0, const float* ts, int N, int T,
                       float* zt, float* xstage, void* stream) {
-  if (!pack || !z0 || !ts || !zt) return gp::set_error("gpode_rollout_fwd: null pointer");
   if (N < 0 || T < 1) return gp::set_error("gpode_rollout_fwd: N=%d T=%d", N, T);
   if (N == 0) return 0;
+  if (!pack || !z0 || !ts || !zt) return gp::set_error("gpode_rollout_fwd: null pointer");
   return gp::rollout_fwd(kernel, order, method, Di, Do, M, S, pack, z0, ts, N, T, zt, xstage, (hipStream_t)stream);
 }
 
 int gpode_rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S,
                       const float* pack, const float* xstage, const float* gzt, const float* ts, int N, int T,
                       float* gz0, float* astage, void* stream) {
-  if (!pack || !xstage || !gzt || !ts || !gz0 || !astage) return gp::set_error("gpode_rollout_bwd: null pointer");
   if (N < 0 || T < 1) return gp::set_error("gpode_rollout_bwd: N=%d T=%d", N, T);
   if (N == 0) return 0;
+  if (!pack || !gzt || !ts || !gz0 || (T > 1 && (!xstage || !astage))) return gp::set_error("gpode_rollout_bwd: null pointer");
   return gp::rollout_bwd(kernel, order, method, Di, Do, M, S, pack, xstage, gzt, ts, N, T, gz0, astage, (hipStream_t)stream);
 }
 
