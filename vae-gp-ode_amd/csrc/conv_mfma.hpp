@@ -197,7 +197,13 @@ __global__ __launch_bounds__(NTHR) void k_conv_igemm(const float* __restrict__ x
   PROBE_T(pt_all);
   for (int e = tid; e < IPB * IMG / 4; e += NTHR) reinterpret_cast<float4*>(s_img)[e] = float4{0.f, 0.f, 0.f, 0.f};
 
-  for (int pass = 0; pass < NC / NCS; ++pass) {
+  // NC / NCS passes over the output channels.  When the grid divides evenly the passes are spread over the workgroups
+  // (each stages ONE slab and walks every image group with its share of the grid); otherwise every workgroup loops.
+  constexpr int NPASS = NC / NCS;
+  const bool spread = NPASS > 1 && gridDim.x % NPASS == 0;
+  const int gstride = spread ? gridDim.x / NPASS : gridDim.x;       // workgroups walking the image groups of one pass
+  const int gfirst = spread ? blockIdx.x % gstride : blockIdx.x;
+  for (int pass = spread ? blockIdx.x / gstride : 0; pass < (spread ? blockIdx.x / gstride + 1 : NPASS); ++pass) {
     const int n0 = pass * NCS;
     __syncthreads();                                 // previous pass done with the slabs
     PROBE_T(pt_w);
@@ -227,8 +233,8 @@ __global__ __launch_bounds__(NTHR) void k_conv_igemm(const float* __restrict__ x
         if (f < nf4) pre[i] = src[f];
       }
     };
-    if ((int)blockIdx.x < ngroups) prefetch(blockIdx.x);
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    if (gfirst < ngroups) prefetch(gfirst);
+    for (int grp = gfirst; grp < ngroups; grp += gstride) {
       const int b0 = grp * IPB;
       const int nimg = min(IPB, B - b0);
       PROBE_T(pt_b1);
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(NTHR) void k_conv_igemm(const float* __restrict__ x
       }
       __syncthreads();
       PROBE_ADD(2, pt_sc);
-      if (grp + (int)gridDim.x < ngroups) prefetch(grp + gridDim.x);
+      if (grp + gstride < ngroups) prefetch(grp + gstride);
 
       // cost (k-steps) of all jobs of the group, and this wavefront's share [lo, hi) of it
       int wtot = 0;
