@@ -162,6 +162,18 @@ int gpode_loglik_rowsum_fwd(const float* X, const float* z, float* out, size_t r
 int gpode_loglik_rowsum_bwd(const float* X, const float* z, const float* grow, float* gz, size_t rows, size_t inner, size_t nX,
                             void* stream);
 
+/* ELBO glue on (N,q)-sized tensors (one launch each):
+ *   reparameterisation z = mu + exp(logvar/2) eps (vae.py:75-78) and its backward;
+ *   klrow[n] = sum_d KL(N(mu, exp(logvar/2)) || N(0,1)) (create_model.py:47-49, torch.distributions closed form) and its backward;
+ *   out[4] = {loss = -(mean(lhood) nobs - mean(klrow) nobs - kl_u), -mean(lhood), mean(klrow), kl_u} (create_model.py:61-73);
+ *   backward: gout[4] (gradients of the four outputs) -> glhood[nl], gklrow[nk], gklu[1]. */
+int gpode_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, size_t n, void* stream);
+int gpode_reparam_bwd(const float* gz, const float* logvar, const float* eps, float* gmu, float* glogvar, size_t n, void* stream);
+int gpode_normal_kl_fwd(const float* mu, const float* logvar, float* klrow, int N, int q, void* stream);
+int gpode_normal_kl_bwd(const float* grow, const float* mu, const float* logvar, float* gmu, float* glogvar, int N, int q, void* stream);
+int gpode_elbo_fwd(const float* lhood, int nl, const float* klrow, int nk, const float* kl_u, float nobs, float* out, void* stream);
+int gpode_elbo_bwd(const float* gout, int nl, int nk, float nobs, float* glhood, float* gklrow, float* gklu, void* stream);
+
 /* torch.optim.Adam step (main.py:194,211) over a whole parameter list in one launch.  params/grads/m1/m2:
  * DEVICE arrays of `ntensors` device pointers; offs: DEVICE array of element prefix offsets (offs[0]=0);
  * step: 1-based step count (bias correction).  step_dev (optional, DEVICE int): when non-NULL it is incremented on the

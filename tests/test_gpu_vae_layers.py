@@ -106,3 +106,35 @@ def test_linear_act_loglik(B):
         rs64 = ll64.reshape(L * B, -1).sum(1)
         (ll64.sum() + (rs64 * torch.arange(1, L * B + 1)).sum()).backward()
         assert relerr(ll, ll64) < TOL and relerr(rs, rs64) < TOL and relerr(z.grad, z64.grad) < TOL
+
+
+@pytest.mark.parametrize('N,q', [(1, 6), (37, 6), (256, 12)])
+def test_elbo_glue_ops(N, q):
+    """Fused reparameterisation, KL(q(z0) || N(0,I)) rows and loss algebra against the torch expressions of the reference
+    (vae.py:75-78; create_model.py:47-49 via torch.distributions; create_model.py:61-73), values and gradients."""
+    from torch.distributions import Normal, kl_divergence
+    from vae_gp_ode_amd import vae_ops as V
+    g = torch.Generator().manual_seed(5)
+    mu, logv, eps = torch.randn(N, q, generator=g), torch.randn(N, q, generator=g) * 0.7 - 1.0, torch.randn(N, q, generator=g)
+    L = 3
+    lh = -torch.rand(L, N, generator=g) * 500 - 100
+    klu, nobs = torch.tensor(12.5), 360.0
+    wz = torch.randn(N, q, generator=g)
+
+    def ref(mu, logv, lh, klu):
+        z = mu + torch.exp(0.5 * logv) * eps.to(mu)
+        klr = kl_divergence(Normal(mu, torch.exp(0.5 * logv)), Normal(torch.zeros(q, dtype=mu.dtype), torch.ones(q, dtype=mu.dtype))).sum(-1)
+        lhood, klreg = lh.mean(0).mean(), klr.mean()
+        return z, klr, torch.stack([-(lhood * nobs - klreg * nobs - klu), -lhood, klreg, klu])
+
+    a64 = [t.double().requires_grad_(True) for t in (mu, logv, lh, klu)]
+    z64, klr64, out64 = ref(*a64)
+    ((z64 * wz.double()).sum() + out64[0] + 0.3 * out64[2]).backward()
+    a = [t.cuda().requires_grad_(True) for t in (mu, logv, lh, klu)]
+    z = V.reparam(a[0], a[1], eps.cuda())
+    klr = V.normal_kl_rows(a[0], a[1])
+    out = V.elbo_terms(a[2], klr, a[3], nobs)
+    ((z * wz.cuda()).sum() + out[0] + 0.3 * out[2]).backward()
+    assert relerr(z, z64) < 1e-6 and relerr(klr, klr64) < 1e-5 and relerr(out, out64) < 1e-5
+    for x, y in zip(a, a64):
+        assert relerr(x.grad, y.grad) < 2e-5

@@ -432,6 +432,107 @@ int loglik_rowsum_bwd(const float* X, const float* z, const float* grow, float* 
   return check_launch("loglik_rowsum_bwd");
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// ELBO glue on (N, q)-sized tensors, one launch each instead of ~10 elementwise launches apiece:
+//   reparameterisation  z = mu + exp(logvar / 2) eps                                   (vae.py:75-78)
+//   KL(N(mu, sigma) || N(0, 1)) summed over the latent dimension, per sample          (create_model.py:47-49 via
+//       torch.distributions: 0.5 (sigma^2 + mu^2 - 1 - log sigma^2), sigma = exp(logvar / 2))
+//   loss = -(mean(lhood) n - mean(kl) n - kl_u), with the three logged terms           (create_model.py:61-73)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_reparam_fwd(const float* __restrict__ mu, const float* __restrict__ logvar, const float* __restrict__ eps,
+                              float* __restrict__ z, size_t n) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) z[e] = mu[e] + expf(0.5f * logvar[e]) * eps[e];
+}
+__global__ void k_reparam_bwd(const float* __restrict__ gz, const float* __restrict__ logvar, const float* __restrict__ eps,
+                              float* __restrict__ gmu, float* __restrict__ glogvar, size_t n) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const float g = gz[e];
+  gmu[e] = g;
+  glogvar[e] = g * eps[e] * (0.5f * expf(0.5f * logvar[e]));
+}
+// one thread per sample
+__global__ void k_normal_kl_fwd(const float* __restrict__ mu, const float* __restrict__ logvar, float* __restrict__ klrow, int N, int q) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int d = 0; d < q; ++d) {
+    const float m = mu[(size_t)n * q + d], sg = expf(0.5f * logvar[(size_t)n * q + d]);
+    const float vr = sg * sg;                        // var_ratio = (sigma_q / sigma_p)^2, t1 = mu^2 (torch/distributions/kl.py _kl_normal_normal)
+    acc += 0.5f * (vr + m * m - 1.f - logf(vr));
+  }
+  klrow[n] = acc;
+}
+__global__ void k_normal_kl_bwd(const float* __restrict__ grow, const float* __restrict__ mu, const float* __restrict__ logvar,
+                                float* __restrict__ gmu, float* __restrict__ glogvar, int N, int q) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)N * q) return;
+  const float g = grow[e / q];
+  gmu[e] = g * mu[e];
+  glogvar[e] = g * 0.5f * (expf(logvar[e]) - 1.f);
+}
+// out[0..3] = {loss, -mean lhood, mean kl, kl_u}; one workgroup
+__global__ __launch_bounds__(256) void k_elbo_fwd(const float* __restrict__ lhood, int nl, const float* __restrict__ klrow, int nk,
+                                                   const float* __restrict__ kl_u, float nobs, float* __restrict__ out) {
+  __shared__ float red[4][2];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < nl; i += 256) a += lhood[i];
+  for (int i = threadIdx.x; i < nk; i += 256) b += klrow[i];
+  const float in2[2] = {a, b};
+  float out2[2];
+  wave_sum_multi<2>(in2, out2);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = out2[0]; red[threadIdx.x >> 6][1] = out2[1]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float lh = ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) / (float)nl;
+    const float kr = ((red[0][1] + red[1][1]) + (red[2][1] + red[3][1])) / (float)nk;
+    const float ku = kl_u[0];
+    out[0] = -(lh * nobs - kr * nobs - ku);
+    out[1] = -lh;
+    out[2] = kr;
+    out[3] = ku;
+  }
+}
+// gout[0..3]: gradients w.r.t. the four outputs -> gradients of the likelihood rows, the KL rows and kl_u
+__global__ void k_elbo_bwd(const float* __restrict__ gout, int nl, int nk, float nobs, float* __restrict__ glhood,
+                           float* __restrict__ gklrow, float* __restrict__ gklu) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const float g0 = gout[0];
+  const float gl = (-g0 * nobs - gout[1]) / (float)nl;
+  const float gk = (g0 * nobs + gout[2]) / (float)nk;
+  if (e < nl) glhood[e] = gl;
+  if (e < nk) gklrow[e] = gk;
+  if (e == 0) gklu[0] = g0 + gout[3];
+}
+
+int reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_reparam_fwd, (unsigned)((n + 255) / 256), 256, 0, st, mu, logvar, eps, z, n);
+  return check_launch("reparam_fwd");
+}
+int reparam_bwd(const float* gz, const float* logvar, const float* eps, float* gmu, float* glogvar, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_reparam_bwd, (unsigned)((n + 255) / 256), 256, 0, st, gz, logvar, eps, gmu, glogvar, n);
+  return check_launch("reparam_bwd");
+}
+int normal_kl_fwd(const float* mu, const float* logvar, float* klrow, int N, int q, hipStream_t st) {
+  hipLaunchKernelGGL(k_normal_kl_fwd, (N + 255) / 256, 256, 0, st, mu, logvar, klrow, N, q);
+  return check_launch("normal_kl_fwd");
+}
+int normal_kl_bwd(const float* grow, const float* mu, const float* logvar, float* gmu, float* glogvar, int N, int q, hipStream_t st) {
+  hipLaunchKernelGGL(k_normal_kl_bwd, (unsigned)(((size_t)N * q + 255) / 256), 256, 0, st, grow, mu, logvar, gmu, glogvar, N, q);
+  return check_launch("normal_kl_bwd");
+}
+int elbo_fwd(const float* lhood, int nl, const float* klrow, int nk, const float* kl_u, float nobs, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_elbo_fwd, 1, 256, 0, st, lhood, nl, klrow, nk, kl_u, nobs, out);
+  return check_launch("elbo_fwd");
+}
+int elbo_bwd(const float* gout, int nl, int nk, float nobs, float* glhood, float* gklrow, float* gklu, hipStream_t st) {
+  const int n = nl > nk ? nl : nk;
+  hipLaunchKernelGGL(k_elbo_bwd, (n + 255) / 256, 256, 0, st, gout, nl, nk, nobs, glhood, gklrow, gklu);
+  return check_launch("elbo_bwd");
+}
+
 }  // namespace gp
 
 // ---------------------------------------------------------------------------------------------

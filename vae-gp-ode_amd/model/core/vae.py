@@ -50,12 +50,17 @@ class Encoder(nn.Module):
     def sample(self, mu, logvar):
         """Reparameterised draw (vae.py:75-78).  ``next_eps`` (if set) replaces the N(0,1) draw once --
         used for parity tests and for data-parallel runs that must share the draw."""
-        std = torch.exp(0.5 * logvar)
         eps = getattr(self, 'next_eps', None)
         if eps is None:
-            eps = torch.randn_like(std)
+            eps = torch.randn_like(mu)
         self.next_eps = None
-        return mu + std * eps.to(std)
+        return V.reparam(mu, logvar, eps.to(mu))     # mu + exp(logvar / 2) * eps, one launch
+
+    def kl_rows(self, mu_s, logvar_s, mu_v=None, logvar_v=None):
+        """kl_divergence(q_dist(...), N(0, I)).sum(-1) (create_model.py:47-49) without building the distributions: (N,)."""
+        if mu_v is not None:
+            mu_s, logvar_s = torch.cat((mu_s, mu_v), dim=1), torch.cat((logvar_s, logvar_v), dim=1)
+        return V.normal_kl_rows(mu_s, logvar_s)
 
     def q_dist(self, mu_s, logvar_s, mu_v=None, logvar_v=None):
         if mu_v is not None:

@@ -25,11 +25,14 @@ def elbo(model, X, Xrec, s0_mu, s0_logv, v0_mu, v0_logv, L):
 
 
 def compute_loss(model, data, L):
-    """-> (loss, nll, kl_reg, kl_u) (create_model.py:61-73)."""
+    """-> (loss, nll, kl_reg, kl_u) (create_model.py:61-73).  Same terms as elbo() above; the per-row pieces go through
+    three fused launches (KL rows, likelihood row sums, loss algebra) instead of ~25 elementwise ones."""
+    from .. import vae_ops as V
     Xrec, (s0_mu, s0_logv), (v0_mu, v0_logv) = model(data, L)
-    lhood, kl_reg, kl_gp = elbo(model, data, Xrec, s0_mu, s0_logv, v0_mu, v0_logv, L)
-    n = model.num_observations
-    return -(lhood * n - kl_reg * n - kl_gp), -lhood, kl_reg, kl_gp
+    kl_rows = model.vae.encoder.kl_rows(s0_mu, s0_logv, v0_mu, v0_logv)               # (N,)
+    lhood_rows = model.vae.decoder.log_prob_rowsum(data, Xrec, L)                     # (L, N)
+    out = V.elbo_terms(lhood_rows, kl_rows, model.flow.kl(), model.num_observations)
+    return out[0], out[1], out[2], out[3]
 
 
 def compute_test_error(X, Xrec):

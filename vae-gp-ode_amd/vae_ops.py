@@ -240,6 +240,78 @@ class _LogLikRowSum(torch.autograd.Function):
         return None, gz, None
 
 
+class _Reparam(torch.autograd.Function):
+    """z = mu + exp(logvar / 2) * eps (vae.py:75-78) in one launch."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        mu, logvar, eps = _chk(mu, 'mu'), _chk(logvar, 'logvar', mu.shape), _chk(eps, 'eps', mu.shape)
+        z = _new(mu.shape, mu)
+        _lib.call('gpode_reparam_fwd', _ptr(mu), _ptr(logvar), _ptr(eps), _ptr(z), mu.numel(), _stream())
+        ctx.save_for_backward(logvar, eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        logvar, eps = ctx.saved_tensors
+        gmu, glv = _new(logvar.shape, logvar), _new(logvar.shape, logvar)
+        _lib.call('gpode_reparam_bwd', _ptr(gz.contiguous()), _ptr(logvar), _ptr(eps), _ptr(gmu), _ptr(glv), logvar.numel(), _stream())
+        return gmu, glv, None
+
+
+class _NormalKL(torch.autograd.Function):
+    """sum_d KL(N(mu, exp(logvar/2)) || N(0, 1)) per row (what kl_divergence(q_dist, prior).sum(-1) evaluates, create_model.py:47-49)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        mu, logvar = _chk(mu, 'mu'), _chk(logvar, 'logvar', mu.shape)
+        N, q = mu.shape
+        out = _new((N,), mu)
+        _lib.call('gpode_normal_kl_fwd', _ptr(mu), _ptr(logvar), _ptr(out), N, q, _stream())
+        ctx.save_for_backward(mu, logvar)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, logvar = ctx.saved_tensors
+        N, q = mu.shape
+        gmu, glv = _new(mu.shape, mu), _new(mu.shape, mu)
+        _lib.call('gpode_normal_kl_bwd', _ptr(g.contiguous()), _ptr(mu), _ptr(logvar), _ptr(gmu), _ptr(glv), N, q, _stream())
+        return gmu, glv
+
+
+class _Elbo(torch.autograd.Function):
+    """(loss, -mean lhood, mean KL(z0), KL(u)) of create_model.py:61-73 from the per-row terms, one launch."""
+
+    @staticmethod
+    def forward(ctx, lhood, klrow, kl_u, nobs):
+        ctx.dims = (lhood.numel(), klrow.numel(), float(nobs), lhood.shape, klrow.shape, kl_u.shape)
+        lhood, klrow, kl_u = _chk(lhood, 'lhood'), _chk(klrow, 'klrow'), _chk(kl_u, 'kl_u')
+        out = _new((4,), lhood)
+        _lib.call('gpode_elbo_fwd', _ptr(lhood), lhood.numel(), _ptr(klrow), klrow.numel(), _ptr(kl_u), ctypes.c_float(nobs), _ptr(out), _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        nl, nk, nobs, sl, sk, su = ctx.dims
+        gl, gk, gu = _new(sl, gout), _new(sk, gout), _new(su, gout)
+        _lib.call('gpode_elbo_bwd', _ptr(gout.contiguous()), nl, nk, ctypes.c_float(nobs), _ptr(gl), _ptr(gk), _ptr(gu), _stream())
+        return gl, gk, gu, None
+
+
+def reparam(mu, logvar, eps):
+    return _Reparam.apply(mu, logvar, eps)
+
+
+def normal_kl_rows(mu, logvar):
+    return _NormalKL.apply(mu, logvar)
+
+
+def elbo_terms(lhood_rows, kl_rows, kl_u, nobs):
+    """-> tensor [loss, nll, kl_reg, kl_u] (views are taken by the caller)."""
+    return _Elbo.apply(lhood_rows, kl_rows, kl_u, float(nobs))
+
+
 def conv2d(x, w, b, stride, pad):
     return _Conv2d.apply(x, w, b, stride, pad)
 
