@@ -132,12 +132,13 @@ size_t gpode_conv_wgrad_scratch(int B, int Ci, int Co, int K);
 int gpode_conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci, int H, int W,
                             int Co, int K, int S, int P, int Ho, int Wo, void* stream);
 /* nn.BatchNorm2d in TRAINING mode (batch statistics), optional fused ReLU (vae.py:55-59,113-120).
- * running_* may be NULL (no update).  gx_chansum (optional, C floats): per-channel sum of gx, i.e. the bias gradient of the
+ * running_* may be NULL (no update); num_batches_tracked (optional, DEVICE int64 scalar, the module buffer) is incremented.
+ * gx_chansum (optional, C floats): per-channel sum of gx, i.e. the bias gradient of the
  * convolution that feeds this BatchNorm, produced while gx is written instead of by a separate pass. */
 size_t gpode_bn_scratch(int B, int C);
 int gpode_bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
-                 float* running_mean, float* running_var, float momentum, float eps, int B, int C, int HW, int relu,
-                 float* scratch, void* stream);
+                 float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, int B, int C,
+                 int HW, int relu, float* scratch, void* stream);
 int gpode_bn_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
                  const float* save_invstd, float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW,
                  int relu, float* scratch, void* stream);

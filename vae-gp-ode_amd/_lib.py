@@ -44,7 +44,7 @@ SIGNATURES.update({
     'gpode_conv_wgrad_scratch': (_sz, [_i, _i, _i, _i]),
     'gpode_conv2d_bwd_weight': (_i, [_c_float_p] * 5 + [_i] * 10 + [_vp]),
     'gpode_bn_scratch': (_sz, [_i, _i]),
-    'gpode_bn_fwd': (_i, [_c_float_p] * 8 + [_f, _f, _i, _i, _i, _i, _c_float_p, _vp]),
+    'gpode_bn_fwd': (_i, [_c_float_p] * 8 + [_vp, _f, _f, _i, _i, _i, _i, _c_float_p, _vp]),
     'gpode_bn_bwd': (_i, [_c_float_p] * 10 + [_i, _i, _i, _i, _c_float_p, _vp]),
     'gpode_bn_eval': (_i, [_c_float_p] * 6 + [_f, _c_float_p, _i, _i, _i, _i, _vp]),
     'gpode_chan_sum': (_i, [_c_float_p, _c_float_p, _i, _i, _i, _c_float_p, _vp]),

@@ -136,10 +136,11 @@ int gpode_conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* g
 }
 size_t gpode_bn_scratch(int B, int C) { return gp::bn_scratch(B, C); }
 int gpode_bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
-                 float* running_mean, float* running_var, float momentum, float eps, int B, int C, int HW, int relu,
-                 float* scratch, void* stream) {
+                 float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, int B, int C,
+                 int HW, int relu, float* scratch, void* stream) {
   if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !scratch) return gp::set_error("gpode_bn_fwd: null pointer");
-  return gp::bn_fwd(x, gamma, beta, y, save_mean, save_invstd, running_mean, running_var, momentum, eps, B, C, HW, relu, scratch, GP_ST);
+  return gp::bn_fwd(x, gamma, beta, y, save_mean, save_invstd, running_mean, running_var, num_batches_tracked, momentum, eps, B, C, HW, relu,
+                    scratch, GP_ST);
 }
 int gpode_bn_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
                  const float* save_invstd, float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW,

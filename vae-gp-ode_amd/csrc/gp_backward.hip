@@ -311,14 +311,26 @@ __global__ __launch_bounds__(256) void param_grad_df_kernel(const float* __restr
   }
 }
 
-// gpack[e] = sum_c slab[c][e] in fixed order
-__global__ void reduce_slab_kernel(const float* __restrict__ slab, int nchunk, size_t pack_floats, float* __restrict__ gpack,
-                                   int accumulate) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= pack_floats) return;
-  float acc = accumulate ? gpack[e] : 0.f;
-  for (int c = 0; c < nchunk; ++c) acc += slab[(size_t)c * pack_floats + e];
-  gpack[e] = acc;
+// gpack[e] = sum_c slab[c][e] in a fixed order: 16 interleaved partial sums per element (independent load streams),
+// combined through LDS.  grid = ceil(pack_floats / 64), block = 1024 (64 elements x 16 chunk groups).
+__global__ __launch_bounds__(1024) void reduce_slab_kernel(const float* __restrict__ slab, int nchunk, size_t pack_floats,
+                                                            float* __restrict__ gpack, int accumulate) {
+  __shared__ float red[16][64];
+  const int ex = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const size_t e = (size_t)blockIdx.x * 64 + ex;
+  float acc = 0.f;
+  if (e < pack_floats) {
+#pragma unroll 8
+    for (int c = cg; c < nchunk; c += 16) acc += slab[(size_t)c * pack_floats + e];
+  }
+  red[cg][ex] = acc;
+  __syncthreads();
+  if (cg == 0 && e < pack_floats) {
+    float v = accumulate ? gpack[e] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v += red[g][ex];
+    gpack[e] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -424,7 +436,7 @@ int param_grad(int kernel, int Di, int Do, int M, int S, const float* pack, cons
     if (!RbfTeamEval<p, q, 1>::fits(M, S)) return set_error("gpode_param_grad: S=%d M=%d too large for the team mapping", S, M); \
     hipLaunchKernelGGL((param_grad_rbf_kernel<p, q, 1>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only); \
     if (check_launch("param_grad_rbf")) return 1;                                                                           \
-    hipLaunchKernelGGL(reduce_slab_kernel, cdiv((int)pf, 256), 256, 0, st, slab, used, pf, gpack, accumulate);              \
+    hipLaunchKernelGGL(reduce_slab_kernel, cdiv((int)pf, 64), 1024, 0, st, slab, used, pf, gpack, accumulate);              \
     return check_launch("reduce_slab");                                                                                      \
   }
     GP_BWD_RBF_DIMS(X)
@@ -435,7 +447,7 @@ int param_grad(int kernel, int Di, int Do, int M, int S, const float* pack, cons
     if (!DfTeamEval<p, 1>::fits(M, S)) return set_error("gpode_param_grad: S=%d M=%d too large for the team mapping", S, M);  \
     hipLaunchKernelGGL((param_grad_df_kernel<p, 1>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only);   \
     if (check_launch("param_grad_df")) return 1;                                                                            \
-    hipLaunchKernelGGL(reduce_slab_kernel, cdiv((int)pf, 256), 256, 0, st, slab, used, pf, gpack, accumulate);              \
+    hipLaunchKernelGGL(reduce_slab_kernel, cdiv((int)pf, 64), 1024, 0, st, slab, used, pf, gpack, accumulate);              \
     return check_launch("reduce_slab");                                                                                      \
   }
     GP_BWD_DF_DIMS(X)

@@ -79,8 +79,8 @@ int conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, 
                       int K, int S, int P, int Ho, int Wo, hipStream_t st);
 size_t bn_scratch(int B, int C);
 int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
-           float* running_mean, float* running_var, float momentum, float eps, int B, int C, int HW, int relu,
-           float* scratch, hipStream_t st);
+           float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, int B, int C, int HW,
+           int relu, float* scratch, hipStream_t st);
 int bn_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
            float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW, int relu, float* scratch, hipStream_t st);
 int bn_eval(const float* x, const float* gy, const float* gamma, const float* beta, const float* running_mean, const float* running_var,

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void k_bn_stats(const float* __restrict__ x, i
 __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ part, const float* __restrict__ shift, int nsplit, float count,
                                                    float eps, float momentum, float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                   float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ y,
+                                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                   long long* __restrict__ num_batches_tracked, float* __restrict__ y,
                                                    int B, int C, int HW, int bps, int relu) {
   const int c = blockIdx.x, b0 = blockIdx.y * bps, nb = min(B, b0 + bps) - b0;
   float s0, s1;
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
       running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count / (count - 1.f));
     }
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
   }
   const float g = gamma[c], bt = beta[c];
   const float lo = relu ? 0.f : -INFINITY;
@@ -262,14 +264,14 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 size_t bn_scratch(int B, int C) { return (size_t)(B < 64 ? B : 64) * C * 4 + (size_t)C * 3; }
 
 int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
-           float* running_mean, float* running_var, float momentum, float eps, int B, int C, int HW, int relu,
-           float* scratch, hipStream_t st) {
+           float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, int B, int C, int HW,
+           int relu, float* scratch, hipStream_t st) {
   if ((HW & 3) == 0 && !(aligned16(x) && aligned16(y))) return set_error("gpode_bn_fwd: x / y must be 16-byte aligned");
   const Split sp = pick(B);
   float* shift = scratch + (size_t)sp.ns * C * 2 + (size_t)C * 2;
   hipLaunchKernelGGL(k_bn_stats, dim3(C, sp.used), 256, 0, st, x, B, C, HW, sp.bps, scratch, shift);
   hipLaunchKernelGGL(k_bn_apply, dim3(C, sp.used), 256, 0, st, x, gamma, beta, scratch, shift, sp.used, (float)B * HW, eps, momentum, save_mean,
-                     save_invstd, running_mean, running_var, y, B, C, HW, sp.bps, relu);
+                     save_invstd, running_mean, running_var, num_batches_tracked, y, B, C, HW, sp.bps, relu);
   return check_launch("bn_fwd");
 }
 

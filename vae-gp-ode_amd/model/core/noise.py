@@ -49,7 +49,13 @@ class DeviceNoise:
             self._gen.manual_seed(self.seed)
         sh = draw_shapes(kernel, Di, Do, M, S, dimwise)
         g = self._gen
-        return dict(rff_w=torch.randn(sh['rff_w'], generator=g, device=device),
-                    rff_eps=torch.randn(sh['rff_eps'], generator=g, device=device),
-                    rff_u=torch.rand(sh['rff_u'], generator=g, device=device),
-                    eps_u=torch.randn(sh['eps_u'], generator=g, device=device))
+        # one launch for all normal draws (the three tensors are contiguous slices of one buffer), one for the uniform phase
+        names = ('rff_w', 'rff_eps', 'eps_u')
+        sizes = [int(np.prod(sh[k])) for k in names]
+        flat = torch.randn(sum(sizes), generator=g, device=device)
+        out, o = {}, 0
+        for k, n in zip(names, sizes):
+            out[k] = flat[o:o + n].view(sh[k])
+            o += n
+        out['rff_u'] = torch.rand(sh['rff_u'], generator=g, device=device)
+        return out

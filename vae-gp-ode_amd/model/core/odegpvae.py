@@ -21,7 +21,12 @@ class ODEGPVAE(nn.Module):
 
     def sample_trajectories(self, z0, T, L=1):
         """L independent function draws, each shared by the whole minibatch (odegpvae.py:37-45)."""
-        ts = self.dt * torch.arange(T, dtype=torch.float, device=z0.device)
+        key = (T, str(z0.device))
+        if getattr(self, '_ts_key', None) != key:            # the grid dt * arange(T) is a constant of the run: build it once
+            self._ts, self._ts_key = self.dt * torch.arange(T, dtype=torch.float, device=z0.device), key
+        ts = self._ts
+        if L == 1:
+            return self.flow(z0, ts).unsqueeze(0)
         return torch.stack([self.flow(z0, ts) for _ in range(L)], 0)
 
     def forward(self, X, L=1, T_custom=None):

@@ -108,14 +108,16 @@ class _ConvT2d(torch.autograd.Function):
 
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, nbt=None):
         x = _chk(x, 'x')
         B, C = x.shape[0], x.shape[1]
         HW = x[0, 0].numel()
         y = _new(x.shape, x)
         mean, invstd = _new((C,), x), _new((C,), x)
+        if nbt is not None and not (nbt.is_cuda and nbt.dtype == torch.int64):
+            raise _lib.GpodeError('num_batches_tracked must be an int64 CUDA/HIP scalar')
         _lib.call('gpode_bn_fwd', _ptr(x), _ptr(_chk(gamma, 'gamma')), _ptr(_chk(beta, 'beta')), _ptr(y), _ptr(mean), _ptr(invstd),
-                  _ptr(running_mean), _ptr(running_var), ctypes.c_float(momentum), ctypes.c_float(eps), B, C, HW, int(relu),
+                  _ptr(running_mean), _ptr(running_var), _ptr(nbt), ctypes.c_float(momentum), ctypes.c_float(eps), B, C, HW, int(relu),
                   _ptr(_bn_scratch(B, C, x)), _stream())
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         ctx.relu = int(relu)
@@ -131,7 +133,7 @@ class _BatchNormTrain(torch.autograd.Function):
                   _ptr(gb), _ptr(cs), B, C, HW, ctx.relu, _ptr(_bn_scratch(B, C, x)), _stream())
         # the channel sums of gx ride along with it: the convolution that produced x needs exactly these as its bias gradient
         gx._gpode_chansum = cs
-        return gx, gg, gb, None, None, None, None, None
+        return gx, gg, gb, None, None, None, None, None, None
 
 
 class _BatchNormEval(torch.autograd.Function):
@@ -322,12 +324,10 @@ def conv_transpose2d(x, w, b, stride, pad, out_pad=0):
 
 def batch_norm_train(x, bn, relu):
     """nn.BatchNorm2d in training mode on the module's own parameters/buffers (updates running stats)."""
-    if bn.training:
-        with torch.no_grad():
-            bn.num_batches_tracked += 1
-    y = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean if bn.training else None,
-                              bn.running_var if bn.training else None, bn.momentum, bn.eps, relu)
-    return y
+    # running statistics and the num_batches_tracked counter are updated by the kernel itself (one launch less per layer)
+    return _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean if bn.training else None,
+                                 bn.running_var if bn.training else None, bn.momentum, bn.eps, relu,
+                                 bn.num_batches_tracked if bn.training else None)
 
 
 def batch_norm_eval(x, bn, relu):
