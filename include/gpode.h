@@ -164,14 +164,18 @@ int gpode_loglik_rowsum_bwd(const float* X, const float* z, const float* grow, f
                             void* stream);
 
 /* ELBO glue on (N,q)-sized tensors (one launch each):
+ *   mu / logvar are (N,q) with row stride ld (ld = 2q: the two halves of the encoder's fc output, vae.py:74), gradients
+ *   are written with row stride ldg;
  *   reparameterisation z = mu + exp(logvar/2) eps (vae.py:75-78) and its backward;
  *   klrow[n] = sum_d KL(N(mu, exp(logvar/2)) || N(0,1)) (create_model.py:47-49, torch.distributions closed form) and its backward;
  *   out[4] = {loss = -(mean(lhood) nobs - mean(klrow) nobs - kl_u), -mean(lhood), mean(klrow), kl_u} (create_model.py:61-73);
  *   backward: gout[4] (gradients of the four outputs) -> glhood[nl], gklrow[nk], gklu[1]. */
-int gpode_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, size_t n, void* stream);
-int gpode_reparam_bwd(const float* gz, const float* logvar, const float* eps, float* gmu, float* glogvar, size_t n, void* stream);
-int gpode_normal_kl_fwd(const float* mu, const float* logvar, float* klrow, int N, int q, void* stream);
-int gpode_normal_kl_bwd(const float* grow, const float* mu, const float* logvar, float* gmu, float* glogvar, int N, int q, void* stream);
+int gpode_reparam_fwd(const float* mu, const float* logvar, int ld, const float* eps, float* z, int N, int q, void* stream);
+int gpode_reparam_bwd(const float* gz, const float* logvar, int ld, const float* eps, float* gmu, float* glogvar, int ldg, int N, int q,
+                      void* stream);
+int gpode_normal_kl_fwd(const float* mu, const float* logvar, int ld, float* klrow, int N, int q, void* stream);
+int gpode_normal_kl_bwd(const float* grow, const float* mu, const float* logvar, int ld, float* gmu, float* glogvar, int ldg, int N, int q,
+                        void* stream);
 int gpode_elbo_fwd(const float* lhood, int nl, const float* klrow, int nk, const float* kl_u, float nobs, float* out, void* stream);
 int gpode_elbo_bwd(const float* gout, int nl, int nk, float nobs, float* glhood, float* gklrow, float* gklu, void* stream);
 

@@ -55,10 +55,10 @@ SIGNATURES.update({
     'gpode_loglik_fwd': (_i, [_c_float_p] * 3 + [_sz, _sz, _vp]),
     'gpode_loglik_bwd': (_i, [_c_float_p] * 4 + [_sz, _sz, _vp]),
     'gpode_loglik_rowsum_fwd': (_i, [_c_float_p] * 3 + [_sz, _sz, _sz, _vp]),
-    'gpode_reparam_fwd': (_i, [_c_float_p] * 4 + [_sz, _vp]),
-    'gpode_reparam_bwd': (_i, [_c_float_p] * 5 + [_sz, _vp]),
-    'gpode_normal_kl_fwd': (_i, [_c_float_p] * 3 + [_i, _i, _vp]),
-    'gpode_normal_kl_bwd': (_i, [_c_float_p] * 5 + [_i, _i, _vp]),
+    'gpode_reparam_fwd': (_i, [_c_float_p, _c_float_p, _i, _c_float_p, _c_float_p, _i, _i, _vp]),
+    'gpode_reparam_bwd': (_i, [_c_float_p, _c_float_p, _i, _c_float_p, _c_float_p, _c_float_p, _i, _i, _i, _vp]),
+    'gpode_normal_kl_fwd': (_i, [_c_float_p, _c_float_p, _i, _c_float_p, _i, _i, _vp]),
+    'gpode_normal_kl_bwd': (_i, [_c_float_p, _c_float_p, _c_float_p, _i, _c_float_p, _c_float_p, _i, _i, _i, _vp]),
     'gpode_elbo_fwd': (_i, [_c_float_p, _i, _c_float_p, _i, _c_float_p, _f, _c_float_p, _vp]),
     'gpode_elbo_bwd': (_i, [_c_float_p, _i, _i, _f, _c_float_p, _c_float_p, _c_float_p, _vp]),
     'gpode_adam_multi': (_i, [_vp, _vp, _vp, _vp, _vp, _i, ctypes.c_longlong, _f, _f, _f, _f, _i, _vp, _vp]),

@@ -180,25 +180,27 @@ int gpode_loglik_rowsum_bwd(const float* X, const float* z, const float* grow, f
                             void* stream) {
   return gp::loglik_rowsum_bwd(X, z, grow, gz, rows, inner, nX, GP_ST);
 }
-int gpode_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, size_t n, void* stream) {
-  if (n == 0) return 0;
-  if (!mu || !logvar || !eps || !z) return gp::set_error("gpode_reparam_fwd: null pointer");
-  return gp::reparam_fwd(mu, logvar, eps, z, n, GP_ST);
-}
-int gpode_reparam_bwd(const float* gz, const float* logvar, const float* eps, float* gmu, float* glogvar, size_t n, void* stream) {
-  if (n == 0) return 0;
-  if (!gz || !logvar || !eps || !gmu || !glogvar) return gp::set_error("gpode_reparam_bwd: null pointer");
-  return gp::reparam_bwd(gz, logvar, eps, gmu, glogvar, n, GP_ST);
-}
-int gpode_normal_kl_fwd(const float* mu, const float* logvar, float* klrow, int N, int q, void* stream) {
+int gpode_reparam_fwd(const float* mu, const float* logvar, int ld, const float* eps, float* z, int N, int q, void* stream) {
   if (N == 0) return 0;
-  if (!mu || !logvar || !klrow || q < 1) return gp::set_error("gpode_normal_kl_fwd: bad argument");
-  return gp::normal_kl_fwd(mu, logvar, klrow, N, q, GP_ST);
+  if (!mu || !logvar || !eps || !z || q < 1 || ld < q) return gp::set_error("gpode_reparam_fwd: bad argument");
+  return gp::reparam_fwd(mu, logvar, ld, eps, z, N, q, GP_ST);
 }
-int gpode_normal_kl_bwd(const float* grow, const float* mu, const float* logvar, float* gmu, float* glogvar, int N, int q, void* stream) {
+int gpode_reparam_bwd(const float* gz, const float* logvar, int ld, const float* eps, float* gmu, float* glogvar, int ldg, int N, int q,
+                      void* stream) {
   if (N == 0) return 0;
-  if (!grow || !mu || !logvar || !gmu || !glogvar || q < 1) return gp::set_error("gpode_normal_kl_bwd: bad argument");
-  return gp::normal_kl_bwd(grow, mu, logvar, gmu, glogvar, N, q, GP_ST);
+  if (!gz || !logvar || !eps || !gmu || !glogvar || q < 1 || ld < q || ldg < q) return gp::set_error("gpode_reparam_bwd: bad argument");
+  return gp::reparam_bwd(gz, logvar, ld, eps, gmu, glogvar, ldg, N, q, GP_ST);
+}
+int gpode_normal_kl_fwd(const float* mu, const float* logvar, int ld, float* klrow, int N, int q, void* stream) {
+  if (N == 0) return 0;
+  if (!mu || !logvar || !klrow || q < 1 || ld < q) return gp::set_error("gpode_normal_kl_fwd: bad argument");
+  return gp::normal_kl_fwd(mu, logvar, ld, klrow, N, q, GP_ST);
+}
+int gpode_normal_kl_bwd(const float* grow, const float* mu, const float* logvar, int ld, float* gmu, float* glogvar, int ldg, int N, int q,
+                        void* stream) {
+  if (N == 0) return 0;
+  if (!grow || !mu || !logvar || !gmu || !glogvar || q < 1 || ld < q || ldg < q) return gp::set_error("gpode_normal_kl_bwd: bad argument");
+  return gp::normal_kl_bwd(grow, mu, logvar, ld, gmu, glogvar, ldg, N, q, GP_ST);
 }
 int gpode_elbo_fwd(const float* lhood, int nl, const float* klrow, int nk, const float* kl_u, float nobs, float* out, void* stream) {
   if (!lhood || !klrow || !kl_u || !out || nl < 1 || nk < 1) return gp::set_error("gpode_elbo_fwd: bad argument");

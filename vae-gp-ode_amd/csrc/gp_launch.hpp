@@ -94,10 +94,10 @@ int loglik_fwd(const float* X, const float* z, float* ll, size_t n, size_t nX, h
 int loglik_bwd(const float* X, const float* z, const float* g, float* gz, size_t n, size_t nX, hipStream_t st);
 int loglik_rowsum_fwd(const float* X, const float* z, float* out, size_t rows, size_t inner, size_t nX, hipStream_t st);
 int loglik_rowsum_bwd(const float* X, const float* z, const float* grow, float* gz, size_t rows, size_t inner, size_t nX, hipStream_t st);
-int reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, size_t n, hipStream_t st);
-int reparam_bwd(const float* gz, const float* logvar, const float* eps, float* gmu, float* glogvar, size_t n, hipStream_t st);
-int normal_kl_fwd(const float* mu, const float* logvar, float* klrow, int N, int q, hipStream_t st);
-int normal_kl_bwd(const float* grow, const float* mu, const float* logvar, float* gmu, float* glogvar, int N, int q, hipStream_t st);
+int reparam_fwd(const float* mu, const float* logvar, int ld, const float* eps, float* z, int N, int q, hipStream_t st);
+int reparam_bwd(const float* gz, const float* logvar, int ld, const float* eps, float* gmu, float* glogvar, int ldg, int N, int q, hipStream_t st);
+int normal_kl_fwd(const float* mu, const float* logvar, int ld, float* klrow, int N, int q, hipStream_t st);
+int normal_kl_bwd(const float* grow, const float* mu, const float* logvar, int ld, float* gmu, float* glogvar, int ldg, int N, int q, hipStream_t st);
 int elbo_fwd(const float* lhood, int nl, const float* klrow, int nk, const float* kl_u, float nobs, float* out, hipStream_t st);
 int elbo_bwd(const float* gout, int nl, int nk, float nobs, float* glhood, float* gklrow, float* gklu, hipStream_t st);
 int adam_multi(float* const* params, const float* const* grads, float* const* m1, float* const* m2, const long long* offs,

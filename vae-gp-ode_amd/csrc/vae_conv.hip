@@ -440,38 +440,45 @@ int loglik_rowsum_bwd(const float* X, const float* z, const float* grow, float* 
 //       torch.distributions: 0.5 (sigma^2 + mu^2 - 1 - log sigma^2), sigma = exp(logvar / 2))
 //   loss = -(mean(lhood) n - mean(kl) n - kl_u), with the three logged terms           (create_model.py:61-73)
 // ---------------------------------------------------------------------------------------------
-__global__ void k_reparam_fwd(const float* __restrict__ mu, const float* __restrict__ logvar, const float* __restrict__ eps,
-                              float* __restrict__ z, size_t n) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n) z[e] = mu[e] + expf(0.5f * logvar[e]) * eps[e];
+// mu / logvar: (N, q) with row stride ld (ld = q: separate tensors; ld = 2q: the two halves of the encoder's fc output);
+// gradients go to gmu / glogvar with row stride ldg
+__global__ void k_reparam_fwd(const float* __restrict__ mu, const float* __restrict__ logvar, int ld, const float* __restrict__ eps,
+                              float* __restrict__ z, int N, int q) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * q) return;
+  const int n = e / q, d = e % q;
+  z[e] = mu[(size_t)n * ld + d] + expf(0.5f * logvar[(size_t)n * ld + d]) * eps[e];
 }
-__global__ void k_reparam_bwd(const float* __restrict__ gz, const float* __restrict__ logvar, const float* __restrict__ eps,
-                              float* __restrict__ gmu, float* __restrict__ glogvar, size_t n) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
+__global__ void k_reparam_bwd(const float* __restrict__ gz, const float* __restrict__ logvar, int ld, const float* __restrict__ eps,
+                              float* __restrict__ gmu, float* __restrict__ glogvar, int ldg, int N, int q) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * q) return;
+  const int n = e / q, d = e % q;
   const float g = gz[e];
-  gmu[e] = g;
-  glogvar[e] = g * eps[e] * (0.5f * expf(0.5f * logvar[e]));
+  gmu[(size_t)n * ldg + d] = g;
+  glogvar[(size_t)n * ldg + d] = g * eps[e] * (0.5f * expf(0.5f * logvar[(size_t)n * ld + d]));
 }
 // one thread per sample
-__global__ void k_normal_kl_fwd(const float* __restrict__ mu, const float* __restrict__ logvar, float* __restrict__ klrow, int N, int q) {
+__global__ void k_normal_kl_fwd(const float* __restrict__ mu, const float* __restrict__ logvar, int ld, float* __restrict__ klrow, int N,
+                                int q) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float acc = 0.f;
   for (int d = 0; d < q; ++d) {
-    const float m = mu[(size_t)n * q + d], sg = expf(0.5f * logvar[(size_t)n * q + d]);
+    const float m = mu[(size_t)n * ld + d], sg = expf(0.5f * logvar[(size_t)n * ld + d]);
     const float vr = sg * sg;                        // var_ratio = (sigma_q / sigma_p)^2, t1 = mu^2 (torch/distributions/kl.py _kl_normal_normal)
     acc += 0.5f * (vr + m * m - 1.f - logf(vr));
   }
   klrow[n] = acc;
 }
-__global__ void k_normal_kl_bwd(const float* __restrict__ grow, const float* __restrict__ mu, const float* __restrict__ logvar,
-                                float* __restrict__ gmu, float* __restrict__ glogvar, int N, int q) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (size_t)N * q) return;
-  const float g = grow[e / q];
-  gmu[e] = g * mu[e];
-  glogvar[e] = g * 0.5f * (expf(logvar[e]) - 1.f);
+__global__ void k_normal_kl_bwd(const float* __restrict__ grow, const float* __restrict__ mu, const float* __restrict__ logvar, int ld,
+                                float* __restrict__ gmu, float* __restrict__ glogvar, int ldg, int N, int q) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * q) return;
+  const int n = e / q, d = e % q;
+  const float g = grow[n];
+  gmu[(size_t)n * ldg + d] = g * mu[(size_t)n * ld + d];
+  glogvar[(size_t)n * ldg + d] = g * 0.5f * (expf(logvar[(size_t)n * ld + d]) - 1.f);
 }
 // out[0..3] = {loss, -mean lhood, mean kl, kl_u}; one workgroup
 __global__ __launch_bounds__(256) void k_elbo_fwd(const float* __restrict__ lhood, int nl, const float* __restrict__ klrow, int nk,
@@ -507,20 +514,22 @@ __global__ void k_elbo_bwd(const float* __restrict__ gout, int nl, int nk, float
   if (e == 0) gklu[0] = g0 + gout[3];
 }
 
-int reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, size_t n, hipStream_t st) {
-  hipLaunchKernelGGL(k_reparam_fwd, (unsigned)((n + 255) / 256), 256, 0, st, mu, logvar, eps, z, n);
+int reparam_fwd(const float* mu, const float* logvar, int ld, const float* eps, float* z, int N, int q, hipStream_t st) {
+  hipLaunchKernelGGL(k_reparam_fwd, (N * q + 255) / 256, 256, 0, st, mu, logvar, ld, eps, z, N, q);
   return check_launch("reparam_fwd");
 }
-int reparam_bwd(const float* gz, const float* logvar, const float* eps, float* gmu, float* glogvar, size_t n, hipStream_t st) {
-  hipLaunchKernelGGL(k_reparam_bwd, (unsigned)((n + 255) / 256), 256, 0, st, gz, logvar, eps, gmu, glogvar, n);
+int reparam_bwd(const float* gz, const float* logvar, int ld, const float* eps, float* gmu, float* glogvar, int ldg, int N, int q,
+                hipStream_t st) {
+  hipLaunchKernelGGL(k_reparam_bwd, (N * q + 255) / 256, 256, 0, st, gz, logvar, ld, eps, gmu, glogvar, ldg, N, q);
   return check_launch("reparam_bwd");
 }
-int normal_kl_fwd(const float* mu, const float* logvar, float* klrow, int N, int q, hipStream_t st) {
-  hipLaunchKernelGGL(k_normal_kl_fwd, (N + 255) / 256, 256, 0, st, mu, logvar, klrow, N, q);
+int normal_kl_fwd(const float* mu, const float* logvar, int ld, float* klrow, int N, int q, hipStream_t st) {
+  hipLaunchKernelGGL(k_normal_kl_fwd, (N + 255) / 256, 256, 0, st, mu, logvar, ld, klrow, N, q);
   return check_launch("normal_kl_fwd");
 }
-int normal_kl_bwd(const float* grow, const float* mu, const float* logvar, float* gmu, float* glogvar, int N, int q, hipStream_t st) {
-  hipLaunchKernelGGL(k_normal_kl_bwd, (unsigned)(((size_t)N * q + 255) / 256), 256, 0, st, grow, mu, logvar, gmu, glogvar, N, q);
+int normal_kl_bwd(const float* grow, const float* mu, const float* logvar, int ld, float* gmu, float* glogvar, int ldg, int N, int q,
+                  hipStream_t st) {
+  hipLaunchKernelGGL(k_normal_kl_bwd, (N * q + 255) / 256, 256, 0, st, grow, mu, logvar, ld, gmu, glogvar, ldg, N, q);
   return check_launch("normal_kl_bwd");
 }
 int elbo_fwd(const float* lhood, int nl, const float* klrow, int nk, const float* kl_u, float nobs, float* out, hipStream_t st) {

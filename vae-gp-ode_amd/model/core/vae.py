@@ -58,9 +58,8 @@ class Encoder(nn.Module):
 
     def kl_rows(self, mu_s, logvar_s, mu_v=None, logvar_v=None):
         """kl_divergence(q_dist(...), N(0, I)).sum(-1) (create_model.py:47-49) without building the distributions: (N,)."""
-        if mu_v is not None:
-            mu_s, logvar_s = torch.cat((mu_s, mu_v), dim=1), torch.cat((logvar_s, logvar_v), dim=1)
-        return V.normal_kl_rows(mu_s, logvar_s)
+        kl = V.normal_kl_rows(mu_s, logvar_s)         # the KL of a factorised Gaussian is additive over (s, v)
+        return kl if mu_v is None else kl + V.normal_kl_rows(mu_v, logvar_v)
 
     def q_dist(self, mu_s, logvar_s, mu_v=None, logvar_v=None):
         if mu_v is not None:

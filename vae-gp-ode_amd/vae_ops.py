@@ -242,44 +242,64 @@ class _LogLikRowSum(torch.autograd.Function):
         return None, gz, None
 
 
+def _packed_halves(mu, logvar):
+    """If (mu, logvar) are the two column halves of one contiguous (N, 2q) tensor (Encoder.forward returns fc(h).chunk(2)),
+    return that tensor: the kernels then read both halves in place and produce ONE gradient for it."""
+    base = getattr(mu, '_base', None)
+    if base is None or getattr(logvar, '_base', None) is not base or base.dim() != 2 or not base.is_contiguous():
+        return None
+    N, q = mu.shape
+    if tuple(base.shape) != (N, 2 * q) or mu.stride() != (2 * q, 1) or logvar.stride() != (2 * q, 1):
+        return None
+    if mu.data_ptr() != base.data_ptr() or logvar.data_ptr() != base.data_ptr() + 4 * q:
+        return None
+    return base
+
+
 class _Reparam(torch.autograd.Function):
-    """z = mu + exp(logvar / 2) * eps (vae.py:75-78) in one launch."""
+    """z = mu + exp(logvar / 2) * eps (vae.py:75-78) in one launch; h = [mu | logvar] packed (N, 2q)."""
 
     @staticmethod
-    def forward(ctx, mu, logvar, eps):
-        mu, logvar, eps = _chk(mu, 'mu'), _chk(logvar, 'logvar', mu.shape), _chk(eps, 'eps', mu.shape)
-        z = _new(mu.shape, mu)
-        _lib.call('gpode_reparam_fwd', _ptr(mu), _ptr(logvar), _ptr(eps), _ptr(z), mu.numel(), _stream())
-        ctx.save_for_backward(logvar, eps)
+    def forward(ctx, h, eps):
+        h = _chk(h, 'h')
+        N, q = h.shape[0], h.shape[1] // 2
+        eps = _chk(eps, 'eps', (N, q))
+        z = _new((N, q), h)
+        _lib.call('gpode_reparam_fwd', _ptr(h), ctypes.c_void_p(h.data_ptr() + 4 * q), 2 * q, _ptr(eps), _ptr(z), N, q, _stream())
+        ctx.save_for_backward(h, eps)
         return z
 
     @staticmethod
     def backward(ctx, gz):
-        logvar, eps = ctx.saved_tensors
-        gmu, glv = _new(logvar.shape, logvar), _new(logvar.shape, logvar)
-        _lib.call('gpode_reparam_bwd', _ptr(gz.contiguous()), _ptr(logvar), _ptr(eps), _ptr(gmu), _ptr(glv), logvar.numel(), _stream())
-        return gmu, glv, None
+        h, eps = ctx.saved_tensors
+        N, q = h.shape[0], h.shape[1] // 2
+        g = _new(h.shape, h)
+        _lib.call('gpode_reparam_bwd', _ptr(gz.contiguous()), ctypes.c_void_p(h.data_ptr() + 4 * q), 2 * q, _ptr(eps), _ptr(g),
+                  ctypes.c_void_p(g.data_ptr() + 4 * q), 2 * q, N, q, _stream())
+        return g, None
 
 
 class _NormalKL(torch.autograd.Function):
-    """sum_d KL(N(mu, exp(logvar/2)) || N(0, 1)) per row (what kl_divergence(q_dist, prior).sum(-1) evaluates, create_model.py:47-49)."""
+    """sum_d KL(N(mu, exp(logvar/2)) || N(0, 1)) per row (what kl_divergence(q_dist, prior).sum(-1) evaluates,
+    create_model.py:47-49); h = [mu | logvar] packed (N, 2q)."""
 
     @staticmethod
-    def forward(ctx, mu, logvar):
-        mu, logvar = _chk(mu, 'mu'), _chk(logvar, 'logvar', mu.shape)
-        N, q = mu.shape
-        out = _new((N,), mu)
-        _lib.call('gpode_normal_kl_fwd', _ptr(mu), _ptr(logvar), _ptr(out), N, q, _stream())
-        ctx.save_for_backward(mu, logvar)
+    def forward(ctx, h):
+        h = _chk(h, 'h')
+        N, q = h.shape[0], h.shape[1] // 2
+        out = _new((N,), h)
+        _lib.call('gpode_normal_kl_fwd', _ptr(h), ctypes.c_void_p(h.data_ptr() + 4 * q), 2 * q, _ptr(out), N, q, _stream())
+        ctx.save_for_backward(h)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        mu, logvar = ctx.saved_tensors
-        N, q = mu.shape
-        gmu, glv = _new(mu.shape, mu), _new(mu.shape, mu)
-        _lib.call('gpode_normal_kl_bwd', _ptr(g.contiguous()), _ptr(mu), _ptr(logvar), _ptr(gmu), _ptr(glv), N, q, _stream())
-        return gmu, glv
+        (h,) = ctx.saved_tensors
+        N, q = h.shape[0], h.shape[1] // 2
+        gh = _new(h.shape, h)
+        _lib.call('gpode_normal_kl_bwd', _ptr(g.contiguous()), _ptr(h), ctypes.c_void_p(h.data_ptr() + 4 * q), 2 * q, _ptr(gh),
+                  ctypes.c_void_p(gh.data_ptr() + 4 * q), 2 * q, N, q, _stream())
+        return gh
 
 
 class _Elbo(torch.autograd.Function):
@@ -301,12 +321,17 @@ class _Elbo(torch.autograd.Function):
         return gl, gk, gu, None
 
 
+def _pack(mu, logvar):
+    h = _packed_halves(mu, logvar)
+    return h if h is not None else torch.cat((mu, logvar), dim=1)
+
+
 def reparam(mu, logvar, eps):
-    return _Reparam.apply(mu, logvar, eps)
+    return _Reparam.apply(_pack(mu, logvar), eps)
 
 
 def normal_kl_rows(mu, logvar):
-    return _NormalKL.apply(mu, logvar)
+    return _NormalKL.apply(_pack(mu, logvar))
 
 
 def elbo_terms(lhood_rows, kl_rows, kl_u, nobs):
