@@ -128,9 +128,17 @@ int gpode_conv2d_fwd(const float* x, const float* w, const float* bias, float* y
                      int K, int S, int P, int Ho, int Wo, void* stream);
 int gpode_conv2d_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co,
                           int K, int S, int P, int Ho, int Wo, void* stream);
+/* The same with the BatchNorm + ReLU that precedes the ConvTranspose2d folded into its input staging: gy is the RAW output of the
+ * previous layer, gy_bn its per-channel table {mean, invstd, gamma, beta} from gpode_bn_stats; the normalised activation is
+ * never written to memory (vae.py:113-120: ConvTranspose2d -> BatchNorm2d -> ReLU -> ConvTranspose2d).  Matrix-core
+ * specialisations only (decnn.4/7/10); other geometries return an error. */
+int gpode_conv2d_bwd_data_bn(const float* gy, const float* gy_bn, const float* w, const float* bias, float* gx, int B, int Ci, int H,
+                             int W, int Co, int K, int S, int P, int Ho, int Wo, void* stream);
 size_t gpode_conv_wgrad_scratch(int B, int Ci, int Co, int K);
 int gpode_conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci, int H, int W,
                             int Co, int K, int S, int P, int Ho, int Wo, void* stream);
+int gpode_conv2d_bwd_weight_bn(const float* x, const float* gy, const float* gy_bn, float* gw, float* gbias, float* scratch, int B, int Ci,
+                               int H, int W, int Co, int K, int S, int P, int Ho, int Wo, void* stream);
 /* nn.BatchNorm2d in TRAINING mode (batch statistics), optional fused ReLU (vae.py:55-59,113-120).
  * running_* may be NULL (no update); num_batches_tracked (optional, DEVICE int64 scalar, the module buffer) is incremented.
  * gx_chansum (optional, C floats): per-channel sum of gx, i.e. the bias gradient of the
@@ -142,6 +150,12 @@ int gpode_bn_fwd(const float* x, const float* gamma, const float* beta, float* y
 int gpode_bn_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
                  const float* save_invstd, float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW,
                  int relu, float* scratch, void* stream);
+/* Training-mode statistics WITHOUT the output pass: save_mean / save_invstd / running statistics / counter as gpode_bn_fwd, plus
+ * table[C][4] = {mean, invstd, gamma, beta} for a consumer that applies the normalisation itself (gpode_conv2d_bwd_*_bn).
+ * Backward: gpode_bn_bwd as usual (it needs x, not y). */
+int gpode_bn_stats(const float* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd, float* running_mean,
+                   float* running_var, long long* num_batches_tracked, float momentum, float eps, float* table, int B, int C, int HW,
+                   float* scratch, void* stream);
 /* nn.BatchNorm2d in EVALUATION mode (running statistics; main.py:157-163 puts the pre-trained VAE in eval()).
  * gy == NULL: out = y = relu?(affine(x)); gy != NULL: out = d/dx (frozen layer: no affine gradients). */
 int gpode_bn_eval(const float* x, const float* gy, const float* gamma, const float* beta, const float* running_mean,

@@ -138,3 +138,35 @@ def test_elbo_glue_ops(N, q):
     assert relerr(z, z64) < 1e-6 and relerr(klr, klr64) < 1e-5 and relerr(out, out64) < 1e-5
     for x, y in zip(a, a64):
         assert relerr(x.grad, y.grad) < 2e-5
+
+
+@pytest.mark.parametrize('B', [2, 37, 130])
+@pytest.mark.parametrize('geom', [((64, 6, 6), (64, 32, 5, 5), (2, 1, 0)), ((32, 13, 13), (32, 16, 5, 5), (2, 1, 1)),
+                                  ((16, 28, 28), (16, 1, 5, 5), (1, 2, 0))])
+def test_fused_batchnorm_relu_conv_transpose(B, geom):
+    """One decoder stage, ConvTranspose2d(ReLU(BatchNorm2d(c))) in training mode, with the normalised activation never
+    materialised (the transposed convolution applies it while staging its input): output, running statistics and every
+    gradient (c, gamma, beta, weight, bias) against torch in fp64."""
+    from vae_gp_ode_amd import vae_ops as V
+    (C, H, _), wshape, (s, p, op) = geom
+    g = torch.Generator().manual_seed(11)
+    c = torch.randn(B, C, H, H, generator=g) * 1.3 + 0.2
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    w, b = torch.randn(wshape, generator=g) * 0.05, torch.randn(wshape[1], generator=g) * 0.1
+    bn = torch.nn.BatchNorm2d(C).cuda()
+    ref = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        bn.weight.copy_(gam); bn.bias.copy_(bet); ref.weight.copy_(gam); ref.bias.copy_(bet)
+    a64 = [t.double().requires_grad_(True) for t in (c, w, b)]
+    y64 = F.conv_transpose2d(F.relu(ref(a64[0])), a64[1], a64[2], stride=s, padding=p, output_padding=op)
+    gy = torch.randn(y64.shape, generator=g)
+    y64.backward(gy.double())
+    a = [t.cuda().requires_grad_(True) for t in (c, w, b)]
+    y = V.bn_relu_conv_transpose2d(a[0], bn, a[1], a[2], s, p, op)
+    y.backward(gy.cuda())
+    assert relerr(y, y64) < TOL
+    for x, x64 in zip(a, a64):
+        assert relerr(x.grad, x64.grad) < 5 * TOL
+    assert relerr(bn.weight.grad, ref.weight.grad) < 5 * TOL and relerr(bn.bias.grad, ref.bias.grad) < 5 * TOL
+    assert relerr(bn.running_mean, ref.running_mean) < 1e-5 and relerr(bn.running_var, ref.running_var) < 1e-5
+    assert int(bn.num_batches_tracked) == 1

@@ -126,13 +126,23 @@ int gpode_conv2d_fwd(const float* x, const float* w, const float* bias, float* y
 int gpode_conv2d_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co,
                           int K, int S, int P, int Ho, int Wo, void* stream) {
   if (!gy || !w || !gx) return gp::set_error("gpode_conv2d_bwd_data: null pointer");
-  return gp::conv2d_bwd_data(gy, w, bias, gx, B, Ci, H, W, Co, K, S, P, Ho, Wo, GP_ST);
+  return gp::conv2d_bwd_data(gy, w, bias, gx, B, Ci, H, W, Co, K, S, P, Ho, Wo, nullptr, GP_ST);
+}
+int gpode_conv2d_bwd_data_bn(const float* gy, const float* gy_bn, const float* w, const float* bias, float* gx, int B, int Ci, int H,
+                             int W, int Co, int K, int S, int P, int Ho, int Wo, void* stream) {
+  if (!gy || !gy_bn || !w || !gx) return gp::set_error("gpode_conv2d_bwd_data_bn: null pointer");
+  return gp::conv2d_bwd_data(gy, w, bias, gx, B, Ci, H, W, Co, K, S, P, Ho, Wo, gy_bn, GP_ST);
 }
 size_t gpode_conv_wgrad_scratch(int B, int Ci, int Co, int K) { return gp::conv_wgrad_scratch(B, Ci, Co, K); }
 int gpode_conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci, int H, int W,
                             int Co, int K, int S, int P, int Ho, int Wo, void* stream) {
   if (!x || !gy || !gw || !scratch) return gp::set_error("gpode_conv2d_bwd_weight: null pointer");
-  return gp::conv2d_bwd_weight(x, gy, gw, gbias, scratch, B, Ci, H, W, Co, K, S, P, Ho, Wo, GP_ST);
+  return gp::conv2d_bwd_weight(x, gy, gw, gbias, scratch, B, Ci, H, W, Co, K, S, P, Ho, Wo, nullptr, GP_ST);
+}
+int gpode_conv2d_bwd_weight_bn(const float* x, const float* gy, const float* gy_bn, float* gw, float* gbias, float* scratch, int B, int Ci,
+                               int H, int W, int Co, int K, int S, int P, int Ho, int Wo, void* stream) {
+  if (!x || !gy || !gy_bn || !gw || !scratch) return gp::set_error("gpode_conv2d_bwd_weight_bn: null pointer");
+  return gp::conv2d_bwd_weight(x, gy, gw, gbias, scratch, B, Ci, H, W, Co, K, S, P, Ho, Wo, gy_bn, GP_ST);
 }
 size_t gpode_bn_scratch(int B, int C) { return gp::bn_scratch(B, C); }
 int gpode_bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
@@ -148,6 +158,13 @@ int gpode_bn_bwd(const float* x, const float* gy, const float* gamma, const floa
   if (!x || !gy || !gamma || !beta || !save_mean || !save_invstd || !gx || !ggamma || !gbeta || !scratch)
     return gp::set_error("gpode_bn_bwd: null pointer");
   return gp::bn_bwd(x, gy, gamma, beta, save_mean, save_invstd, gx, ggamma, gbeta, gx_chansum, B, C, HW, relu, scratch, GP_ST);
+}
+int gpode_bn_stats(const float* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd, float* running_mean,
+                   float* running_var, long long* num_batches_tracked, float momentum, float eps, float* table, int B, int C, int HW,
+                   float* scratch, void* stream) {
+  if (!x || !gamma || !beta || !save_mean || !save_invstd || !table || !scratch) return gp::set_error("gpode_bn_stats: null pointer");
+  return gp::bn_stats(x, gamma, beta, save_mean, save_invstd, running_mean, running_var, num_batches_tracked, momentum, eps, table, B, C, HW,
+                      scratch, GP_ST);
 }
 int gpode_bn_eval(const float* x, const float* gy, const float* gamma, const float* beta, const float* running_mean,
                   const float* running_var, float eps, float* out, int B, int C, int HW, int relu, void* stream) {

@@ -24,7 +24,8 @@ constexpr int PST = PLANE + 4;                       // T plane stride: 4 planes
 // forward.  grid <= 256, block 512, LDS = 25 * PST floats.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void k_fwd(const float* __restrict__ x, const float* __restrict__ w,
-                                             const float* __restrict__ bias, float* __restrict__ y, int B) {
+                                             const float* __restrict__ bias, float* __restrict__ y, int B,
+                                             const float* __restrict__ in_bn) {
   float* s_T = igemm_smem;                           // [25][PST], zero borders
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
@@ -40,6 +41,11 @@ __global__ __launch_bounds__(512) void k_fwd(const float* __restrict__ x, const 
       wa[ks][c] = tap < KK ? w[(size_t)(4 * ks + lk) * KK + tap] : 0.f;
     }
   const float bv = bias ? bias[0] : 0.f;
+  // in_bn ([16][4] = mean, invstd, gamma, beta): x is the raw output of decnn.7 and decnn.8/9 (BatchNorm + ReLU) are applied
+  // to the operands in registers
+  float4 tf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) tf[ks] = in_bn ? reinterpret_cast<const float4*>(in_bn)[4 * ks + lk] : float4{0.f, 1.f, 1.f, 0.f};
   // B = x[b][ci = 4 ks + lk][16 t + lr], fetched one image ahead
   float xb[MAXT][4];
   auto prefetch = [&](int b) {
@@ -64,7 +70,8 @@ __global__ __launch_bounds__(512) void k_fwd(const float* __restrict__ x, const 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks][c], xb[j][ks], acc[c], 0, 0, 0);
+          for (int c = 0; c < 2; ++c)
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks][c], in_bn ? bn_relu(xb[j][ks], tf[ks]) : xb[j][ks], acc[c], 0, 0, 0);
         // lane: source pixel 16 t + lr, taps 16 c + 4 lk + r
         const int p = 16 * t + lr, pa = (p / H + 2) * WP + p % H + 2;
 #pragma unroll
@@ -166,7 +173,8 @@ __global__ __launch_bounds__(512) void k_bwd_data(const float* __restrict__ gy, 
 // d/d weight.  grid <= 256, block 512, LDS = max(IPB planes, reduction buffer); part[blockIdx.x][ci][tap].
 // ---------------------------------------------------------------------------------------------
 template <int IPB>
-__global__ __launch_bounds__(512) void k_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int B) {
+__global__ __launch_bounds__(512) void k_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int B,
+                                               const float* __restrict__ in_bn) {
   float* s_g = igemm_smem;                           // [IPB][32][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
@@ -181,6 +189,7 @@ __global__ __launch_bounds__(512) void k_wgrad(const float* __restrict__ x, cons
     toff[c] = (tap / 5) * WP + tap % 5;
   }
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const float4 tf = in_bn ? reinterpret_cast<const float4*>(in_bn)[lr] : float4{0.f, 1.f, 1.f, 0.f};   // BatchNorm + ReLU of x (channel lr)
   const int ngroups = (B + IPB - 1) / IPB;
   float4 pre[NLD];
   float4 xa[NJ];                                     // A = x[b][ci = lr][16 j + 4 lk + i], i = 0..3 -> MFMA i
@@ -227,7 +236,11 @@ __global__ __launch_bounds__(512) void k_wgrad(const float* __restrict__ x, cons
       const int g = wave + 8 * q;
       if (g < nimg * NTILE) {                        // wave-uniform
         const int im = g / NTILE, j = g % NTILE;
-        const float av[4] = {xc[q].x, xc[q].y, xc[q].z, xc[q].w};
+        float av[4] = {xc[q].x, xc[q].y, xc[q].z, xc[q].w};
+        if (in_bn) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) av[i] = bn_relu(av[i], tf);
+        }
         float bf[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <type_traits>
+#include "bn_math.hpp"
 
 namespace gp {
 
@@ -171,7 +172,8 @@ extern __shared__ __attribute__((aligned(16))) float igemm_smem[];
 // measured 401 MB of HBM writes for a 205 MB output).
 template <class PL, int IPB, int TG, int NCJ, bool PAIR, int NTHR>
 __global__ __launch_bounds__(NTHR) void k_conv_igemm(const float* __restrict__ x, const float* __restrict__ w,
-                                                      const float* __restrict__ bias, float* __restrict__ y, int B) {
+                                                      const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                      const float* __restrict__ in_bn) {
   constexpr int KC = PL::KC, NC = PL::NC, NCS = PL::NCS, NCLS = PL::NCLS, SH = PL::SH, OH = PL::OH, HP = PL::HP, PS = PL::PS;
   constexpr int PADL = PL::PADL, WROW = PL::WROW, NWE = PL::NWE;
   static_assert(NCS % 16 == 0 && NC % NCS == 0 && KC % 4 == 0 && NTHR % 256 == 0, "MFMA tiling");
@@ -187,10 +189,16 @@ __global__ __launch_bounds__(NTHR) void k_conv_igemm(const float* __restrict__ x
   constexpr int NLD = (IPB * SRC / 4 + NTHR - 1) / NTHR;   // float4 fetches per thread per group
   float* s_img = igemm_smem;                         // [IPB][KC][PS] zero padded planes
   float* s_w = igemm_smem + IPB * IMG;               // [cls][tap][KC][WROW]
+  // in_bn ([KC][4] = mean, invstd, gamma, beta per source channel): the source is the raw output of the previous
+  // convolution and the BatchNorm + ReLU that follows it is applied while the images are scattered to LDS, so the
+  // normalised activation never goes through HBM (the zero padding is written once and stays zero)
+  float4* s_tf = reinterpret_cast<float4*>(s_w + PL::WSLAB);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
   const int ngroups = (B + IPB - 1) / IPB;
   const float4* x4 = reinterpret_cast<const float4*>(x);
+  if (in_bn)
+    for (int e = tid; e < KC; e += NTHR) s_tf[e] = reinterpret_cast<const float4*>(in_bn)[e];
   // wavefront w runs on SIMD w & 3: order the wavefronts SIMD-major so that each SIMD owns a contiguous cost range
   const int jw = (wave & 3) * (NW / 4) + (wave >> 2);
 
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(NTHR) void k_conv_igemm(const float* __restrict__ x
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const int e = 4 * f + k, pl = e / (SH * SH), q = e % (SH * SH);
-              s_img[pl * PS + (q / SH + PADL) * HP + q % SH + PADL] = v[k];
+              s_img[pl * PS + (q / SH + PADL) * HP + q % SH + PADL] = in_bn ? bn_relu(v[k], s_tf[pl % KC]) : v[k];
             }
           }
         }
@@ -380,7 +388,7 @@ template <class L> struct WgradGeo {
 
 template <class L, int IPB, int WM, int WN, int WT, bool PIPE, int NTHR>
 __global__ __launch_bounds__(NTHR) void k_convT_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ gy,
-                                                            float* __restrict__ part, int B) {
+                                                            float* __restrict__ part, int B, const float* __restrict__ in_bn) {
   using G = WgradGeo<L>;
   constexpr int CI = L::CI, CO = L::CO, HI = L::HI, HO = L::HO, K = L::K, S = L::S, P = L::P, KK = K * K;
   constexpr int MT = CI / 16, NT = CO / 16;
@@ -392,6 +400,9 @@ __global__ __launch_bounds__(NTHR) void k_convT_wgrad_mfma(const float* __restri
   constexpr int NLX = (IPB * SRCX / 4 + NTHR - 1) / NTHR, NLG = (IPB * SRCG / 4 + NTHR - 1) / NTHR;
   float* s_x = igemm_smem;                           // [IPB][CI][PSX]
   float* s_g = igemm_smem + IPB * IMGX;              // [IPB][CO][PSG]
+  float4* s_tf = reinterpret_cast<float4*>(igemm_smem + IPB * (IMGX + IMGG));   // optional BatchNorm + ReLU of x, as in k_conv_igemm
+  if (in_bn)
+    for (int e = threadIdx.x; e < CI; e += NTHR) s_tf[e] = reinterpret_cast<const float4*>(in_bn)[e];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
   const int wm = wave % WM, wn = (wave / WM) % WN, wt = wave / (WM * WN);
@@ -445,8 +456,8 @@ __global__ __launch_bounds__(NTHR) void k_convT_wgrad_mfma(const float* __restri
         const float v[4] = {prex[i].x, prex[i].y, prex[i].z, prex[i].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int e = 4 * f + k;
-          s_x[(e / NPIX) * PSX + e % NPIX] = v[k];
+          const int e = 4 * f + k, pl = e / NPIX;
+          s_x[pl * PSX + e % NPIX] = in_bn ? bn_relu(v[k], s_tf[pl % CI]) : v[k];
         }
       }
     }
@@ -532,7 +543,7 @@ __global__ __launch_bounds__(NTHR) void k_convT_wgrad_mfma(const float* __restri
 }
 
 template <class L, int IPB> constexpr size_t wgrad_lds_bytes() {
-  return sizeof(float) * (size_t)IPB * (WgradGeo<L>::IMGX + WgradGeo<L>::IMGG);
+  return sizeof(float) * ((size_t)IPB * (WgradGeo<L>::IMGX + WgradGeo<L>::IMGG) + (size_t)4 * L::CI);
 }
 
 // gw[ci][co][tap] = sum_s part[s][tap][mt][nt][r][lane] (the accumulator layout of k_convT_wgrad_mfma), fixed order.
@@ -583,8 +594,8 @@ __global__ __launch_bounds__(1024) void k_sum_splits4(const float* __restrict__ 
   }
 }
 
-template <class PL, int IPB> constexpr size_t igemm_lds_bytes() {
-  return sizeof(float) * ((size_t)IPB * PL::KC * PL::PS + (size_t)PL::WSLAB);
+template <class PL, int IPB> constexpr size_t igemm_lds_bytes() {   // planes + weight slabs + the optional input-transform table
+  return sizeof(float) * ((size_t)IPB * PL::KC * PL::PS + (size_t)PL::WSLAB + (size_t)4 * PL::KC);
 }
 
 }  // namespace gp

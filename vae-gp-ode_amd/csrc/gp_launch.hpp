@@ -73,16 +73,19 @@ int cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, const float* ws,
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S,
                int P, int Ho, int Wo, hipStream_t st);
 int conv2d_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co, int K, int S,
-                    int P, int Ho, int Wo, hipStream_t st);
+                    int P, int Ho, int Wo, const float* gy_bn, hipStream_t st);
 size_t conv_wgrad_scratch(int B, int Ci, int Co, int K);
 int conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci, int H, int W, int Co,
-                      int K, int S, int P, int Ho, int Wo, hipStream_t st);
+                      int K, int S, int P, int Ho, int Wo, const float* gy_bn, hipStream_t st);
 size_t bn_scratch(int B, int C);
 int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
            float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, int B, int C, int HW,
            int relu, float* scratch, hipStream_t st);
 int bn_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
            float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW, int relu, float* scratch, hipStream_t st);
+int bn_stats(const float* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd, float* running_mean,
+             float* running_var, long long* num_batches_tracked, float momentum, float eps, float* table, int B, int C, int HW,
+             float* scratch, hipStream_t st);
 int bn_eval(const float* x, const float* gy, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
             float eps, float* out, int B, int C, int HW, int relu, hipStream_t st);
 int chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, hipStream_t st);

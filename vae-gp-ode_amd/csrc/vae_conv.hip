@@ -307,9 +307,9 @@ static inline int ew_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g
 int tiled_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S, int P,
               int Ho, int Wo, hipStream_t st);
 int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co, int K, int S,
-                   int P, int Ho, int Wo, hipStream_t st);
+                   int P, int Ho, int Wo, const float* in_bn, hipStream_t st);
 int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch, int B, int Ci, int H, int W, int Co, int K, int S,
-                     int P, int Ho, int Wo, hipStream_t st);
+                     int P, int Ho, int Wo, const float* in_bn, hipStream_t st);
 
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S,
                int P, int Ho, int Wo, hipStream_t st) {
@@ -322,9 +322,12 @@ int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int 
   return set_error("gpode_conv2d_fwd: kernel %d stride %d not built", K, S);
 }
 
+// gy_bn (optional, [Co][4] = mean, invstd, gamma, beta): gy is the raw output of the previous layer and the BatchNorm + ReLU
+// between the two layers is applied on the fly (matrix-core specialisations only)
 int conv2d_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co, int K, int S,
-                    int P, int Ho, int Wo, hipStream_t st) {
-  { const int r = tiled_bwd_data(gy, w, bias, gx, B, Ci, H, W, Co, K, S, P, Ho, Wo, st); if (r >= 0) return r; }
+                    int P, int Ho, int Wo, const float* gy_bn, hipStream_t st) {
+  { const int r = tiled_bwd_data(gy, w, bias, gx, B, Ci, H, W, Co, K, S, P, Ho, Wo, gy_bn, st); if (r >= 0) return r; }
+  if (gy_bn) return set_error("gpode_conv2d_bwd_data_bn: no matrix-core specialisation for this geometry");
   ConvDims d{B, Ci, H, W, Co, P, Ho, Wo};
   const size_t total = (size_t)B * Ci * H * W;
 #define X(k, s) if (K == k && S == s) { hipLaunchKernelGGL((k_conv_bwd_data<k, s>), ew_grid(total), 256, 0, st, gy, w, bias, gx, d); return check_launch("conv_bwd_data"); }
@@ -350,15 +353,16 @@ size_t conv_wgrad_scratch(int B, int Ci, int Co, int K) {
 }
 
 int conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci, int H, int W, int Co,
-                      int K, int S, int P, int Ho, int Wo, hipStream_t st) {
+                      int K, int S, int P, int Ho, int Wo, const float* gy_bn, hipStream_t st) {
   {
-    const int r = tiled_bwd_weight(x, gy, gw, scratch, B, Ci, H, W, Co, K, S, P, Ho, Wo, st);
+    const int r = tiled_bwd_weight(x, gy, gw, scratch, B, Ci, H, W, Co, K, S, P, Ho, Wo, gy_bn, st);
     if (r > 0) return r;
     if (r == 0) {
       if (gbias) return chan_sum(gy, gbias, B, Co, Ho * Wo, scratch, st);
       return 0;
     }
   }
+  if (gy_bn) return set_error("gpode_conv2d_bwd_weight_bn: no matrix-core specialisation for this geometry");
   ConvDims d{B, Ci, H, W, Co, P, Ho, Wo};
   const int nsplit = pick_split(B, Co * Ci);
   const int bps = (B + nsplit - 1) / nsplit;

@@ -389,28 +389,30 @@ static bool use_mfma() {
 
 // matrix-core path (conv_mfma.hpp): persistent grid of one 512-thread workgroup per CU
 template <class PL, int IPB, int TG, int NCJ, bool PAIR = false>
-static int launch_igemm(const float* x, const float* w, const float* bias, float* y, int B, hipStream_t st, const char* what) {
+static int launch_igemm(const float* x, const float* w, const float* bias, float* y, int B, hipStream_t st, const char* what,
+                        const float* in_bn = nullptr) {
   constexpr int NTHR = 512;
   constexpr size_t lds = igemm_lds_bytes<PL, IPB>();
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto km = k_conv_igemm<PL, IPB, TG, NCJ, PAIR, NTHR>;
   if (set_max_lds((const void*)km, lds)) return 1;
   const int ngroups = (B + IPB - 1) / IPB;
-  hipLaunchKernelGGL(km, ngroups < 256 ? ngroups : 256, NTHR, lds, st, x, w, bias, y, B);
+  hipLaunchKernelGGL(km, ngroups < 256 ? ngroups : 256, NTHR, lds, st, x, w, bias, y, B, in_bn);
   return check_launch(what);
 }
 
 // IPB: images per workgroup of the VALU kernel; IPBM / COS: images per group and output channels per pass of the MFMA kernel
 template <class L, int IPB, int IPBM, int COS>
-static int launch_T1(const float* x, const float* w, const float* bias, float* y, int B, hipStream_t st) {
+static int launch_T1(const float* x, const float* w, const float* bias, float* y, int B, hipStream_t st, const float* in_bn) {
   constexpr int MAXTAPS = ((L::K + L::S - 1) / L::S) * ((L::K + L::S - 1) / L::S);
   const size_t lds = sizeof(float) * ((size_t)IPB * L::CI * L::HP * L::HP + (size_t)MAXTAPS * L::CI * L::CO);
   if (use_mfma() && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     constexpr int TG = COS >= 64 ? 1 : (COS >= 32 ? 2 : 4);
     // column-parity classes pair up when both cover the same pixel grid: stride 2, (HO + P) even
     constexpr bool PAIR = L::S == 2 && (L::HO % 2 == 0) && (L::P % 2 == 1);
-    return launch_igemm<FwdPolicy<L, COS>, IPBM, TG, COS / 16, PAIR>(x, w, bias, y, B, st, "convT_fwd_mfma");
+    return launch_igemm<FwdPolicy<L, COS>, IPBM, TG, COS / 16, PAIR>(x, w, bias, y, B, st, "convT_fwd_mfma", in_bn);
   }
+  if (in_bn) return set_error("convT forward with a fused BatchNorm input needs the matrix-core path (16-byte aligned input, GPODE_CONV_VALU unset)");
   auto kern = k_convT_fwd<L, IPB>;
   if (set_max_lds((const void*)kern, lds)) return 1;
   hipLaunchKernelGGL(kern, (B + IPB - 1) / IPB, 256, lds, st, x, w, bias, y, B);
@@ -432,14 +434,14 @@ static int launch_T2(const float* gy, const float* w, float* gx, int B, hipStrea
 }
 
 template <class L, int IPBM, int WM, int WN, int WT, bool PIPE>
-static int launch_wgrad_mfma(const float* x, const float* gy, float* gw, float* scratch, int B, hipStream_t st) {
+static int launch_wgrad_mfma(const float* x, const float* gy, float* gw, float* scratch, int B, hipStream_t st, const float* in_bn) {
   constexpr size_t ldsm = wgrad_lds_bytes<L, IPBM>();
   static_assert(ldsm <= 160 * 1024, "LDS budget");
   auto km = k_convT_wgrad_mfma<L, IPBM, WM, WN, WT, PIPE, 512>;
   if (set_max_lds((const void*)km, ldsm)) return 1;
   const int ngroups = (B + IPBM - 1) / IPBM;
   const int nwg = ngroups < 256 ? ngroups : 256;
-  hipLaunchKernelGGL(km, nwg, 512, ldsm, st, x, gy, scratch, B);
+  hipLaunchKernelGGL(km, nwg, 512, ldsm, st, x, gy, scratch, B, in_bn);
   const size_t n = (size_t)L::CI * L::CO * L::K * L::K;
   hipLaunchKernelGGL(k_sum_splits_wgrad, (unsigned)((n + 63) / 64), 1024, 0, st, scratch, nwg, L::CI / 16, L::CO / 16, L::K * L::K, gw);
   return check_launch("convT_wgrad_mfma");
@@ -447,9 +449,10 @@ static int launch_wgrad_mfma(const float* x, const float* gy, float* gw, float* 
 
 // IPBM / WM x WN x WT: images per group and wavefront split (ci tiles, co tiles, taps) of the MFMA kernel
 template <class L, int COW, int IPBM, int WM, int WN, int WT, bool PIPE>
-static int launch_T3(const float* x, const float* gy, float* gw, float* scratch, int B, hipStream_t st) {
+static int launch_T3(const float* x, const float* gy, float* gw, float* scratch, int B, hipStream_t st, const float* in_bn) {
   if (use_mfma() && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0)
-    return launch_wgrad_mfma<L, IPBM, WM, WN, WT, PIPE>(x, gy, gw, scratch, B, st);
+    return launch_wgrad_mfma<L, IPBM, WM, WN, WT, PIPE>(x, gy, gw, scratch, B, st, in_bn);
+  if (in_bn) return set_error("convT weight gradient with a fused BatchNorm input needs the matrix-core path");
   constexpr int NT = L::CI * (COW / 4), PSPLIT = 256 / NT, KK = L::K * L::K;
   size_t fl = (size_t)L::HI * L::HI * L::CI + (size_t)L::GP_ * L::GP_ * COW;
   const size_t red = PSPLIT > 1 ? (size_t)PSPLIT * NT * KK * 4 : 0;
@@ -469,18 +472,18 @@ static int launch_T3(const float* x, const float* gy, float* gw, float* scratch,
 
 // ConvTranspose2d forward (called with the conv geometry of its adjoint, as conv2d_bwd_data is)
 int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co, int K, int S,
-                   int P, int Ho, int Wo, hipStream_t st) {
+                   int P, int Ho, int Wo, const float* in_bn, hipStream_t st) {
   if (H != W || Ho != Wo) return -1;
-  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec7, 3, 2, 16>(gy, w, bias, gx, B, st);
-  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec4, 3, 2, 16>(gy, w, bias, gx, B, st);
-  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec1, 8, 8, 64>(gy, w, bias, gx, B, st);
+  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec7, 3, 2, 16>(gy, w, bias, gx, B, st, in_bn);
+  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec4, 3, 2, 16>(gy, w, bias, gx, B, st, in_bn);
+  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec1, 8, 8, 64>(gy, w, bias, gx, B, st, in_bn);
   if (matches<Enc6>(Ci, Co, H, Ho, K, S, P) && use_mfma() && (reinterpret_cast<uintptr_t>(gy) & 15) == 0)   // d/d input of the encoder's cnn.6
-    return launch_igemm<FwdPolicy<Enc6, 16>, 8, 4, 1>(gy, w, bias, gx, B, st, "enc_conv6_bwd_data_mfma");
+    return launch_igemm<FwdPolicy<Enc6, 16>, 8, 4, 1>(gy, w, bias, gx, B, st, "enc_conv6_bwd_data_mfma", in_bn);
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) {
     if (use_mfma()) {
       const size_t ldsm = sizeof(float) * dec10::KK * dec10::PST;
       if (set_max_lds((const void*)dec10::k_fwd, ldsm)) return 1;
-      hipLaunchKernelGGL(dec10::k_fwd, B < 256 ? B : 256, 512, ldsm, st, gy, w, bias, gx, B);
+      hipLaunchKernelGGL(dec10::k_fwd, B < 256 ? B : 256, 512, ldsm, st, gy, w, bias, gx, B, in_bn);
       return check_launch("dec10_fwd_mfma");
     }
     constexpr int IPB = 2;
@@ -521,20 +524,20 @@ int tiled_fwd(const float* x, const float* w, const float* bias, float* y, int B
 
 // ConvTranspose2d d/d weight (conv geometry: x := grad_output, gy := the layer's input)
 int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch, int B, int Ci, int H, int W, int Co, int K, int S,
-                     int P, int Ho, int Wo, hipStream_t st) {
+                     int P, int Ho, int Wo, const float* in_bn, hipStream_t st) {
   if (H != W || Ho != Wo) return -1;
-  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec7, 16, 2, 1, 1, 8, true>(gy, x, gw, scratch, B, st);
-  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec4, 16, 2, 4, 2, 1, false>(gy, x, gw, scratch, B, st);
-  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec1, 32, 8, 2, 4, 1, true>(gy, x, gw, scratch, B, st);
+  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec7, 16, 2, 1, 1, 8, true>(gy, x, gw, scratch, B, st, in_bn);
+  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec4, 16, 2, 4, 2, 1, false>(gy, x, gw, scratch, B, st, in_bn);
+  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec1, 32, 8, 2, 4, 1, true>(gy, x, gw, scratch, B, st, in_bn);
   if (matches<Enc6>(Ci, Co, H, Ho, K, S, P) && use_mfma() && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0)
-    return launch_wgrad_mfma<Enc6, 8, 2, 1, 4, true>(gy, x, gw, scratch, B, st);   // d/d weight of the encoder's cnn.6
+    return launch_wgrad_mfma<Enc6, 8, 2, 1, 4, true>(gy, x, gw, scratch, B, st, in_bn);   // d/d weight of the encoder's cnn.6
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P) && use_mfma() &&
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0) {
     constexpr int IPB = 1;
     const size_t fl = (size_t)IPB * dec10::PLANE > 8 * 16 * 32 ? (size_t)IPB * dec10::PLANE : 8 * 16 * 32;
     const int ngroups = (B + IPB - 1) / IPB;
     const int nwg = ngroups < 256 ? ngroups : 256;
-    hipLaunchKernelGGL(dec10::k_wgrad<IPB>, nwg, 512, sizeof(float) * fl, st, gy, x, scratch, B);
+    hipLaunchKernelGGL(dec10::k_wgrad<IPB>, nwg, 512, sizeof(float) * fl, st, gy, x, scratch, B, in_bn);
     hipLaunchKernelGGL(k_sum_splits4, (400 + 63) / 64, 1024, 0, st, scratch, nwg, (size_t)400, gw);
     return check_launch("dec10_wgrad_mfma");
   }

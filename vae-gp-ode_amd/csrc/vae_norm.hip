@@ -13,14 +13,11 @@
 #include <hip/hip_runtime.h>
 #include "gp_launch.hpp"
 #include "wave_reduce.hpp"
+#include "bn_math.hpp"
 
 namespace gp {
 
 namespace {
-
-// normalised value and affine output with pinned rounding (forward and backward must agree on the ReLU mask)
-__device__ __forceinline__ float bn_xhat(float x, float m, float is) { return __fmul_rn(__fsub_rn(x, m), is); }
-__device__ __forceinline__ float bn_affine(float x, float m, float is, float g, float b) { return __fmaf_rn(bn_xhat(x, m, is), g, b); }
 
 // visit channel c of images [b0, b0 + nb): f4(offset of 4 consecutive floats) when HW % 4 == 0, else f1(offset)
 template <class F4, class F1>
@@ -139,6 +136,31 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ x, c
               *reinterpret_cast<float4*>(y + i) = o;
             },
             [&](size_t i) { y[i] = fmaxf(bn_affine(x[i], m, is, g, bt), lo); });
+}
+
+// statistics only (no output): finalises the split sums into save_mean / save_invstd / running statistics and writes the
+// per-channel table {mean, invstd, gamma, beta} that a consuming convolution applies on the fly (conv_mfma.hpp, in_bn)
+__global__ __launch_bounds__(64) void k_bn_table(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ part,
+                                                 const float* __restrict__ shift, int nsplit, int C, float count, float eps, float momentum,
+                                                 float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                 long long* __restrict__ num_batches_tracked, float* __restrict__ table) {
+  const int c = blockIdx.x;
+  float s0, s1;
+  split_sums(part, nsplit, C, c, s0, s1);
+  if (threadIdx.x != 0) return;
+  const float d = s0 / count;
+  const float m = shift[c] + d;
+  const float var = fmaxf(s1 / count - d * d, 0.f);
+  const float is = rsqrtf(var + eps);
+  save_mean[c] = m;
+  save_invstd[c] = is;
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count / (count - 1.f));
+  }
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  table[4 * c + 0] = m; table[4 * c + 1] = is; table[4 * c + 2] = gamma[c]; table[4 * c + 3] = beta[c];
 }
 
 // g = gy masked by the ReLU; part[split][c] = {sum g, sum g * xhat}
@@ -273,6 +295,18 @@ int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, floa
   hipLaunchKernelGGL(k_bn_apply, dim3(C, sp.used), 256, 0, st, x, gamma, beta, scratch, shift, sp.used, (float)B * HW, eps, momentum, save_mean,
                      save_invstd, running_mean, running_var, num_batches_tracked, y, B, C, HW, sp.bps, relu);
   return check_launch("bn_fwd");
+}
+
+int bn_stats(const float* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd, float* running_mean,
+             float* running_var, long long* num_batches_tracked, float momentum, float eps, float* table, int B, int C, int HW,
+             float* scratch, hipStream_t st) {
+  if ((HW & 3) == 0 && !aligned16(x)) return set_error("gpode_bn_stats: x must be 16-byte aligned");
+  const Split sp = pick(B);
+  float* shift = scratch + (size_t)sp.ns * C * 2 + (size_t)C * 2;
+  hipLaunchKernelGGL(k_bn_stats, dim3(C, sp.used), 256, 0, st, x, B, C, HW, sp.bps, scratch, shift);
+  hipLaunchKernelGGL(k_bn_table, C, 64, 0, st, gamma, beta, scratch, shift, sp.used, C, (float)B * HW, eps, momentum, save_mean, save_invstd,
+                     running_mean, running_var, num_batches_tracked, table);
+  return check_launch("bn_stats");
 }
 
 // the forward output is not needed: the ReLU mask is recomputed from x (same pinned arithmetic as k_bn_apply)

@@ -106,6 +106,54 @@ class _ConvT2d(torch.autograd.Function):
         return gx, gw, gb, None, None, None
 
 
+class _BnReluConvT(torch.autograd.Function):
+    """ConvTranspose2d(ReLU(BatchNorm2d_train(c))) (vae.py:113-120, one decoder stage) with the normalised activation never
+    written to memory: forward = batch statistics of c (one read) + the transposed convolution applying normalise / affine /
+    ReLU while it stages its input; backward = weight gradient (same staging), input gradient of the convolution, then the
+    BatchNorm backward on c.  Training mode only; the eval-mode path keeps the separate ops."""
+
+    @staticmethod
+    def forward(ctx, c, gamma, beta, running_mean, running_var, nbt, momentum, eps, w, b, stride, pad, out_pad):
+        c, w = _chk(c, 'c'), _chk(w, 'weight')
+        B, Cin, Hi, Wi = c.shape
+        _, Cout, K, _ = w.shape
+        Ht, Wt = (Hi - 1) * stride - 2 * pad + K + out_pad, (Wi - 1) * stride - 2 * pad + K + out_pad
+        mean, invstd, table = _new((Cin,), c), _new((Cin,), c), _new((Cin, 4), c)
+        _lib.call('gpode_bn_stats', _ptr(c), _ptr(_chk(gamma, 'gamma')), _ptr(_chk(beta, 'beta')), _ptr(mean), _ptr(invstd),
+                  _ptr(running_mean), _ptr(running_var), _ptr(nbt), ctypes.c_float(momentum), ctypes.c_float(eps), _ptr(table),
+                  B, Cin, Hi * Wi, _ptr(_bn_scratch(B, Cin, c)), _stream())
+        y = _new((B, Cout, Ht, Wt), c)
+        _lib.call('gpode_conv2d_bwd_data_bn', _ptr(c), _ptr(table), _ptr(w), _ptr(b), _ptr(y), B, Cout, Ht, Wt, Cin, K, stride, pad, Hi, Wi,
+                  _stream())
+        ctx.save_for_backward(c, gamma, beta, mean, invstd, table, w)
+        ctx.geom = (B, Cout, Ht, Wt, Cin, K, stride, pad, Hi, Wi, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        c, gamma, beta, mean, invstd, table, w = ctx.saved_tensors
+        B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, has_b = ctx.geom
+        gy = gy.contiguous()
+        gw = gb = None
+        if ctx.needs_input_grad[8]:
+            gw = _new(w.shape, c)
+            _lib.call('gpode_conv2d_bwd_weight_bn', _ptr(gy), _ptr(c), _ptr(table), _ptr(gw), _ptr(None),
+                      _ptr(_wgrad_scratch(B, Cout, Cin, K, c)), B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, _stream())
+            if has_b:
+                gb = _fused_chansum(gy, Cout)
+                if gb is None:
+                    gb = _new((Cout,), c)
+                    _lib.call('gpode_chan_sum', _ptr(gy), _ptr(gb), B, Cout, Ht * Wt, _ptr(_bn_scratch(B, Cout, c)), _stream())
+        # gradient w.r.t. the (never materialised) normalised activation, then through the BatchNorm to c
+        ga = _new(c.shape, c)
+        _lib.call('gpode_conv2d_fwd', _ptr(gy), _ptr(w), _ptr(None), _ptr(ga), B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, _stream())
+        gc, gg, gbeta, cs = _new(c.shape, c), _new((Cin,), c), _new((Cin,), c), _new((Cin,), c)
+        _lib.call('gpode_bn_bwd', _ptr(c), _ptr(ga), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(gc), _ptr(gg), _ptr(gbeta),
+                  _ptr(cs), B, Cin, Hi * Wi, 1, _ptr(_bn_scratch(B, Cin, c)), _stream())
+        gc._gpode_chansum = cs
+        return gc, gg, gbeta, None, None, None, None, None, gw, gb, None, None, None
+
+
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, nbt=None):
@@ -353,6 +401,12 @@ def batch_norm_train(x, bn, relu):
     return _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean if bn.training else None,
                                  bn.running_var if bn.training else None, bn.momentum, bn.eps, relu,
                                  bn.num_batches_tracked if bn.training else None)
+
+
+def bn_relu_conv_transpose2d(c, bn, w, b, stride, pad, out_pad=0):
+    """conv_transpose2d(relu(bn(c)), w, b) for a BatchNorm2d module in training mode, fused (see _BnReluConvT)."""
+    return _BnReluConvT.apply(c, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps,
+                              w, b, stride, pad, out_pad)
 
 
 def batch_norm_eval(x, bn, relu):
