@@ -16,7 +16,7 @@ template <class L> void run(const char* name, int B) {
   for (int rep = 0; rep < 3; ++rep) {
     unsigned long long z[8] = {0};
     hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z));
-    tiled_bwd_data(x, w, b, y, B, L::CO, L::HO, L::HO, L::CI, L::K, L::S, L::P, L::HI, L::HI, 0);
+    tiled_bwd_data(x, w, b, y, B, L::CO, L::HO, L::HO, L::CI, L::K, L::S, L::P, L::HI, L::HI, nullptr, 0);
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(z, HIP_SYMBOL(g_probe), sizeof(z));
     if (rep == 2)
@@ -50,7 +50,7 @@ template <class L> void runw(const char* name, int B) {
   for (int rep = 0; rep < 3; ++rep) {
     unsigned long long z[8] = {0};
     hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z));
-    tiled_bwd_weight(gy, x, gw, scr, B, L::CO, L::HO, L::HO, L::CI, L::K, L::S, L::P, L::HI, L::HI, 0);
+    tiled_bwd_weight(gy, x, gw, scr, B, L::CO, L::HO, L::HO, L::CI, L::K, L::S, L::P, L::HI, L::HI, nullptr, 0);
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(z, HIP_SYMBOL(g_probe), sizeof(z));
     if (rep == 2) printf("%s B=%d cycles: barrier %llu scatter %llu mma %llu total %llu\n", name, B, z[1], z[2], z[3], z[5]);

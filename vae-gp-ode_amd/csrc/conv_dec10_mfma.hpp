@@ -23,6 +23,7 @@ constexpr int PST = PLANE + 4;                       // T plane stride: 4 planes
 // ---------------------------------------------------------------------------------------------
 // forward.  grid <= 256, block 512, LDS = 25 * PST floats.
 // ---------------------------------------------------------------------------------------------
+template <bool HAS_BN>
 __global__ __launch_bounds__(512) void k_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                              const float* __restrict__ bias, float* __restrict__ y, int B,
                                              const float* __restrict__ in_bn) {
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(512) void k_fwd(const float* __restrict__ x, const 
   // to the operands in registers
   float4 tf[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) tf[ks] = in_bn ? reinterpret_cast<const float4*>(in_bn)[4 * ks + lk] : float4{0.f, 1.f, 1.f, 0.f};
+  for (int ks = 0; ks < 4; ++ks) tf[ks] = HAS_BN ? reinterpret_cast<const float4*>(in_bn)[4 * ks + lk] : float4{0.f, 1.f, 1.f, 0.f};
   // B = x[b][ci = 4 ks + lk][16 t + lr], fetched one image ahead
   float xb[MAXT][4];
   auto prefetch = [&](int b) {
@@ -68,10 +69,11 @@ __global__ __launch_bounds__(512) void k_fwd(const float* __restrict__ x, const 
       if (t < NTILE) {                               // wave-uniform
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) {
+          const float xv = HAS_BN ? bn_relu(xb[j][ks], tf[ks]) : xb[j][ks];
 #pragma unroll
-          for (int c = 0; c < 2; ++c)
-            acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks][c], in_bn ? bn_relu(xb[j][ks], tf[ks]) : xb[j][ks], acc[c], 0, 0, 0);
+          for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks][c], xv, acc[c], 0, 0, 0);
+        }
         // lane: source pixel 16 t + lr, taps 16 c + 4 lk + r
         const int p = 16 * t + lr, pa = (p / H + 2) * WP + p % H + 2;
 #pragma unroll

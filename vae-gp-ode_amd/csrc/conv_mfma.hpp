@@ -386,7 +386,7 @@ template <class L> struct WgradGeo {
   static_assert(L::S == 1 || L::S == 2, "stride");
 };
 
-template <class L, int IPB, int WM, int WN, int WT, bool PIPE, int NTHR>
+template <class L, int IPB, int WM, int WN, int WT, bool PIPE, bool HAS_BN, int NTHR>
 __global__ __launch_bounds__(NTHR) void k_convT_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ gy,
                                                             float* __restrict__ part, int B, const float* __restrict__ in_bn) {
   using G = WgradGeo<L>;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(NTHR) void k_convT_wgrad_mfma(const float* __restri
   float* s_x = igemm_smem;                           // [IPB][CI][PSX]
   float* s_g = igemm_smem + IPB * IMGX;              // [IPB][CO][PSG]
   float4* s_tf = reinterpret_cast<float4*>(igemm_smem + IPB * (IMGX + IMGG));   // optional BatchNorm + ReLU of x, as in k_conv_igemm
-  if (in_bn)
+  if (HAS_BN)
     for (int e = threadIdx.x; e < CI; e += NTHR) s_tf[e] = reinterpret_cast<const float4*>(in_bn)[e];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(NTHR) void k_convT_wgrad_mfma(const float* __restri
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int e = 4 * f + k, pl = e / NPIX;
-          s_x[pl * PSX + e % NPIX] = in_bn ? bn_relu(v[k], s_tf[pl % CI]) : v[k];
+          s_x[pl * PSX + e % NPIX] = HAS_BN ? bn_relu(v[k], s_tf[pl % CI]) : v[k];
         }
       }
     }
@@ -481,6 +481,8 @@ __global__ __launch_bounds__(NTHR) void k_convT_wgrad_mfma(const float* __restri
     // k loop over (image, 4-pixel step), operands of step s+1 in flight while the MFMAs of step s issue
     const int nsteps = nimg * NKS;
     float afA[MTW], bfA[NTAPW][NTW], afB[MTW], bfB[NTAPW][NTW];
+    // (addresses are recomputed from s each step: an incremental (row, column) update was measured 17 % slower -- the
+    // loop-carried dependence serialises the address arithmetic in front of the LDS fetches)
     auto fetch = [&](int s, float (&af)[MTW], float (&bf)[NTAPW][NTW]) {
       const int im = s / NKS, ks = s % NKS;
       const int p = 4 * ks + lk, pc = min(p, NPIX - 1), iy = pc / HI, ix = pc % HI;   // tail pixels: x is zero there

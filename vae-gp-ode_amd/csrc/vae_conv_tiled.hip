@@ -437,11 +437,13 @@ template <class L, int IPBM, int WM, int WN, int WT, bool PIPE>
 static int launch_wgrad_mfma(const float* x, const float* gy, float* gw, float* scratch, int B, hipStream_t st, const float* in_bn) {
   constexpr size_t ldsm = wgrad_lds_bytes<L, IPBM>();
   static_assert(ldsm <= 160 * 1024, "LDS budget");
-  auto km = k_convT_wgrad_mfma<L, IPBM, WM, WN, WT, PIPE, 512>;
-  if (set_max_lds((const void*)km, ldsm)) return 1;
+  auto km = k_convT_wgrad_mfma<L, IPBM, WM, WN, WT, PIPE, false, 512>;
+  auto kb = k_convT_wgrad_mfma<L, IPBM, WM, WN, WT, PIPE, true, 512>;
+  if (set_max_lds((const void*)km, ldsm) || set_max_lds((const void*)kb, ldsm)) return 1;
   const int ngroups = (B + IPBM - 1) / IPBM;
   const int nwg = ngroups < 256 ? ngroups : 256;
-  hipLaunchKernelGGL(km, nwg, 512, ldsm, st, x, gy, scratch, B, in_bn);
+  if (in_bn) hipLaunchKernelGGL(kb, nwg, 512, ldsm, st, x, gy, scratch, B, in_bn);
+  else hipLaunchKernelGGL(km, nwg, 512, ldsm, st, x, gy, scratch, B, in_bn);
   const size_t n = (size_t)L::CI * L::CO * L::K * L::K;
   hipLaunchKernelGGL(k_sum_splits_wgrad, (unsigned)((n + 63) / 64), 1024, 0, st, scratch, nwg, L::CI / 16, L::CO / 16, L::K * L::K, gw);
   return check_launch("convT_wgrad_mfma");
@@ -482,8 +484,9 @@ int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) {
     if (use_mfma()) {
       const size_t ldsm = sizeof(float) * dec10::KK * dec10::PST;
-      if (set_max_lds((const void*)dec10::k_fwd, ldsm)) return 1;
-      hipLaunchKernelGGL(dec10::k_fwd, B < 256 ? B : 256, 512, ldsm, st, gy, w, bias, gx, B, in_bn);
+      if (set_max_lds((const void*)dec10::k_fwd<true>, ldsm) || set_max_lds((const void*)dec10::k_fwd<false>, ldsm)) return 1;
+      if (in_bn) hipLaunchKernelGGL(dec10::k_fwd<true>, B < 256 ? B : 256, 512, ldsm, st, gy, w, bias, gx, B, in_bn);
+      else hipLaunchKernelGGL(dec10::k_fwd<false>, B < 256 ? B : 256, 512, ldsm, st, gy, w, bias, gx, B, in_bn);
       return check_launch("dec10_fwd_mfma");
     }
     constexpr int IPB = 2;
