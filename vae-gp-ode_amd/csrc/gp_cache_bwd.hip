@@ -140,24 +140,31 @@ __global__ __launch_bounds__(256) void k_linv_dc(int step, int sb, int npairs, i
   const int row0 = (c0 + rb) * NB, col0 = (a0 + cb) * NB;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   const int k_lo = step == 0 ? cb : 0, k_hi = step == 0 ? sb : rb + 1;
-  for (int kb = k_lo; kb < k_hi; ++kb) {
+  const float* P = step == 0 ? Lm : Li;
+  const float* Q = step == 0 ? Li : T;
+  float ra[4], rq[4];                                // next k-block's tiles, in flight during the current product
+  auto load = [&](int kb) {
     const int kcol = (step == 0 ? a0 + kb : c0 + kb) * NB;           // P columns / Q rows
-    const float* P = step == 0 ? Lm : Li;
-    const float* Q = step == 0 ? Li : T;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = ty + 8 * q;
-      sA[r][tx] = (step == 1 || row0 + r < n) ? P[(size_t)(row0 + r) * np + kcol + tx] : 0.f;   // rows >= n of L are not part of the factor
-      sB[r][tx] = Q[(size_t)(kcol + r) * np + col0 + tx];
+      ra[q] = (step == 1 || row0 + r < n) ? P[(size_t)(row0 + r) * np + kcol + tx] : 0.f;   // rows >= n of L are not part of the factor
+      rq[q] = Q[(size_t)(kcol + r) * np + col0 + tx];
     }
+  };
+  if (k_lo < k_hi) load(k_lo);
+  for (int kb = k_lo; kb < k_hi; ++kb) {
     __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sA[ty + 8 * q][tx] = ra[q]; sB[ty + 8 * q][tx] = rq[q]; }
+    __syncthreads();
+    if (kb + 1 < k_hi) load(kb + 1);
 #pragma unroll 8
     for (int p = 0; p < NB; ++p) {
       const float bv = sB[p][tx];
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[q] = fmaf(sA[ty + 8 * q][p], bv, acc[q]);
     }
-    __syncthreads();
   }
   float* out = step == 0 ? T : Li;
 #pragma unroll
@@ -238,7 +245,6 @@ __global__ void k_gUs(int M, int Do, const float* __restrict__ g_u, const float*
 __global__ __launch_bounds__(256) void k_gemm_phiX(const float* __restrict__ Linv_all, size_t batch_stride, int np, int nbn,
                                                     const float* __restrict__ vec_all, float* __restrict__ X_all) {
   __shared__ float sA[NB][NB + 1], sP[NB][NB + 1];
-  __shared__ float sri[NB], sqi[NB], sqj[NB], svj[NB];
   const int ab = blockIdx.x, jb = blockIdx.y, b = blockIdx.z, nb = gridDim.z;
   const float* Li = Linv_all + (size_t)b * batch_stride;
   float* X = X_all + (size_t)b * batch_stride;
@@ -246,21 +252,26 @@ __global__ __launch_bounds__(256) void k_gemm_phiX(const float* __restrict__ Lin
   const float* vr = vec_all + (size_t)(3 * nb + b) * np;
   const float* vv = vec_all + (size_t)(4 * nb + b) * np;
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-  if (tid < NB) { sqj[tid] = vq[jb * NB + tid]; svj[tid] = vv[jb * NB + tid]; }
+  const float qj = vq[jb * NB + tx], vj = vv[jb * NB + tx];         // column quantities of this thread
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int ib = (ab > jb ? ab : jb); ib < nbn; ++ib) {
-    __syncthreads();
-    if (tid < NB) { sri[tid] = vr[ib * NB + tid]; sqi[tid] = vq[ib * NB + tid]; }
-    __syncthreads();
+  float ra[4], rp[4];                                                // next block: Linv tile and the Phi tile generated on the fly
+  auto load = [&](int ib) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int p = ty + 8 * q;
-      sA[p][tx] = Li[(size_t)(ib * NB + p) * np + ab * NB + tx];  // Linv[i][a]
-      const int gi = ib * NB + p, gj = jb * NB + tx;
-      const float ph = -sri[p] * sqj[tx] + sqi[p] * svj[tx];
-      sP[p][tx] = gi > gj ? ph : (gi == gj ? 0.5f * ph : 0.f);
+      const int p = ty + 8 * q, gi = ib * NB + p, gj = jb * NB + tx;
+      ra[q] = Li[(size_t)gi * np + ab * NB + tx];                    // Linv[i][a]
+      const float ph = -vr[gi] * qj + vq[gi] * vj;
+      rp[q] = gi > gj ? ph : (gi == gj ? 0.5f * ph : 0.f);
     }
+  };
+  const int ib0 = ab > jb ? ab : jb;
+  load(ib0);
+  for (int ib = ib0; ib < nbn; ++ib) {
     __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sA[ty + 8 * q][tx] = ra[q]; sP[ty + 8 * q][tx] = rp[q]; }
+    __syncthreads();
+    if (ib + 1 < nbn) load(ib + 1);
 #pragma unroll 8
     for (int p = 0; p < NB; ++p) {
       const float pv = sP[p][tx];
@@ -282,15 +293,23 @@ __global__ __launch_bounds__(256) void k_gemm_S(const float* __restrict__ X_all,
   float* Sm = S_all + (size_t)b * batch_stride;
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int jb = cb; jb < nbn; ++jb) {
-    __syncthreads();
+  // tiles of k-block jb + 1 travel to registers while block jb is multiplied (the loop is latency-, not bandwidth-bound)
+  float ra[4], rb[4];
+  auto load = [&](int jb) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = ty + 8 * q;
-      sA[r][tx] = X[(size_t)(ab * NB + r) * np + jb * NB + tx];
-      sB[r][tx] = Li[(size_t)(jb * NB + r) * np + cb * NB + tx];
+      ra[q] = X[(size_t)(ab * NB + r) * np + jb * NB + tx];
+      rb[q] = Li[(size_t)(jb * NB + r) * np + cb * NB + tx];
     }
+  };
+  load(cb);
+  for (int jb = cb; jb < nbn; ++jb) {
     __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sA[ty + 8 * q][tx] = ra[q]; sB[ty + 8 * q][tx] = rb[q]; }
+    __syncthreads();
+    if (jb + 1 < nbn) load(jb + 1);
 #pragma unroll 8
     for (int p = 0; p < NB; ++p) {
       const float bv = sB[p][tx];
