@@ -176,3 +176,29 @@ def test_degenerate_batches_and_grids(name, kernel, order):
     assert torch.equal(out[:z0.shape[0]], full) and torch.equal(out[-1], full[(259 - 1) % z0.shape[0]])
     zs, xs = ops.rollout(c, z0, ts[:1], order, 'rk4', save_stages=True)
     assert xs.shape[1] == 0
+
+
+def test_df_sixteen_dimensional_latent_forward():
+    """The D = 16 divergence-free path of BASELINE configs[4] at a reduced inducing count (M = 64 -> a 1024 x 1024 K_uu,
+    32 block columns of the blocked Cholesky): cache build and RK4 rollout against the oracle evaluated in fp64 on the
+    same parameters and noise."""
+    from vae_gp_ode_amd import ops
+    D, M, S, N, T = 16, 64, 256, 8, 6
+    g = torch.Generator().manual_seed(31)
+    p = dict(raw_ell=O.invsoftplus(2.0 * (1 + 0.05 * torch.rand(D, D, generator=g))), raw_var=O.invsoftplus(torch.ones(D)),
+             Z=torch.randn(M, D, generator=g) * 2.0, Um=torch.randn(M, D, generator=g) * 0.1,
+             Us=torch.zeros(D, M * (M + 1) // 2))
+    idx = torch.tensor([n * (n + 1) // 2 + n for n in range(M)])
+    p['Us'][:, idx] = 1e-2
+    nz = dict(rff_w=torch.randn(2 * S, D, generator=g), rff_eps=torch.randn(D, S, D, generator=g),
+              rff_u=torch.rand(1, S, D, generator=g), eps_u=torch.randn(M, D, generator=g))
+    z0, ts = torch.randn(N, D, generator=g), 0.1 * torch.arange(T, dtype=torch.float)
+    c = ops.cache_build('DF', *[p[k].cuda() for k in ('raw_ell', 'raw_var', 'Z', 'Um', 'Us')],
+                        *[nz[k].cuda() for k in ('eps_u', 'rff_w', 'rff_eps', 'rff_u')])
+    c.check_factorisation()
+    zt = ops.rollout(c, z0.cuda(), ts.cuda(), 1, 'rk4')
+    c32 = O.build_cache(p, nz, 'DF')
+    c64 = O.build_cache(O.to_dtype(p, torch.float64), O.to_dtype(nz, torch.float64), 'DF')
+    z32 = O.flow_forward(z0, ts, c32, 1, 'rk4')
+    z64 = O.flow_forward(z0.double(), ts.double(), c64, 1, 'rk4')
+    assert relerr(zt, z64) < 2e-4 + 3 * relerr(z32, z64), (relerr(zt, z64), relerr(z32, z64))
