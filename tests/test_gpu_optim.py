@@ -152,3 +152,22 @@ def test_graph_replay_equals_eager_steps():
                 assert torch.equal(a, b), (use_graph, overlap, bucketed)
     finally:
         ops.set_overlap(False)
+
+
+def test_vae_pretraining_loop_feeds_pretrained_run(tmp_path, monkeypatch):
+    """main_vae.py's training loop on synthetic frames (loss decreases, checkpoints written), then main.py --pretrained on
+    exactly those checkpoints."""
+    import os
+    from vae_gp_ode_amd import main as M
+    from vae_gp_ode_amd import main_vae as MV
+    monkeypatch.chdir(tmp_path)
+    args = MV.make_parser().parse_args(['--synthetic', 'True', '--n_train', '8', '--n_angle', '4', '--batch', '16', '--vae_epochs', '6',
+                                        '--lr', '2e-3', '--log_freq', '1'])
+    args.device = 'cuda'
+    lines = []
+    vae, meters = MV.vae_train(args, MV.load_images(args).clamp(0.05, 0.95), args.vae_epochs, str(tmp_path / 'MNIST-VAE'), log=lines.append)
+    first = float(lines[0].split('elbo')[1].split('(')[0])
+    assert meters['elbo'].val < first and os.path.exists(tmp_path / 'MNIST-VAE' / 'decoder.pt')
+    M.main(['--task', 'synthetic', '--Ndata', '8', '--Ntest', '4', '--batch', '4', '--T', '6', '--solver', 'rk4', '--num_inducing', '16',
+            '--num_features', '32', '--lr', '1e-4', '--log_freq', '1', '--Nepoch', '1', '--save', 'results/pv', '--pretrained', 'True',
+            '--vae_path', str(tmp_path / 'MNIST-VAE')])
