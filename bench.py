@@ -227,9 +227,13 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
     from vae_gp_ode_amd.parallel import GradAllReduce
     model, X = make_model_inputs(w, a.seed, dev, rank)
     Xd = X.to(dev)
-    # lr 1e-4: with the reference's lr = 1e-3 = initial diag(Us_sqrt), Adam's first step lands some diagonal entries
-    # on exactly 0 under random-noise images (log 0 in the inducing KL); the update kernel does the same work.
-    opt = HipAdam(model.parameters(), lr=1e-4, bucketed=dist is not None)   # one GPU: no gradient bucket to all-reduce
+    # lr 1e-6: the step does the same work at any learning rate, and a benchmark must finish whatever --steps is.  With the
+    # reference's lr = 1e-3 = initial diag(Us_sqrt), Adam's first step lands some diagonal entries on exactly 0 (log 0 in the
+    # inducing KL); and on random-noise targets normalised to [-0.42, 2.8] (data/utils.py:8-15) the Bernoulli likelihood is
+    # unbounded, so any learning rate that moves the decoder drives sigmoid outputs to exactly 1.0f within a few
+    # thousand steps (lr 1e-4: non-finite loss before step 5000).  Adam moves a parameter by <= lr per step: 1e-6 keeps 1e5 steps
+    # within 0.1 of the initial state.
+    opt = HipAdam(model.parameters(), lr=1e-6, bucketed=dist is not None)   # one GPU: no gradient bucket to all-reduce
     sync = GradAllReduce(opt.flat_grads, dist) if dist is not None else None
     last = {}
 
