@@ -380,14 +380,29 @@ def run_integrator(a, w, dev, rank, n_gpus, dist, barrier):
     if not torch.equal(flow(z0d, tsd), step()):
         raise SystemExit('Flow.forward and the bracketed step disagree')
 
-    for _ in range(a.warmup):
+    # rollout launch duration: a few eager steps bracketed by events on the launch stream
+    for _ in range(max(a.warmup, 1)):
         step()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(a.steps, 20))]
+    for ev in evs:
+        zt = step(ev)
+    torch.cuda.synchronize()
+    # the timed loop replays the draw + rollout as one HIP graph (the cache build alone is ~25 dependent launches)
+    run, graphed = step, False
+    if not a.no_graph:
+        try:
+            from vae_gp_ode_amd.graph import GraphedStep
+            g = GraphedStep(step, warmup=1)
+            run, graphed = g, True
+        except Exception as e:
+            print('[bench] HIP graph capture failed (%s); running the step eagerly' % type(e).__name__, file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        zt = run()
     barrier()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        zt = step(evs[k])
+        zt = run()
     barrier()
     el = time.perf_counter() - t0
     if not torch.isfinite(zt).all():
@@ -408,7 +423,7 @@ def run_integrator(a, w, dev, rank, n_gpus, dist, barrier):
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': w['desc'] + '; step = GP draw (K_uu, Cholesky, nu) + rk4 rollout, L=1 [integrator fwd]',
                    'global_batch': w['batch'] * n_gpus, 'solver': 'rk4 (3/8 rule)', 'parallelism': 'dp%d' % n_gpus,
-                   'hip_graph': False},
+                   'hip_graph': graphed},
         'roofline': {'bound': 'mfma', 'kernel': 'rollout_kernel', 'achieved': achieved, 'peak': PEAK_FP32_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS, 'traffic': None,
                      'ms_per_launch': roll_ms,
