@@ -4,6 +4,7 @@ import types
 import pytest
 import torch
 
+from conftest import sub
 from test_gpu_forward import relerr
 
 pytestmark = pytest.mark.gpu
@@ -171,3 +172,63 @@ def test_vae_pretraining_loop_feeds_pretrained_run(tmp_path, monkeypatch):
     M.main(['--task', 'synthetic', '--Ndata', '8', '--Ntest', '4', '--batch', '4', '--T', '6', '--solver', 'rk4', '--num_inducing', '16',
             '--num_features', '32', '--lr', '1e-4', '--log_freq', '1', '--Nepoch', '1', '--save', 'results/pv', '--pretrained', 'True',
             '--vae_path', str(tmp_path / 'MNIST-VAE')])
+
+
+def test_training_trajectory_matches_the_oracle_over_several_steps():
+    """Four full training steps (encoder, GP draw, rollout, decoder, ELBO, backward, Adam) from the reference's own initial
+    state (fixture model_df1_tiny) with identical noise fed to both sides: the loss sequence and the parameters after the last
+    step against the pinned torch-CPU oracle + torch.optim.Adam.  Tolerance |hip - oracle32| <= base + 3 |oracle32 - oracle64|."""
+    import copy
+    from oracle import gpode_oracle as O
+    from test_gpu_model import CASES, make_model
+    from vae_gp_ode_amd.model.create_model import compute_loss
+    from vae_gp_ode_amd.optim import HipAdam
+    name, kw, L = CASES[2]
+    m, g = make_model(name, kw, L)
+    X = g['X']
+    N, q, M, S = X.shape[0], 6, 16, 32
+    gen = torch.Generator().manual_seed(77)
+    draws = [dict(nz=dict(eps_u=torch.randn(M, q, generator=gen), rff_w=torch.randn(2 * S, q, generator=gen),
+                          rff_eps=torch.randn(q, S, q, generator=gen), rff_u=torch.rand(1, S, q, generator=gen)),
+                  eps=torch.randn(N, q, generator=gen)) for _ in range(4)]
+    lr = 1e-3
+
+    def run_oracle(dtype):
+        sd = {k: (v.detach().cpu().to(dtype).clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k and '_num_evals' not in k
+                  else v.detach().cpu().clone()) for k, v in sub(g, 'sd.').items()}
+        opt = torch.optim.Adam([v for v in sd.values() if v.requires_grad], lr=lr)
+        losses = []
+        for d in draws:
+            opt.zero_grad()
+            r = O.compute_loss(X.to(dtype), sd, [O.to_dtype(d['nz'], dtype)], d['eps'].to(dtype), None, kernel='DF', order=1, method='rk4',
+                               dt=0.1, Ndata=360)
+            r['loss'].backward()
+            opt.step()
+            losses.append(r['loss'].item())
+        return losses, sd
+    l32, sd32 = run_oracle(torch.float32)
+    l64, sd64 = run_oracle(torch.float64)
+    opt = HipAdam(m.parameters(), lr=lr)
+    gp = m.flow.odefunc.diffeq
+    gp._next_noise.clear()            # make_model queued the fixture's own draw
+    lh = []
+    for d in draws:
+        gp.set_noise({k: v.cuda() for k, v in d['nz'].items()})
+        m.vae.encoder.next_eps = d['eps'].cuda()
+        opt.zero_grad()
+        loss, *_ = compute_loss(m, X.cuda(), 1)
+        loss.backward()
+        opt.step()
+        lh.append(loss.item())
+    for a, b, c in zip(lh, l32, l64):
+        assert abs(a - b) <= 1e-5 * abs(b) + 3 * abs(b - c), (lh, l32, l64)
+    sdh = m.state_dict()
+    worst = 0.0
+    for k, v in sd32.items():
+        if not (torch.is_tensor(v) and v.requires_grad):
+            continue
+        tol = 2e-3 + 3 * relerr(v, sd64[k])
+        err = relerr(sdh[k], v)
+        worst = max(worst, err / tol)
+        assert err < tol, (k, err, tol)
+    print('worst err/tol over parameters after 4 steps: %.2f' % worst)
