@@ -100,3 +100,23 @@ def test_bias_gradients_ride_on_the_batchnorm_backward():
     loss, *_ = compute_loss(m, g['X'].cuda(), L)
     loss.backward()
     assert V.fused_bias_grads - before == 5
+
+
+def test_t_custom_extrapolation_prefix_property():
+    """ODEGPVAE.forward(X, L, T_custom) (odegpvae.py:51-53, used by the plotting / test-error code to roll out beyond the
+    observed window): the first T frames of a longer rollout under the same draw equal the T-frame rollout, and the shape
+    follows T_custom."""
+    name, kw, L = CASES[2]
+    m, g = make_model(name, kw, L)
+    X = g['X'].cuda()
+    T = X.shape[1]
+    gp = m.flow.odefunc.diffeq
+    nz = {k: v.cuda() for k, v in sub(g, 'noise0.').items()}
+    m.eval()           # evaluation-mode BatchNorm: reconstructions of different lengths then see identical statistics
+    with torch.no_grad():
+        gp._next_noise.clear(); gp.set_noise(nz); m.vae.encoder.next_eps = g['eps_s'].cuda()
+        a, _, _ = m(X, 1)
+        gp.set_noise(nz); m.vae.encoder.next_eps = g['eps_s'].cuda()
+        b, _, _ = m(X, 1, T_custom=2 * T)
+    assert tuple(a.shape) == (1, X.shape[0], T, 1, 28, 28) and tuple(b.shape) == (1, X.shape[0], 2 * T, 1, 28, 28)
+    assert torch.equal(a, b[:, :, :T])
