@@ -29,21 +29,25 @@ class ODEGPVAE(nn.Module):
             return self.flow(z0, ts).unsqueeze(0)
         return torch.stack([self.flow(z0, ts) for _ in range(L)], 0)
 
+    def encode_initial_state(self, X):
+        """q(z0 | X): position code from the first frame, velocity code (order 2) from the first ``v_steps`` frames stacked as
+        channels; returns the reparameterised sample and the (mean, log-variance) pairs the ELBO needs (odegpvae.py:55-63)."""
+        pos = self.vae.encoder
+        mu_s, logv_s = pos(X[:, 0])
+        z0 = pos.sample(mu=mu_s, logvar=logv_s)
+        if self.order == 1:
+            return z0, (mu_s, logv_s), (None, None)
+        vel = self.vae.encoder_v
+        mu_v, logv_v = vel(torch.squeeze(X[:, 0:self.v_steps]))
+        return torch.concat([z0, vel.sample(mu=mu_v, logvar=logv_v)], dim=1), (mu_s, logv_s), (mu_v, logv_v)
+
     def forward(self, X, L=1, T_custom=None):
+        """X (N,T,nc,d,d) -> (Xrec (L,N,T',nc,d,d), (mu_s, logv_s), (mu_v, logv_v)); T' = T_custom or T (odegpvae.py:48-70)."""
         N, T, nc, d, _ = X.shape
-        if T_custom:
-            T = T_custom
-        enc = self.vae.encoder
-        gp = self.flow.odefunc.diffeq
-        if L == 1 and hasattr(gp, 'prebuild_cache'):
-            gp.prebuild_cache()                      # overlap mode only: the draw's cache builds next to the encoder
-        s0_mu, s0_logv = enc(X[:, 0])
-        z0 = enc.sample(mu=s0_mu, logvar=s0_logv)
-        v0_mu = v0_logv = None
-        if self.order == 2:
-            enc_v = self.vae.encoder_v
-            v0_mu, v0_logv = enc_v(torch.squeeze(X[:, 0:self.v_steps]))
-            z0 = torch.concat([z0, enc_v.sample(mu=v0_mu, logvar=v0_logv)], dim=1)
-        ztL = self.sample_trajectories(z0, T, L)
-        Xrec = self.build_decoding(ztL, (L, N, T, nc, d, d))
-        return Xrec, (s0_mu, s0_logv), (v0_mu, v0_logv)
+        horizon = T_custom if T_custom else T
+        field = self.flow.odefunc.diffeq
+        if L == 1 and hasattr(field, 'prebuild_cache'):
+            field.prebuild_cache()                   # overlap mode only: the draw's cache builds next to the encoder
+        z0, code_s, code_v = self.encode_initial_state(X)
+        ztL = self.sample_trajectories(z0, horizon, L)
+        return self.build_decoding(ztL, (L, N, horizon, nc, d, d)), code_s, code_v

@@ -9,11 +9,14 @@ from .core.vae import VAE
 
 
 def build_model(args):
-    gp = SVGP_Layer(D_in=args.D_in, D_out=args.D_out, M=args.num_inducing, S=args.num_features,
-                    dimwise=args.dimwise, q_diag=args.q_diag, device=args.device, kernel=args.kernel)
-    flow = Flow(diffeq=gp, order=args.ode, solver=args.solver, use_adjoint=args.use_adjoint)
-    vae = VAE(frames=args.frames, n_filt=args.n_filt, latent_dim=args.latent_dim, order=args.ode, device=args.device)
-    return ODEGPVAE(flow=flow, vae=vae, num_observations=args.Ndata, order=args.ode, steps=args.frames, dt=args.dt)
+    """GP vector field -> Flow -> VAE -> ODEGPVAE from the argument namespace of main.py (create_model.py:16-33 reads the
+    same fields).  The construction order fixes the order of the numpy draws that initialise the GP parameters."""
+    a = args
+    field = SVGP_Layer(a.D_in, a.D_out, a.num_inducing, a.num_features, q_diag=a.q_diag, dimwise=a.dimwise, device=a.device,
+                       kernel=a.kernel)
+    return ODEGPVAE(flow=Flow(field, order=a.ode, solver=a.solver, use_adjoint=a.use_adjoint),
+                    vae=VAE(frames=a.frames, n_filt=a.n_filt, latent_dim=a.latent_dim, device=a.device, order=a.ode),
+                    num_observations=a.Ndata, steps=a.frames, order=a.ode, dt=a.dt)
 
 
 def elbo(model, X, Xrec, s0_mu, s0_logv, v0_mu, v0_logv, L):

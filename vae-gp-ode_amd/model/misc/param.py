@@ -1,5 +1,7 @@
-"""Constrained parameter wrapper (mirrors experiments/model/misc/param.py:7-28): the trainable tensor is
-``optvar`` (unconstrained); calling the module returns the constrained value."""
+"""Constrained parameter: the trainable tensor is the UNCONSTRAINED ``optvar`` (that is what the optimiser, the checkpoint
+and the HIP kernels see); evaluating the module maps it through the transform.  API of experiments/model/misc/param.py:7-28
+(``Param(value, transform, name)``, ``.optvar``, ``param()``), which the reference borrows from GPflow's Parameter."""
+import numpy as np
 import torch
 
 from . import transforms
@@ -8,14 +10,16 @@ from .settings import settings
 
 class Param(torch.nn.Module):
     def __init__(self, value, transform=None, name='var'):
-        super().__init__()
-        self.transform = transform if transform is not None else transforms.Identity()
+        torch.nn.Module.__init__(self)
         self.name = name
-        raw = self.transform.backward(value)
-        self.optvar = torch.nn.Parameter(torch.tensor(data=raw, dtype=settings.torch_float, device=settings.device))
+        self.transform = transforms.Identity() if transform is None else transform
+        unconstrained = np.asarray(self.transform.backward(value))       # constrained initial value -> optimisation variable
+        self.register_parameter('optvar', torch.nn.Parameter(
+            torch.as_tensor(unconstrained, dtype=settings.torch_float).to(settings.device)))
 
-    def __call__(self):
+    def forward(self):
+        """The constrained value (differentiable w.r.t. ``optvar``)."""
         return self.transform.forward_tensor(self.optvar)
 
     def __repr__(self):
-        return '{} parameter with {}'.format(self.name, self.transform)
+        return '%s parameter with %s' % (self.name, self.transform)
