@@ -171,7 +171,7 @@ extern __shared__ __attribute__((aligned(16))) float igemm_smem[];
 // (stride-2 layers with an even output width: without it every 64-byte line of y is written twice, half each time --
 // measured 401 MB of HBM writes for a 205 MB output).
 template <class PL, int IPB, int TG, int NCJ, bool PAIR, int NTHR>
-__global__ __launch_bounds__(NTHR) void k_conv_igemm(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y, int B,
                                                       const float* __restrict__ in_bn) {
   constexpr int KC = PL::KC, NC = PL::NC, NCS = PL::NCS, NCLS = PL::NCLS, SH = PL::SH, OH = PL::OH, HP = PL::HP, PS = PL::PS;
@@ -387,7 +387,7 @@ template <class L> struct WgradGeo {
 };
 
 template <class L, int IPB, int WM, int WN, int WT, bool PIPE, bool HAS_BN, int NTHR>
-__global__ __launch_bounds__(NTHR) void k_convT_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ gy,
+__global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_convT_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ gy,
                                                             float* __restrict__ part, int B, const float* __restrict__ in_bn) {
   using G = WgradGeo<L>;
   constexpr int CI = L::CI, CO = L::CO, HI = L::HI, HO = L::HO, K = L::K, S = L::S, P = L::P, KK = K * K;

@@ -347,8 +347,8 @@ static inline int pick_split(int B, int nblocks_per_split) {
 // scratch: conv_wgrad_scratch_floats(...) floats
 size_t conv_wgrad_scratch(int B, int Ci, int Co, int K) {
   const size_t generic = (size_t)pick_split(B, Co * Ci) * Co * Ci * K * K + (size_t)64 * Co * 2;
-  // the tiled weight-gradient kernels split the batch into up to 256 slabs of Co*Ci*K*K floats
-  const size_t tiled = (size_t)(B < 256 ? B : 256) * Co * Ci * K * K + (size_t)64 * Co * 2;
+  // the tiled weight-gradient kernels split the batch into up to 512 slabs (two workgroups per CU) of Co*Ci*K*K floats
+  const size_t tiled = (size_t)(B < 512 ? B : 512) * Co * Ci * K * K + (size_t)64 * Co * 2;
   return generic > tiled ? generic : tiled;
 }
 

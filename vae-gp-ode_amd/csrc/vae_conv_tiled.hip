@@ -388,16 +388,18 @@ static bool use_mfma() {
 }
 
 // matrix-core path (conv_mfma.hpp): persistent grid of one 512-thread workgroup per CU
-template <class PL, int IPB, int TG, int NCJ, bool PAIR = false>
+// NTHR = 256 with a footprint <= 80 KB: TWO independent 4-wavefront workgroups per CU, whose scatter / store phases interleave
+// with each other's MFMA phases instead of idling the matrix pipe in lockstep
+template <class PL, int IPB, int TG, int NCJ, bool PAIR = false, int NTHR = 512>
 static int launch_igemm(const float* x, const float* w, const float* bias, float* y, int B, hipStream_t st, const char* what,
                         const float* in_bn = nullptr) {
-  constexpr int NTHR = 512;
   constexpr size_t lds = igemm_lds_bytes<PL, IPB>();
-  static_assert(lds <= 160 * 1024, "LDS budget");
+  static_assert(lds <= (NTHR == 512 ? 160 : 80) * 1024, "LDS budget");
   auto km = k_conv_igemm<PL, IPB, TG, NCJ, PAIR, NTHR>;
   if (set_max_lds((const void*)km, lds)) return 1;
   const int ngroups = (B + IPB - 1) / IPB;
-  hipLaunchKernelGGL(km, ngroups < 256 ? ngroups : 256, NTHR, lds, st, x, w, bias, y, B, in_bn);
+  const int cap = 256 * (512 / NTHR);
+  hipLaunchKernelGGL(km, ngroups < cap ? ngroups : cap, NTHR, lds, st, x, w, bias, y, B, in_bn);
   return check_launch(what);
 }
 
@@ -420,11 +422,11 @@ static int launch_T1(const float* x, const float* w, const float* bias, float* y
 }
 
 // IPBM / CIS / TG / NCJ: images per group, input channels per pass, pixel tiles and channel tiles per job of the MFMA kernel
-template <class L, int IPB, int COC, int IPBM, int CIS, int TG, int NCJ>
+template <class L, int IPB, int COC, int IPBM, int CIS, int TG, int NCJ, int NTHR = 512>
 static int launch_T2(const float* gy, const float* w, float* gx, int B, hipStream_t st) {
   if constexpr (IPBM > 0) {
     if (use_mfma() && (reinterpret_cast<uintptr_t>(gy) & 15) == 0)
-      return launch_igemm<BwdDataPolicy<L, CIS>, IPBM, TG, NCJ>(gy, w, nullptr, gx, B, st, "convT_bwd_data_mfma");
+      return launch_igemm<BwdDataPolicy<L, CIS>, IPBM, TG, NCJ, false, NTHR>(gy, w, nullptr, gx, B, st, "convT_bwd_data_mfma");
   }
   const size_t lds = sizeof(float) * ((size_t)IPB * L::CO * L::GP_ * L::GP_ + (size_t)COC * L::K * L::K * L::CI);
   auto kern = k_convT_bwd_data<L, IPB, COC>;
@@ -435,15 +437,17 @@ static int launch_T2(const float* gy, const float* w, float* gx, int B, hipStrea
 
 template <class L, int IPBM, int WM, int WN, int WT, bool PIPE>
 static int launch_wgrad_mfma(const float* x, const float* gy, float* gw, float* scratch, int B, hipStream_t st, const float* in_bn) {
+  constexpr int NTHR = WM * WN * WT * 64;            // 512: one workgroup per CU; 256: two (footprint <= 80 KB)
   constexpr size_t ldsm = wgrad_lds_bytes<L, IPBM>();
-  static_assert(ldsm <= 160 * 1024, "LDS budget");
-  auto km = k_convT_wgrad_mfma<L, IPBM, WM, WN, WT, PIPE, false, 512>;
-  auto kb = k_convT_wgrad_mfma<L, IPBM, WM, WN, WT, PIPE, true, 512>;
+  static_assert(ldsm <= (NTHR == 512 ? 160 : 80) * 1024, "LDS budget");
+  auto km = k_convT_wgrad_mfma<L, IPBM, WM, WN, WT, PIPE, false, NTHR>;
+  auto kb = k_convT_wgrad_mfma<L, IPBM, WM, WN, WT, PIPE, true, NTHR>;
   if (set_max_lds((const void*)km, ldsm) || set_max_lds((const void*)kb, ldsm)) return 1;
   const int ngroups = (B + IPBM - 1) / IPBM;
-  const int nwg = ngroups < 256 ? ngroups : 256;
-  if (in_bn) hipLaunchKernelGGL(kb, nwg, 512, ldsm, st, x, gy, scratch, B, in_bn);
-  else hipLaunchKernelGGL(km, nwg, 512, ldsm, st, x, gy, scratch, B, in_bn);
+  const int cap = 256 * (512 / NTHR);
+  const int nwg = ngroups < cap ? ngroups : cap;
+  if (in_bn) hipLaunchKernelGGL(kb, nwg, NTHR, ldsm, st, x, gy, scratch, B, in_bn);
+  else hipLaunchKernelGGL(km, nwg, NTHR, ldsm, st, x, gy, scratch, B, in_bn);
   const size_t n = (size_t)L::CI * L::CO * L::K * L::K;
   hipLaunchKernelGGL(k_sum_splits_wgrad, (unsigned)((n + 63) / 64), 1024, 0, st, scratch, nwg, L::CI / 16, L::CO / 16, L::K * L::K, gw);
   return check_launch("convT_wgrad_mfma");
@@ -508,7 +512,7 @@ int tiled_fwd(const float* x, const float* w, const float* bias, float* y, int B
     if (matches<Enc6>(Ci, Co, H, Ho, K, S, P)) return launch_igemm<BwdDataPolicy<Enc6, 32>, 8, 1, 2>(x, w, bias, y, B, st, "enc_conv6_fwd_mfma");
   }
   if (bias) return -1;
-  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec7, 2, 8, 2, 32, 2, 2>(x, w, y, B, st);
+  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec7, 2, 8, 1, 16, 2, 1, 256>(x, w, y, B, st);
   if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec4, 3, 8, 2, 32, 1, 1>(x, w, y, B, st);
   if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec1, 8, 32, 6, 32, 1, 1>(x, w, y, B, st);
 
