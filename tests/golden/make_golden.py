@@ -17,6 +17,12 @@ What is NOT: the two third-party imports that are absent here --
 The reference draws its noise from numpy/torch RNGs (partly unseeded, SURVEY F6);
 the three sampler helpers and torch.randn_like are wrapped so every draw is
 recorded and stored with the fixture.
+
+``data_case`` pins the data path (data/utils.py, data/mnist.py): ``data.mnist`` imports
+``torchvision`` (absent; used only for the MNIST download inside create_rotating_dataset),
+so an empty module object of that name is registered for the import and the functions that
+never touch it -- Dataset, rot_start, rotate_img, the rotating part of the dataset builder
+-- run as the reference wrote them on seeded random images.
 """
 import os
 import sys
@@ -262,8 +268,29 @@ def model_case_intermediates(name, kernel, order, N, M, S, q, T, L, solver, seed
     np.savez_compressed(os.path.join(OUT, name + '_fwd.npz'), **out)
 
 
+def data_case(name, seed):
+    """Dataset items, rot_start, rotate_img of the reference on seeded random frames."""
+    for modname in ('torchvision', 'torchvision.transforms'):
+        sys.modules.setdefault(modname, types.ModuleType(modname))
+    sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+    from data import utils as rdu, mnist as rdm
+    rng = np.random.RandomState(seed)
+    seqs = (rng.randint(0, 256, (3, 16, 784)) / 255).astype(np.float32)     # grey levels, like the dataset's
+    ds = rdu.Dataset(seqs)
+    items = np.stack([npy(ds[i]) for i in range(len(ds))])
+    Xtr = torch.tensor(seqs).view(3, 16, 1, 28, 28)
+    np.random.seed(seed + 1)
+    rot = rdm.rot_start(Xtr, 16, 3)
+    digits = (rng.rand(3, 28, 28) * 255).astype(np.uint8)
+    angles = np.rad2deg(np.linspace(0, 2 * np.pi, 8)[1:])
+    rotated = rdm.rotate_img(torch.tensor(digits), angles)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), seqs=seqs, items=items, rot_seed=np.int64(seed + 1), rot=npy(rot),
+                        digits=digits, angles=angles, rotated=rotated)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
+    data_case('data_path', 301)
     # tiny shapes: every variant
     gp_case('gp_rbf1_tiny', 'RBF', 1, N=4, M=16, S=32, q=6, T=5, seed=101)
     gp_case('gp_rbf2_tiny', 'RBF', 2, N=4, M=16, S=32, q=3, T=5, seed=102)

@@ -1,6 +1,7 @@
 """GPU: the one-launch HIP Adam against torch.optim.Adam, and a few real training steps (loss decreases)."""
 import types
 
+import numpy as np
 import pytest
 import torch
 
@@ -172,6 +173,33 @@ def test_vae_pretraining_loop_feeds_pretrained_run(tmp_path, monkeypatch):
     M.main(['--task', 'synthetic', '--Ndata', '8', '--Ntest', '4', '--batch', '4', '--T', '6', '--solver', 'rk4', '--num_inducing', '16',
             '--num_features', '32', '--lr', '1e-4', '--log_freq', '1', '--Nepoch', '1', '--save', 'results/pv', '--pretrained', 'True',
             '--vae_path', str(tmp_path / 'MNIST-VAE')])
+
+
+def test_main_trains_from_the_reference_dataset_file(tmp_path, monkeypatch):
+    """``--task mnist`` on a (synthetic) ``rot_mnist/rot-mnist.mat``: the reference's loader contract, the set resident in HBM,
+    eager and graph-replayed loop (the last minibatch is ragged: 10 sequences in batches of 4)."""
+    import glob
+    import scipy.io as sio
+    from vae_gp_ode_amd import main as M
+    from vae_gp_ode_amd.data.utils import ResidentLoader
+    from vae_gp_ode_amd.data.wrappers import load_data
+    rng = np.random.RandomState(2)
+    root = tmp_path / 'data'
+    (root / 'rot_mnist').mkdir(parents=True)
+    Y = np.tile(np.array([3, 8]), 18)
+    sio.savemat(str(root / 'rot_mnist' / 'rot-mnist.mat'), {'X': (rng.rand(1, 36, 16, 784) > 0.7).astype(np.float32), 'Y': Y[None]})
+    tr, te = load_data(types.SimpleNamespace(data_root=str(root), task='mnist', mask=True, value=3, Ndata=10, Ntest=4, batch=4,
+                                             device='cuda', seed=0, save=str(tmp_path)), plot=False)
+    assert isinstance(tr, ResidentLoader) and tr.items.is_cuda and tr.items.shape == (10, 16, 1, 28, 28) and te.items.shape[0] == 4
+    assert [b.shape[0] for b in tr] == [4, 4, 2]
+    monkeypatch.chdir(tmp_path)
+    common = ['--task', 'mnist', '--data_root', str(root), '--Ndata', '10', '--Ntest', '4', '--batch', '4', '--solver', 'rk4',
+              '--num_inducing', '16', '--num_features', '32', '--lr', '1e-4', '--log_freq', '1', '--Nepoch', '2']
+    M.main(common + ['--save', 'results/d'])
+    M.main(common + ['--save', 'results/dg', '--hip_graph', 'True'])
+    for tag in ('d', 'dg'):
+        ck = glob.glob(str(tmp_path / 'results' / (tag + '_*') / 'odegpvae_mnist.pth'))
+        assert len(ck) == 1 and all(torch.isfinite(v).all() for v in torch.load(ck[0]).values() if v.is_floating_point())
 
 
 def test_training_trajectory_matches_the_oracle_over_several_steps():

@@ -4,9 +4,10 @@ NaN guard, per-epoch evaluation on the first test batch, ``odegpvae_mnist.pth`` 
 ``--continue_training`` / ``--pretrained`` wiring, same log lines.  Every arithmetic step runs in the HIP
 kernels behind ``model/``; the optimizer is the one-launch HIP Adam.
 
-Out of scope here: the data pipeline and the plots.  ``--task mnist`` expects the tensors the
-reference's loader would produce (``<data_root>/rot_mnist_{train,test}.pt``, shape (N,T,1,28,28), already
-z-normalised); ``--task synthetic`` generates rotating blobs so the loop can be exercised without the dataset.
+Data: ``--task mnist`` goes through ``data/wrappers.load_data`` (``<data_root>/rot_mnist/rot-mnist.mat``, the reference's
+file; the set is uploaded once and minibatches are gathered on the device) or, when that file is absent, tensors saved as
+``<data_root>/rot_mnist_{train,test}.pt`` (shape (N,T,1,28,28), already z-normalised); ``--task synthetic`` generates rotating
+blobs so the loop can be exercised without the dataset.  The plots are out of scope.
 """
 import argparse
 import logging
@@ -100,14 +101,23 @@ def synthetic_sequences(n, T, seed):
     return (imgs.clamp(0, 1) - 0.1307) / 0.3081
 
 
+def _frames(batch):
+    """a loader item: the tensor itself (reference loaders, ResidentLoader) or a TensorDataset 1-tuple"""
+    return batch[0] if isinstance(batch, (list, tuple)) else batch
+
+
 def load_data(args):
     if args.task == 'synthetic':
         tr, te = synthetic_sequences(args.Ndata, args.T, args.seed), synthetic_sequences(args.Ntest, args.T, args.seed + 1)
+    elif os.path.exists(os.path.join(args.data_root, 'rot_mnist', 'rot-mnist.mat')):
+        from .data.wrappers import load_data as load_reference_data
+        return load_reference_data(args, plot=False)
     else:
         fn = lambda s: os.path.join(args.data_root, 'rot_mnist_%s.pt' % s)
         if not (os.path.exists(fn('train')) and os.path.exists(fn('test'))):
-            raise FileNotFoundError('%s / %s not found: the reference dataset is an external download (README.md:19); '
-                                    'use --task synthetic to exercise the loop' % (fn('train'), fn('test')))
+            raise FileNotFoundError('neither %s nor %s / %s found: the reference dataset is an external download (README.md:19); '
+                                    'use --task synthetic to exercise the loop'
+                                    % (os.path.join(args.data_root, 'rot_mnist', 'rot-mnist.mat'), fn('train'), fn('test')))
         tr, te = torch.load(fn('train')), torch.load(fn('test'))
     mk = lambda d, shuffle: torch.utils.data.DataLoader(torch.utils.data.TensorDataset(d), batch_size=args.batch, shuffle=shuffle)
     return mk(tr, True), mk(te, False)
@@ -183,8 +193,8 @@ def main(argv=None):
     begin = time.time()
     for ep in range(args.Nepoch):
         L = 1 if ep < args.Nepoch // 2 else 5
-        for itr, (local_batch,) in enumerate(trainset):
-            minibatch = local_batch.to(args.device)
+        for itr, local_batch in enumerate(trainset):
+            minibatch = _frames(local_batch).to(args.device)
             if args.hip_graph:
                 loss, nlhood, kl_reg, kl_u = graphed_step(minibatch, L)
             else:
@@ -203,7 +213,8 @@ def main(argv=None):
                     itr, timedelta(seconds=time.time() - begin), meters['elbo'].val, meters['elbo'].avg, meters['nll'].val, meters['nll'].avg,
                     meters['reg_kl'].val, meters['reg_kl'].avg, meters['inducing_kl'].val, meters['inducing_kl'].avg))
         with torch.no_grad():
-            for (test_batch,) in testset:
+            for test_batch in testset:
+                test_batch = _frames(test_batch)
                 test_batch = test_batch.to(args.device)
                 Xrec, _, _ = model(test_batch)
                 test_mse = compute_test_error(test_batch, Xrec.squeeze(0))

@@ -36,10 +36,15 @@ def load_images(args):
     if args.synthetic:
         g = torch.Generator().manual_seed(args.seed)
         return torch.rand(args.n_train * args.n_angle, 1, 28, 28, generator=g)
-    fn = os.path.join(args.save, 'rotating_mnist_train_3_%d_angles.npy' % args.n_angle)
-    if not os.path.exists(fn):
-        raise FileNotFoundError('%s not found: the reference creates it from a torchvision MNIST download; use --synthetic True '
-                                'to exercise the loop' % fn)
+    fn, fn_test = (os.path.join(args.save, 'rotating_mnist_%s_3_%d_angles.npy' % (s, args.n_angle)) for s in ('train', 'test'))
+    if not os.path.exists(fn):      # main_vae.py:155-165: build the arrays once and keep them next to the digits
+        from .data.mnist import create_rotating_dataset
+        try:
+            train, test = create_rotating_dataset(args.save, digit=args.digit, train_n=args.n_train, test_n=args.n_test, n_angles=args.n_angle)
+        except FileNotFoundError as e:
+            raise FileNotFoundError('%s not found and it cannot be created (%s); use --synthetic True to exercise the loop' % (fn, e))
+        np.save(fn, train)
+        np.save(fn_test, test)
     return torch.tensor(np.load(fn), dtype=torch.float32).reshape(-1, 1, 28, 28)
 
 
