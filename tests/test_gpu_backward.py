@@ -236,3 +236,72 @@ def test_shared_hyperparameter_rbf_matches_reference(name, order, method):
         tol = 1e-3 + 3 * relerr(ref, p64[short].grad)
         assert relerr(got[short], ref) < tol, (short, relerr(got[short], ref), tol)
     assert relerr(z0.grad, gr['z0']) < 5e-4 + 3 * relerr(gr['z0'], z64.grad)
+
+
+def synthetic_gp(kernel, Di, Do, M, S, N, T, seed):
+    """Seeded parameters + noise in the oracle's naming (no fixture exists past the reference's CPU-runnable shapes)."""
+    g = torch.Generator().manual_seed(seed)
+    p = dict(raw_ell=O.invsoftplus(2.0 * (1 + 0.05 * torch.rand(Do, Di, generator=g))), raw_var=O.invsoftplus(torch.ones(Do)),
+             Z=torch.randn(M, Di, generator=g) * 2.0, Um=torch.randn(M, Do, generator=g) * 0.1,
+             Us=torch.zeros(Do, M * (M + 1) // 2))
+    p['Us'][:, torch.tensor([n * (n + 1) // 2 + n for n in range(M)])] = 1e-2
+    p['Us'] += 1e-3 * torch.randn(p['Us'].shape, generator=g) * (p['Us'] == 0)
+    if kernel == 'DF':
+        nz = dict(rff_w=torch.randn(2 * S, Do, generator=g), rff_eps=torch.randn(Di, S, Do, generator=g),
+                  rff_u=torch.rand(1, S, Do, generator=g), eps_u=torch.randn(M, Do, generator=g))
+    else:
+        nz = dict(rff_w=torch.randn(S, Do, generator=g), rff_eps=torch.randn(Di, S, Do, generator=g),
+                  rff_u=torch.rand(1, S, Do, generator=g), eps_u=torch.randn(M, Do, generator=g))
+    return p, nz, torch.randn(N, Di, generator=g), 0.1 * torch.arange(T, dtype=torch.float), torch.randn(N, T, Di, generator=g)
+
+
+STREAM_CASES = [                                   # shapes past the register-resident team mapping (S <= 256, M <= 128, D <= 8)
+    ('DF', 6, 6, 1, 160, 64, 'rk4'),              # M > 128
+    ('DF', 6, 6, 1, 48, 320, 'rk4'),              # S > 256
+    ('DF', 16, 16, 1, 72, 96, 'rk4'),             # BASELINE configs[4]'s latent width
+    ('DF', 16, 16, 1, 24, 64, 'midpoint'),
+    ('RBF', 6, 6, 1, 200, 320, 'rk4'),
+    ('RBF', 6, 3, 2, 136, 64, 'euler'),
+    ('RBF', 16, 16, 1, 40, 64, 'rk4'),
+    ('RBF', 16, 8, 2, 40, 64, 'rk4'),
+    ('DF', 16, 16, 1, 512, 256, 'rk4'),           # BASELINE configs[4] at full width: K_uu is 8192 x 8192 (oracle: ~30 s of CPU)
+]
+
+
+@pytest.mark.parametrize('kernel,Di,Do,order,M,S,method', STREAM_CASES)
+def test_streamed_backward_matches_fp64_oracle(kernel, Di, Do, order, M, S, method):
+    """loss.backward() through Flow.forward where the backward takes the STREAMED team kernels (pack read from L2 instead of
+    held in registers): every gradient against the oracle's fp64 autograd on the same parameters and noise, tolerance
+    calibrated by the oracle's own fp32 run."""
+    from vae_gp_ode_amd.model.core.flow import Flow
+    from vae_gp_ode_amd.model.core.svpy import SVGP_Layer
+    N, T = (5, 4) if M < 512 else (4, 3)
+    p, nz, z0, ts, gw = synthetic_gp(kernel, Di, Do, M, S, N, T, seed=1000 + M + S + Di)
+    gp = SVGP_Layer(Di, Do, M, S, kernel=kernel).cuda()
+    with torch.no_grad():
+        gp.kern.unconstrained_lengthscales.copy_(p['raw_ell'])
+        gp.kern.unconstrained_variance.copy_(p['raw_var'])
+        gp.inducing_loc.optvar.copy_(p['Z'])
+        gp.Um.optvar.copy_(p['Um'])
+        gp.Us_sqrt.optvar.copy_(p['Us'])
+    flow = Flow(gp, order=order, solver=method).cuda()
+    gp.set_noise({k: v.cuda() for k, v in nz.items()})
+    zg = z0.cuda().requires_grad_(True)
+    zt = flow(zg, ts.cuda())
+    (zt * gw.cuda()).sum().backward()
+    got = {'raw_ell': gp.kern.unconstrained_lengthscales.grad, 'raw_var': gp.kern.unconstrained_variance.grad,
+           'Z': gp.inducing_loc.optvar.grad, 'Um': gp.Um.optvar.grad, 'Us': gp.Us_sqrt.optvar.grad, 'z0': zg.grad}
+
+    def oracle(dtype):
+        q = {k: v.to(dtype).clone().requires_grad_(True) for k, v in p.items()}
+        c = O.build_cache(q, O.to_dtype(nz, dtype), kernel)
+        z = z0.to(dtype).clone().requires_grad_(True)
+        out = O.flow_forward(z, ts.to(dtype), c, order, method)
+        (out * gw.to(dtype)).sum().backward()
+        return out.detach(), dict({k: v.grad for k, v in q.items()}, z0=z.grad)
+    z64, g64 = oracle(torch.float64)
+    z32, g32 = oracle(torch.float32)
+    assert relerr(zt, z64) < 2e-4 + 3 * relerr(z32, z64)
+    for k in got:
+        tol = 1e-3 + 3 * relerr(g32[k], g64[k])
+        assert relerr(got[k], g64[k]) < tol, (k, relerr(got[k], g64[k]), tol)

@@ -311,6 +311,210 @@ __global__ __launch_bounds__(256) void param_grad_df_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// B (streamed): the same sums for shapes past the register-resident team (S > 256, M > 128, DF D = 16).
+// A workgroup still owns a chunk of rows, but walks the records one batch of four wavefronts at a time: a
+// wavefront holds ONE record and that record's gradient in registers, streams the chunk's rows past it (x, a are
+// wave-uniform loads from L2) and writes the finished record gradient to the slab; the uniform-tail partials stay
+// in registers across the inducing batches.
+// ---------------------------------------------------------------------------------------------
+template <int DI, int DO>
+__global__ __launch_bounds__(256) void param_grad_rbf_stream_kernel(const float* __restrict__ pack, int M, int S,
+                                                                     const float* __restrict__ xr, const float* __restrict__ ar,
+                                                                     int R, int rows_per_chunk, float* __restrict__ slab,
+                                                                     size_t pack_floats, int prior_only) {
+  using L = RbfLayout<DI, DO>;
+  constexpr int DH = (DO + 1) / 2;
+  __shared__ __attribute__((aligned(16))) float sInd[2][64][4 * L::RQ2];
+  __shared__ float sUni[TEAM][DH * DI];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float4* p4 = reinterpret_cast<const float4*>(pack);
+  const float4* i4 = p4 + L::rff_f4(S);
+  const float* wl = pack + 4 * (L::rff_f4(S) + L::ind_f4(M));
+  const int r0 = blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+  float* out = slab + (size_t)blockIdx.x * pack_floats;
+  const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
+  for (int rec = wave; rec < SJ * DO; rec += TEAM) {
+    float4 rq[L::RQ];
+    load_record<L::RQ>(p4, rec, lane, rq);
+    float g[4 * L::RQ];
+#pragma unroll
+    for (int q = 0; q < 4 * L::RQ; ++q) g[q] = 0.f;
+    const int d = rec % DO;
+    for (int r = r0; r < r1; ++r) {
+      float x[DI], gx[DI];
+#pragma unroll
+      for (int i = 0; i < DI; ++i) { x[i] = xr[(size_t)r * DI + i]; gx[i] = 0.f; }
+      rbf_rff_bwd<DI, DO, true>(rq, x, ar[(size_t)r * DO + d], gx, g);
+    }
+#pragma unroll
+    for (int q = 0; q < L::RQ; ++q) st4(out, ((size_t)rec * L::RQ + q) * 64 + lane, &g[4 * q]);
+  }
+  const int half = wave & 1;
+  float gwl[DH][DI];
+#pragma unroll
+  for (int d = 0; d < DH; ++d)
+#pragma unroll
+    for (int i = 0; i < DI; ++i) gwl[d][i] = 0.f;
+  float* ind_out = out + 4 * L::rff_f4(S);
+  for (int jb = 0; jb < MJ; jb += 2) {
+    const int j = jb + (wave >> 1);
+    const bool valid = j < MJ;
+    float4 ind[L::RQ2];
+    float gi[4 * L::RQ2];
+#pragma unroll
+    for (int q = 0; q < 4 * L::RQ2; ++q) gi[q] = 0.f;
+    if (valid) {
+      load_record<L::RQ2>(i4, j, lane, ind);
+      if (!prior_only) {
+        for (int r = r0; r < r1; ++r) {
+          asm volatile("" ::: "memory");   // as in the DF kernel below
+          float x[DI], a[DO], gx[DI];
+#pragma unroll
+          for (int i = 0; i < DI; ++i) { x[i] = xr[(size_t)r * DI + i]; gx[i] = 0.f; }
+#pragma unroll
+          for (int i = 0; i < DO; ++i) a[i] = ar[(size_t)r * DO + i];
+          rbf_ind_half_bwd<DI, DO, true>(ind, x, wl, half, a, gx, gi, gwl);
+        }
+      }
+    }
+    if (half == 1) {
+#pragma unroll
+      for (int q = 0; q < 4 * L::RQ2; ++q) sInd[wave >> 1][lane][q] = gi[q];
+    }
+    __syncthreads();
+    if (half == 0 && valid) {
+      float v[4 * L::RQ2];
+#pragma unroll
+      for (int q = 0; q < 4 * L::RQ2; ++q) v[q] = gi[q] + sInd[wave >> 1][lane][q];
+#pragma unroll
+      for (int q = 0; q < L::RQ2; ++q) st4(ind_out, ((size_t)j * L::RQ2 + q) * 64 + lane, &v[4 * q]);
+    }
+    __syncthreads();
+  }
+  {
+    float flat[DH * DI], red[DH * DI];
+#pragma unroll
+    for (int e = 0; e < DH * DI; ++e) flat[e] = gwl[e / DI][e % DI];
+    wave_sum_all<DH * DI>(flat, red);
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < DH * DI; ++e) sUni[wave][e] = red[e];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < DO * DI) {
+    const int d = threadIdx.x / DI, i = threadIdx.x % DI;
+    const int h = d / DH, dd = d % DH;
+    float* uni_out = out + 4 * (L::rff_f4(S) + L::ind_f4(M));
+    uni_out[d * DI + i] = sUni[h][dd * DI + i] + sUni[h + 2][dd * DI + i];
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void param_grad_df_stream_kernel(const float* __restrict__ pack, int M, int S,
+                                                                    const float* __restrict__ xr, const float* __restrict__ ar,
+                                                                    int R, int rows_per_chunk, float* __restrict__ slab,
+                                                                    size_t pack_floats, int prior_only) {
+  using L = DfLayout<D>;
+  constexpr int DH = (D + 1) / 2;
+  constexpr int NU = 2 * D * DH + DH;
+  __shared__ __attribute__((aligned(16))) float sInd[2][64][4 * L::RQ2];
+  __shared__ float sUni[TEAM][NU];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float4* p4 = reinterpret_cast<const float4*>(pack);
+  const float4* i4 = p4 + L::rff_f4(S);
+  const float* uni = pack + 4 * (L::rff_f4(S) + L::ind_f4(M));
+  const int r0 = blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+  float* out = slab + (size_t)blockIdx.x * pack_floats;
+  const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
+  for (int rec = wave; rec < SJ * D; rec += TEAM) {
+    float4 rq[L::RQ];
+    load_record<L::RQ>(p4, rec, lane, rq);
+    float g[4 * L::RQ];
+#pragma unroll
+    for (int q = 0; q < 4 * L::RQ; ++q) g[q] = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      float x[D], a[D], gx[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) { x[i] = xr[(size_t)r * D + i]; a[i] = ar[(size_t)r * D + i]; gx[i] = 0.f; }
+      df_rff_bwd<D, true>(rq, x, a, gx, g);
+    }
+#pragma unroll
+    for (int q = 0; q < L::RQ; ++q) st4(out, ((size_t)rec * L::RQ + q) * 64 + lane, &g[4 * q]);
+  }
+  const int half = wave & 1;
+  float gwab[D][DH], gil2[D][DH], gvar[DH];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b < DH; ++b) { gwab[a][b] = 0.f; gil2[a][b] = 0.f; }
+#pragma unroll
+  for (int b = 0; b < DH; ++b) gvar[b] = 0.f;
+  float* ind_out = out + 4 * L::rff_f4(S);
+  for (int jb = 0; jb < MJ; jb += 2) {
+    const int j = jb + (wave >> 1);
+    const bool valid = j < MJ;
+    float4 ind[L::RQ2];
+    float gi[4 * L::RQ2];
+#pragma unroll
+    for (int q = 0; q < 4 * L::RQ2; ++q) gi[q] = 0.f;
+    if (valid) {
+      load_record<L::RQ2>(i4, j, lane, ind);
+      if (!prior_only) {
+        for (int r = r0; r < r1; ++r) {
+          asm volatile("" ::: "memory");   // uniform-table loads stay in the loop (hoisted, 2 D^2 + D values spill)
+          float x[D], a[D], gx[D];
+#pragma unroll
+          for (int i = 0; i < D; ++i) { x[i] = xr[(size_t)r * D + i]; a[i] = ar[(size_t)r * D + i]; gx[i] = 0.f; }
+          df_ind_half_bwd<D, true>(ind, x, uni, half, a, gx, gi, gwab, gil2, gvar);
+        }
+      }
+    }
+    if (half == 1) {
+#pragma unroll
+      for (int q = 0; q < 4 * L::RQ2; ++q) sInd[wave >> 1][lane][q] = gi[q];
+    }
+    __syncthreads();
+    if (half == 0 && valid) {
+      float v[4 * L::RQ2];
+#pragma unroll
+      for (int q = 0; q < 4 * L::RQ2; ++q) v[q] = gi[q] + sInd[wave >> 1][lane][q];
+#pragma unroll
+      for (int q = 0; q < L::RQ2; ++q) st4(ind_out, ((size_t)j * L::RQ2 + q) * 64 + lane, &v[4 * q]);
+    }
+    __syncthreads();
+  }
+  {
+    float flat[NU];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b < DH; ++b) { flat[a * DH + b] = gwab[a][b]; flat[D * DH + a * DH + b] = gil2[a][b]; }
+#pragma unroll
+    for (int b = 0; b < DH; ++b) flat[2 * D * DH + b] = gvar[b];
+    float red[NU];
+    wave_sum_all<NU>(flat, red);
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < NU; ++e) sUni[wave][e] = red[e];
+    }
+  }
+  __syncthreads();
+  {
+    float* uni_out = out + 4 * (L::rff_f4(S) + L::ind_f4(M));
+    for (int t = threadIdx.x; t < D * D; t += 256) {
+      const int a = t / D, b = t % D, h = b / DH, bb = b % DH;
+      uni_out[a * D + b] = sUni[h][a * DH + bb] + sUni[h + 2][a * DH + bb];
+      uni_out[D * D + a * D + b] = sUni[h][D * DH + a * DH + bb] + sUni[h + 2][D * DH + a * DH + bb];
+    }
+    if (threadIdx.x < D) {
+      const int t = threadIdx.x, h = t / DH, bb = t % DH;
+      uni_out[2 * D * D + t] = sUni[h][2 * D * DH + bb] + sUni[h + 2][2 * D * DH + bb];
+    }
+  }
+}
+
 // gpack[e] = sum_c slab[c][e] in a fixed order: 16 interleaved partial sums per element (independent load streams),
 // combined through LDS.  grid = ceil(pack_floats / 64), block = 1024 (64 elements x 16 chunk groups).
 __global__ __launch_bounds__(1024) void reduce_slab_kernel(const float* __restrict__ slab, int nchunk, size_t pack_floats,
@@ -338,30 +542,48 @@ __global__ __launch_bounds__(1024) void reduce_slab_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------
 static inline int team_grid_b(int N) { return N < 2048 ? N : 2048; }
 
+// register-resident team when the quarter pack fits (S <= 256, M <= 128, D <= 8), streamed team otherwise
+template <int DI, int DO> static bool rbf_team_ok(int M, int S) {
+  if constexpr (DO <= 8) return RbfTeamEval<DI, DO, 1>::fits(M, S);
+  return false;
+}
+template <int D> static bool df_team_ok(int M, int S) {
+  if constexpr (D <= 8) return DfTeamEval<D, 1>::fits(M, S);
+  return false;
+}
+
 template <int DI, int DO, int ORDER, int METHOD>
 static int launch_bwd_rbf(const float* pack, int M, int S, const float* xstage, const float* gzt, const float* ts, int N, int T,
                           float* gz0, float* astage, hipStream_t st) {
-  if (!RbfTeamEval<DI, DO, 1>::fits(M, S)) return set_error("gpode_rollout_bwd: S=%d M=%d exceed the register-resident team mapping (S<=256, M<=128)", S, M);
-  hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO, ORDER, METHOD>), team_grid_b(N), 256, 0, st,
+  if constexpr (DO <= 8) {
+    if (rbf_team_ok<DI, DO>(M, S)) {
+      hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO, ORDER, METHOD>), team_grid_b(N), 256, 0, st,
+                         pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+      return check_launch("rollout_bwd_rbf");
+    }
+  }
+  hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfStreamTeam<DI, DO>, DI, DO, ORDER, METHOD>), team_grid_b(N), 256, 0, st,
                      pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
-  return check_launch("rollout_bwd_rbf");
+  return check_launch("rollout_bwd_rbf_stream");
 }
 
 template <int D, int METHOD>
 static int launch_bwd_df(const float* pack, int M, int S, const float* xstage, const float* gzt, const float* ts, int N, int T,
                          float* gz0, float* astage, hipStream_t st) {
   if constexpr (D <= 8) {
-    if (!DfTeamEval<D, 1>::fits(M, S)) return set_error("gpode_rollout_bwd: S=%d M=%d exceed the register-resident team mapping", S, M);
-    hipLaunchKernelGGL((rollout_bwd_team_kernel<DfTeamEval<D, 1>, D, D, 1, METHOD>), team_grid_b(N), 256, 0, st,
-                       pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
-    return check_launch("rollout_bwd_df");
-  } else {
-    return set_error("gpode_rollout_bwd: DF backward is built for D <= 8");
+    if (df_team_ok<D>(M, S)) {
+      hipLaunchKernelGGL((rollout_bwd_team_kernel<DfTeamEval<D, 1>, D, D, 1, METHOD>), team_grid_b(N), 256, 0, st,
+                         pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+      return check_launch("rollout_bwd_df");
+    }
   }
+  hipLaunchKernelGGL((rollout_bwd_team_kernel<DfStreamTeam<D>, D, D, 1, METHOD>), team_grid_b(N), 256, 0, st,
+                     pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+  return check_launch("rollout_bwd_df_stream");
 }
 
-#define GP_BWD_RBF_DIMS(X) X(6, 6) X(6, 3) X(4, 4) X(4, 2) X(2, 2) X(2, 1) X(8, 8) X(8, 4) X(3, 3)
-#define GP_BWD_DF_DIMS(X) X(6) X(4) X(2) X(3) X(8)
+#define GP_BWD_RBF_DIMS(X) X(6, 6) X(6, 3) X(4, 4) X(4, 2) X(2, 2) X(2, 1) X(8, 8) X(8, 4) X(3, 3) X(16, 16) X(16, 8) X(12, 6)
+#define GP_BWD_DF_DIMS(X) X(6) X(4) X(2) X(3) X(8) X(16)
 
 template <int DI, int DO>
 static int bwd_rbf_dispatch(int order, int method, const float* pack, int M, int S, const float* xstage, const float* gzt,
@@ -397,25 +619,39 @@ int rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S,
   return set_error("gpode_rollout_bwd: no specialisation for kernel=%d Di=%d Do=%d", kernel, Di, Do);
 }
 
+template <int DI, int DO>
+static int launch_vjp_rbf(const float* pack, int M, int S, const float* x, const float* a, int R, float* gx, int prior_only, hipStream_t st) {
+  if constexpr (DO <= 8) {
+    if (rbf_team_ok<DI, DO>(M, S)) {
+      hipLaunchKernelGGL((rhs_vjp_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);
+      return check_launch("rhs_vjp_rbf");
+    }
+  }
+  hipLaunchKernelGGL((rhs_vjp_team_kernel<RbfStreamTeam<DI, DO>, DI, DO>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);
+  return check_launch("rhs_vjp_rbf_stream");
+}
+
+template <int D>
+static int launch_vjp_df(const float* pack, int M, int S, const float* x, const float* a, int R, float* gx, int prior_only, hipStream_t st) {
+  if constexpr (D <= 8) {
+    if (df_team_ok<D>(M, S)) {
+      hipLaunchKernelGGL((rhs_vjp_team_kernel<DfTeamEval<D, 1>, D, D>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);
+      return check_launch("rhs_vjp_df");
+    }
+  }
+  hipLaunchKernelGGL((rhs_vjp_team_kernel<DfStreamTeam<D>, D, D>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);
+  return check_launch("rhs_vjp_df_stream");
+}
+
 int rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, const float* a, int R, float* gx,
             int prior_only, hipStream_t st) {
   if (R <= 0) return 0;
   if (kernel == 0) {
-#define X(p, q)                                                                                                              \
-  if (Di == p && Do == q) {                                                                                                  \
-    if (!RbfTeamEval<p, q, 1>::fits(M, S)) return set_error("gpode_rhs_vjp: S=%d M=%d too large for the team mapping", S, M); \
-    hipLaunchKernelGGL((rhs_vjp_team_kernel<RbfTeamEval<p, q, 1>, p, q>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only); \
-    return check_launch("rhs_vjp_rbf");                                                                                      \
-  }
+#define X(p, q) if (Di == p && Do == q) return launch_vjp_rbf<p, q>(pack, M, S, x, a, R, gx, prior_only, st);
     GP_BWD_RBF_DIMS(X)
 #undef X
   } else {
-#define X(p)                                                                                                                 \
-  if (Di == p && Do == p) {                                                                                                  \
-    if (!DfTeamEval<p, 1>::fits(M, S)) return set_error("gpode_rhs_vjp: S=%d M=%d too large for the team mapping", S, M);     \
-    hipLaunchKernelGGL((rhs_vjp_team_kernel<DfTeamEval<p, 1>, p, p>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);   \
-    return check_launch("rhs_vjp_df");                                                                                       \
-  }
+#define X(p) if (Di == p && Do == p) return launch_vjp_df<p>(pack, M, S, x, a, R, gx, prior_only, st);
     GP_BWD_DF_DIMS(X)
 #undef X
   }
@@ -423,6 +659,32 @@ int rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack, const f
 }
 
 // rows (R,Di) x adjoints (R,Do) -> gpack (pack layout).  slab: nchunk * pack_floats floats of scratch.
+template <int DI, int DO>
+static int launch_pgrad_rbf(const float* pack, int M, int S, const float* xr, const float* ar, int R, int rpc, int used, float* slab,
+                            size_t pf, int prior_only, hipStream_t st) {
+  if constexpr (DO <= 8) {
+    if (rbf_team_ok<DI, DO>(M, S)) {
+      hipLaunchKernelGGL((param_grad_rbf_kernel<DI, DO, 1>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only);
+      return check_launch("param_grad_rbf");
+    }
+  }
+  hipLaunchKernelGGL((param_grad_rbf_stream_kernel<DI, DO>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only);
+  return check_launch("param_grad_rbf_stream");
+}
+
+template <int D>
+static int launch_pgrad_df(const float* pack, int M, int S, const float* xr, const float* ar, int R, int rpc, int used, float* slab,
+                           size_t pf, int prior_only, hipStream_t st) {
+  if constexpr (D <= 8) {
+    if (df_team_ok<D>(M, S)) {
+      hipLaunchKernelGGL((param_grad_df_kernel<D, 1>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only);
+      return check_launch("param_grad_df");
+    }
+  }
+  hipLaunchKernelGGL((param_grad_df_stream_kernel<D>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only);
+  return check_launch("param_grad_df_stream");
+}
+
 int param_grad(int kernel, int Di, int Do, int M, int S, const float* pack, const float* xr, const float* ar, int R,
                float* slab, int nchunk, float* gpack, int accumulate, int prior_only, hipStream_t st) {
   size_t pf = 0;
@@ -430,30 +692,20 @@ int param_grad(int kernel, int Di, int Do, int M, int S, const float* pack, cons
   if (R <= 0 || nchunk <= 0) return set_error("gpode_param_grad: R=%d nchunk=%d", R, nchunk);
   const int rpc = cdiv(R, nchunk);
   const int used = cdiv(R, rpc);
+  int rc = -1;
   if (kernel == 0) {
-#define X(p, q)                                                                                                              \
-  if (Di == p && Do == q) {                                                                                                  \
-    if (!RbfTeamEval<p, q, 1>::fits(M, S)) return set_error("gpode_param_grad: S=%d M=%d too large for the team mapping", S, M); \
-    hipLaunchKernelGGL((param_grad_rbf_kernel<p, q, 1>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only); \
-    if (check_launch("param_grad_rbf")) return 1;                                                                           \
-    hipLaunchKernelGGL(reduce_slab_kernel, cdiv((int)pf, 64), 1024, 0, st, slab, used, pf, gpack, accumulate);              \
-    return check_launch("reduce_slab");                                                                                      \
-  }
+#define X(p, q) if (Di == p && Do == q) rc = launch_pgrad_rbf<p, q>(pack, M, S, xr, ar, R, rpc, used, slab, pf, prior_only, st);
     GP_BWD_RBF_DIMS(X)
 #undef X
   } else {
-#define X(p)                                                                                                                 \
-  if (Di == p && Do == p) {                                                                                                  \
-    if (!DfTeamEval<p, 1>::fits(M, S)) return set_error("gpode_param_grad: S=%d M=%d too large for the team mapping", S, M);  \
-    hipLaunchKernelGGL((param_grad_df_kernel<p, 1>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only);   \
-    if (check_launch("param_grad_df")) return 1;                                                                            \
-    hipLaunchKernelGGL(reduce_slab_kernel, cdiv((int)pf, 64), 1024, 0, st, slab, used, pf, gpack, accumulate);              \
-    return check_launch("reduce_slab");                                                                                      \
-  }
+#define X(p) if (Di == p && Do == p) rc = launch_pgrad_df<p>(pack, M, S, xr, ar, R, rpc, used, slab, pf, prior_only, st);
     GP_BWD_DF_DIMS(X)
 #undef X
   }
-  return set_error("gpode_param_grad: no specialisation for kernel=%d Di=%d Do=%d", kernel, Di, Do);
+  if (rc < 0) return set_error("gpode_param_grad: no specialisation for kernel=%d Di=%d Do=%d", kernel, Di, Do);
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_slab_kernel, (unsigned)((pf + 63) / 64), 1024, 0, st, slab, used, pf, gpack, accumulate);
+  return check_launch("reduce_slab");
 }
 
 }  // namespace gp

@@ -689,9 +689,9 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
                        bws + b.gZpart, bws + b.kpart, g_raw_ell, g_raw_var, g_Z);                                          \
     return check_launch("cache bwd: chain df");                                                                            \
   }
-  X(6) X(4) X(2) X(3) X(8)
+  X(6) X(4) X(2) X(3) X(8) X(16)
 #undef X
-  return set_error("gpode_cache_build_bwd: DF backward is built for D in {2,3,4,6,8}");
+  return set_error("gpode_cache_build_bwd: DF backward is built for D in {2,3,4,6,8,16}");
 }
 
 }  // namespace gp

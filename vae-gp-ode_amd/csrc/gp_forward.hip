@@ -378,6 +378,10 @@ static int launch_rhs_rbf(const float* pack, int M, int S, const float* x, int N
       return check_launch("rhs_rbf_team");
     }
   }
+  if (N <= kTeamMaxRows) {     // past the register-resident quarter pack: the same team, records streamed from L2
+    hipLaunchKernelGGL((rhs_team_kernel<RbfStreamTeam<DI, DO>, DI, DO>), team_grid(N), 256, 0, st, pack, M, S, x, N, f, mode);
+    return check_launch("rhs_rbf_team_stream");
+  }
   const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
   if constexpr (rbf_reg_fits<DI, DO, 4, 2>()) {
     if (SJ == 4 && MJ == 2) {
@@ -407,6 +411,10 @@ static int launch_rhs_df(const float* pack, int M, int S, const float* x, int N,
       return check_launch("rhs_df_team");
     }
   }
+  if (N <= kTeamMaxRows) {
+    hipLaunchKernelGGL((rhs_team_kernel<DfStreamTeam<D>, D, D>), team_grid(N), 256, 0, st, pack, M, S, x, N, f, mode);
+    return check_launch("rhs_df_team_stream");
+  }
   // one evaluation per row: staging the pack in LDS only pays when a workgroup evaluates many rows
   if (f4 * 16 <= kLdsLimitBytes && N >= 2048) {
     block = 256; grid = 256;
@@ -428,6 +436,10 @@ static int launch_rollout_rbf(const float* pack, int M, int S, const float* z0, 
       hipLaunchKernelGGL((rollout_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO, ORDER, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
       return check_launch("rollout_rbf_team");
     }
+  }
+  if (N <= kTeamMaxRows) {
+    hipLaunchKernelGGL((rollout_team_kernel<RbfStreamTeam<DI, DO>, DI, DO, ORDER, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
+    return check_launch("rollout_rbf_team_stream");
   }
   const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
   if constexpr (rbf_reg_fits<DI, DO, 4, 2>()) {
@@ -457,6 +469,10 @@ static int launch_rollout_df(const float* pack, int M, int S, const float* z0, c
       hipLaunchKernelGGL((rollout_team_kernel<DfTeamEval<D, 1>, D, D, 1, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
       return check_launch("rollout_df_team");
     }
+  }
+  if (N <= kTeamMaxRows) {     // e.g. BASELINE configs[4] (D = 16, M = 512): 4 wavefronts per trajectory, records streamed from L2
+    hipLaunchKernelGGL((rollout_team_kernel<DfStreamTeam<D>, D, D, 1, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
+    return check_launch("rollout_df_team_stream");
   }
   if (f4 * 16 <= kLdsLimitBytes) {
     if (N <= 1024) { block = 64; grid = N < 256 ? N : 256; }

@@ -208,5 +208,156 @@ template <int D, int NJ> struct DfTeamEval {
   }
 };
 
+// ----------------------------------------------------------------------------------------------
+// STREAMED team evaluators: the same 4-wave team and combine, but the pack stays in
+// global memory -- it is L2-resident (0.66 MB at D=16, M=512, S=256) -- and every wave walks its share
+// of the records: rff records rec = wave, wave+4, ...; inducing work units u = 2 j + half = wave,
+// wave+4, ... (so `half` is still a per-wave constant).  Any S and M, and the D whose records no longer
+// fit a register-resident quarter (DF D=16: 36 floats per record, 16 records per lane group).
+// ----------------------------------------------------------------------------------------------
+template <int NQ>
+__device__ __forceinline__ void load_record(const float4* __restrict__ base, int rec, int lane, float4 (&r)[NQ]) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) r[q] = base[((size_t)rec * NQ + q) * 64 + lane];
+}
+
+// v[idx] for a wave-uniform idx without a runtime register index
+template <int N> __device__ __forceinline__ float pick(const float (&v)[N], int idx) {
+  float r = v[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) r = (idx == i) ? v[i] : r;
+  return r;
+}
+
+template <int DI, int DO> struct RbfStreamTeam {
+  using L = RbfLayout<DI, DO>;
+  const float4* p4;
+  const float4* i4;
+  const float* wl;
+  int nrec, nunit, wave, lane;
+  TeamCombine comb;
+  __device__ __forceinline__ void init(const float* pack, int M, int S, float* lds, int w, int l) {
+    p4 = reinterpret_cast<const float4*>(pack);
+    i4 = p4 + L::rff_f4(S);
+    wl = pack + 4 * (L::rff_f4(S) + L::ind_f4(M));
+    nrec = cdiv(S, 64) * DO;
+    nunit = 2 * cdiv(M, 64);
+    wave = w; lane = l;
+    comb.init(lds, w, l);
+  }
+  template <int MODE> __device__ __forceinline__ void eval(const float (&x)[DI], float (&f)[DO]) {
+    float acc[DO];
+#pragma unroll
+    for (int d = 0; d < DO; ++d) acc[d] = 0.f;
+    if (MODE != 2) {
+      for (int rec = wave; rec < nrec; rec += TEAM) {
+        float4 r[L::RQ];
+        load_record<L::RQ>(p4, rec, lane, r);
+        float v = 0.f;
+        rbf_rff_record<DI, DO>(r, x, v);
+        const int d = rec % DO;
+#pragma unroll
+        for (int i = 0; i < DO; ++i) acc[i] += (d == i) ? v : 0.f;
+      }
+    }
+    if (MODE != 1) {
+      for (int u = wave; u < nunit; u += TEAM) {
+        asm volatile("" ::: "memory");
+        float4 r[L::RQ2];
+        load_record<L::RQ2>(i4, u >> 1, lane, r);
+        rbf_ind_record_half<DI, DO>(r, x, wl, wave & 1, acc);
+      }
+    }
+    float part[DO];
+    wave_sum_all<DO>(acc, part);
+    comb.run<DO>(part, f);
+  }
+  __device__ __forceinline__ void vjp(const float (&x)[DI], const float (&a)[DO], float (&gx)[DI], bool prior_only = false) {
+    float acc[DI];
+#pragma unroll
+    for (int i = 0; i < DI; ++i) acc[i] = 0.f;
+    float g0[4 * L::RQ], g1[4 * L::RQ2], g2[(DO + 1) / 2][DI];
+    for (int rec = wave; rec < nrec; rec += TEAM) {
+      float4 r[L::RQ];
+      load_record<L::RQ>(p4, rec, lane, r);
+      rbf_rff_bwd<DI, DO, false>(r, x, pick<DO>(a, rec % DO), acc, g0);
+    }
+    if (!prior_only) {
+      for (int u = wave; u < nunit; u += TEAM) {
+        asm volatile("" ::: "memory");   // as below: uniform-table loads stay in the loop
+        float4 r[L::RQ2];
+        load_record<L::RQ2>(i4, u >> 1, lane, r);
+        rbf_ind_half_bwd<DI, DO, false>(r, x, wl, wave & 1, a, acc, g1, g2);
+      }
+    }
+    float part[DI];
+    wave_sum_all<DI>(acc, part);
+    comb.run<DI>(part, gx);
+  }
+};
+
+template <int D> struct DfStreamTeam {
+  using L = DfLayout<D>;
+  const float4* p4;
+  const float4* i4;
+  const float* uni;
+  int nrec, nunit, wave, lane;
+  TeamCombine comb;
+  __device__ __forceinline__ void init(const float* pack, int M, int S, float* lds, int w, int l) {
+    p4 = reinterpret_cast<const float4*>(pack);
+    i4 = p4 + L::rff_f4(S);
+    uni = pack + 4 * (L::rff_f4(S) + L::ind_f4(M));
+    nrec = cdiv(S, 64) * D;
+    nunit = 2 * cdiv(M, 64);
+    wave = w; lane = l;
+    comb.init(lds, w, l);
+  }
+  template <int MODE> __device__ __forceinline__ void eval(const float (&x)[D], float (&f)[D]) {
+    float acc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = 0.f;
+    if (MODE != 2) {
+      for (int rec = wave; rec < nrec; rec += TEAM) {
+        float4 r[L::RQ];
+        load_record<L::RQ>(p4, rec, lane, r);
+        df_rff_record<D>(r, x, acc);
+      }
+    }
+    if (MODE != 1) {
+      for (int u = wave; u < nunit; u += TEAM) {
+        asm volatile("" ::: "memory");
+        float4 r[L::RQ2];
+        load_record<L::RQ2>(i4, u >> 1, lane, r);
+        df_ind_record_half<D>(r, x, uni, wave & 1, acc);
+      }
+    }
+    float part[D];
+    wave_sum_all<D>(acc, part);
+    comb.run<D>(part, f);
+  }
+  __device__ __forceinline__ void vjp(const float (&x)[D], const float (&a)[D], float (&gx)[D], bool prior_only = false) {
+    float acc[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) acc[i] = 0.f;
+    float g0[4 * L::RQ], g1[4 * L::RQ2], g2[D][(D + 1) / 2], g3[D][(D + 1) / 2], g4[(D + 1) / 2];
+    for (int rec = wave; rec < nrec; rec += TEAM) {
+      float4 r[L::RQ];
+      load_record<L::RQ>(p4, rec, lane, r);
+      df_rff_bwd<D, false>(r, x, a, acc, g0);
+    }
+    if (!prior_only) {
+      for (int u = wave; u < nunit; u += TEAM) {
+        asm volatile("" ::: "memory");   // keep the 2 D^2 + D uniform-table loads inside the loop (hoisted they spill)
+        float4 r[L::RQ2];
+        load_record<L::RQ2>(i4, u >> 1, lane, r);
+        df_ind_half_bwd<D, false>(r, x, uni, wave & 1, a, acc, g1, g2, g3, g4);
+      }
+    }
+    float part[D];
+    wave_sum_all<D>(acc, part);
+    comb.run<D>(part, gx);
+  }
+};
+
 
 }  // namespace gp
