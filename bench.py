@@ -38,7 +38,7 @@ WORKLOADS = {
                  desc='configs[2]: ode2 RBF Din=6 Dout=3 M=100 S=256 T=16 batch=256'),
     'cfg4': dict(kernel='RBF', order=1, q=6, M=100, S=256, T=16, batch=256, mflop=2.252,
                  desc='configs[3] per-GPU shard: ode1 RBF q=6 M=100 S=256 T=16 batch=256/GPU (2048 over 8)'),
-    # integrator mode only: the backward for M > 128 / DF D > 8 is not built
+    # K_uu is 8192 x 8192; forward and backward take the streamed 4-wavefront team (pack read from L2)
     'cfg5': dict(kernel='DF', order=1, q=16, M=512, S=256, T=64, batch=128, mflop=438.7,
                  desc='configs[4] per-GPU shard: ode1 DF q=16 M=512 S=256 T=64 batch=128/GPU (1024 over 8)'),
 }
@@ -209,8 +209,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if a.workload == 'cfg5' and a.mode != 'integrator':
-        raise SystemExit('cfg5 runs in --mode integrator only (forward path; its backward is not built yet)')
     if a.mode == 'integrator':
         out = run_integrator(a, w, dev, rank, n_gpus, dist, barrier)
     else:

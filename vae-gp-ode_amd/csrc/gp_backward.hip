@@ -411,15 +411,19 @@ __global__ __launch_bounds__(256) void param_grad_rbf_stream_kernel(const float*
   }
 }
 
-template <int D>
+// NP: column parts per inducing record (one wavefront each): 2 (halves) up to D = 8, 4 at D = 16 so that the uniform-parameter
+// partials (2 x D x ceil(D/NP) registers) stay out of scratch
+template <int D, int NP>
 __global__ __launch_bounds__(256) void param_grad_df_stream_kernel(const float* __restrict__ pack, int M, int S,
                                                                     const float* __restrict__ xr, const float* __restrict__ ar,
                                                                     int R, int rows_per_chunk, float* __restrict__ slab,
                                                                     size_t pack_floats, int prior_only) {
   using L = DfLayout<D>;
-  constexpr int DH = (D + 1) / 2;
-  constexpr int NU = 2 * D * DH + DH;
-  __shared__ __attribute__((aligned(16))) float sInd[2][64][4 * L::RQ2];
+  constexpr int DQ = (D + NP - 1) / NP;
+  constexpr int NU = 2 * D * DQ + DQ;
+  constexpr int RPI = TEAM / NP;                     // records per iteration of the inducing loop
+  static_assert(TEAM % NP == 0, "column parts per team");
+  __shared__ __attribute__((aligned(16))) float sInd[RPI][NP - 1][64][4 * L::RQ2];
   __shared__ float sUni[TEAM][NU];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float4* p4 = reinterpret_cast<const float4*>(pack);
@@ -443,17 +447,17 @@ __global__ __launch_bounds__(256) void param_grad_df_stream_kernel(const float* 
 #pragma unroll
     for (int q = 0; q < L::RQ; ++q) st4(out, ((size_t)rec * L::RQ + q) * 64 + lane, &g[4 * q]);
   }
-  const int half = wave & 1;
-  float gwab[D][DH], gil2[D][DH], gvar[DH];
+  const int part = wave % NP, slot = wave / NP;
+  float gwab[D][DQ], gil2[D][DQ], gvar[DQ];
 #pragma unroll
   for (int a = 0; a < D; ++a)
 #pragma unroll
-    for (int b = 0; b < DH; ++b) { gwab[a][b] = 0.f; gil2[a][b] = 0.f; }
+    for (int b = 0; b < DQ; ++b) { gwab[a][b] = 0.f; gil2[a][b] = 0.f; }
 #pragma unroll
-  for (int b = 0; b < DH; ++b) gvar[b] = 0.f;
+  for (int b = 0; b < DQ; ++b) gvar[b] = 0.f;
   float* ind_out = out + 4 * L::rff_f4(S);
-  for (int jb = 0; jb < MJ; jb += 2) {
-    const int j = jb + (wave >> 1);
+  for (int jb = 0; jb < MJ; jb += RPI) {
+    const int j = jb + slot;
     const bool valid = j < MJ;
     float4 ind[L::RQ2];
     float gi[4 * L::RQ2];
@@ -467,19 +471,23 @@ __global__ __launch_bounds__(256) void param_grad_df_stream_kernel(const float* 
           float x[D], a[D], gx[D];
 #pragma unroll
           for (int i = 0; i < D; ++i) { x[i] = xr[(size_t)r * D + i]; a[i] = ar[(size_t)r * D + i]; gx[i] = 0.f; }
-          df_ind_half_bwd<D, true>(ind, x, uni, half, a, gx, gi, gwab, gil2, gvar);
+          df_ind_part_bwd<D, NP, true>(ind, x, uni, part, a, gx, gi, gwab, gil2, gvar);
         }
       }
     }
-    if (half == 1) {
+    if (part > 0) {
 #pragma unroll
-      for (int q = 0; q < 4 * L::RQ2; ++q) sInd[wave >> 1][lane][q] = gi[q];
+      for (int q = 0; q < 4 * L::RQ2; ++q) sInd[slot][part - 1][lane][q] = gi[q];
     }
     __syncthreads();
-    if (half == 0 && valid) {
+    if (part == 0 && valid) {
       float v[4 * L::RQ2];
 #pragma unroll
-      for (int q = 0; q < 4 * L::RQ2; ++q) v[q] = gi[q] + sInd[wave >> 1][lane][q];
+      for (int q = 0; q < 4 * L::RQ2; ++q) {
+        v[q] = gi[q];
+#pragma unroll
+        for (int pp = 0; pp < NP - 1; ++pp) v[q] += sInd[slot][pp][lane][q];
+      }
 #pragma unroll
       for (int q = 0; q < L::RQ2; ++q) st4(ind_out, ((size_t)j * L::RQ2 + q) * 64 + lane, &v[4 * q]);
     }
@@ -490,9 +498,9 @@ __global__ __launch_bounds__(256) void param_grad_df_stream_kernel(const float* 
 #pragma unroll
     for (int a = 0; a < D; ++a)
 #pragma unroll
-      for (int b = 0; b < DH; ++b) { flat[a * DH + b] = gwab[a][b]; flat[D * DH + a * DH + b] = gil2[a][b]; }
+      for (int b = 0; b < DQ; ++b) { flat[a * DQ + b] = gwab[a][b]; flat[D * DQ + a * DQ + b] = gil2[a][b]; }
 #pragma unroll
-    for (int b = 0; b < DH; ++b) flat[2 * D * DH + b] = gvar[b];
+    for (int b = 0; b < DQ; ++b) flat[2 * D * DQ + b] = gvar[b];
     float red[NU];
     wave_sum_all<NU>(flat, red);
     if (lane == 0) {
@@ -502,15 +510,20 @@ __global__ __launch_bounds__(256) void param_grad_df_stream_kernel(const float* 
   }
   __syncthreads();
   {
+    // column b belongs to part b / DQ; the wavefronts w = part, part + NP, ... hold its partials
     float* uni_out = out + 4 * (L::rff_f4(S) + L::ind_f4(M));
     for (int t = threadIdx.x; t < D * D; t += 256) {
-      const int a = t / D, b = t % D, h = b / DH, bb = b % DH;
-      uni_out[a * D + b] = sUni[h][a * DH + bb] + sUni[h + 2][a * DH + bb];
-      uni_out[D * D + a * D + b] = sUni[h][D * DH + a * DH + bb] + sUni[h + 2][D * DH + a * DH + bb];
+      const int a = t / D, b = t % D, pt = b / DQ, bb = b % DQ;
+      float v0 = 0.f, v1 = 0.f;
+      for (int w = pt; w < TEAM; w += NP) { v0 += sUni[w][a * DQ + bb]; v1 += sUni[w][D * DQ + a * DQ + bb]; }
+      uni_out[a * D + b] = v0;
+      uni_out[D * D + a * D + b] = v1;
     }
     if (threadIdx.x < D) {
-      const int t = threadIdx.x, h = t / DH, bb = t % DH;
-      uni_out[2 * D * D + t] = sUni[h][2 * D * DH + bb] + sUni[h + 2][2 * D * DH + bb];
+      const int t = threadIdx.x, pt = t / DQ, bb = t % DQ;
+      float v = 0.f;
+      for (int w = pt; w < TEAM; w += NP) v += sUni[w][2 * D * DQ + bb];
+      uni_out[2 * D * D + t] = v;
     }
   }
 }
@@ -681,7 +694,7 @@ static int launch_pgrad_df(const float* pack, int M, int S, const float* xr, con
       return check_launch("param_grad_df");
     }
   }
-  hipLaunchKernelGGL((param_grad_df_stream_kernel<D>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only);
+  hipLaunchKernelGGL((param_grad_df_stream_kernel<D, (D > 8 ? 4 : 2)>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only);
   return check_launch("param_grad_df_stream");
 }
 

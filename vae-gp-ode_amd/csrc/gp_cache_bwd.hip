@@ -322,6 +322,101 @@ __global__ __launch_bounds__(256) void k_gemm_S(const float* __restrict__ X_all,
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same two products on the matrix cores for big factors (np a multiple of 128: the 8192 x 8192 K_uu of BASELINE
+// configs[4] is 2 x 0.55 TFLOP here).  128 x 128 output tile per workgroup, 4 wavefronts x (4 x 4) v_mfma_f32_16x16x4_f32
+// tiles, k in steps of 16 through LDS ([k][128 + 16]: the four k rows of an operand fetch fall on disjoint banks), the next
+// k-tile travelling to registers while the current one is multiplied.  MODE 0: S = X Linv (k >= column tile);
+// MODE 1: X = Linv^T tril(Phi), Phi generated from its two rank-1 terms while staging (k >= both tiles).
+// ---------------------------------------------------------------------------------------------
+typedef float gf32x4 __attribute__((ext_vector_type(4)));
+constexpr int GT = 128, GK = 16, GLD = GT + 16;
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_gemm_mfma(const float* __restrict__ A_all, const float* __restrict__ B_all,
+                                                       size_t batch_stride, int np, const float* __restrict__ vec_all,
+                                                       float* __restrict__ C_all) {
+  __shared__ __attribute__((aligned(16))) float sA[GK][GLD], sB[GK][GLD];
+  const int tm = blockIdx.x, tn = blockIdx.y, b = blockIdx.z, nb = gridDim.z;
+  const float* A = A_all + (size_t)b * batch_stride;
+  const float* B = B_all + (size_t)b * batch_stride;
+  float* C = C_all + (size_t)b * batch_stride;
+  const float* vq = vec_all + (size_t)(1 * nb + b) * np;
+  const float* vr = vec_all + (size_t)(3 * nb + b) * np;
+  const float* vv = vec_all + (size_t)(4 * nb + b) * np;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+  gf32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = gf32x4{0.f, 0.f, 0.f, 0.f};
+  const int nkt = np / GK;
+  const int kt0 = (MODE == 0 ? tn : (tm > tn ? tm : tn)) * (GT / GK);
+  float4 ra[2], rb[2];
+  auto load = [&](int kt) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + 256 * q;
+      const int k = e >> 5, c4 = (e & 31) * 4;                      // row k of the k-tile, 4 consecutive columns
+      const size_t gk = (size_t)kt * GK + k;
+      if (MODE == 0) {
+        const int m = e >> 2, k4 = (e & 3) * 4;                     // A = X[a][k]: k is the contiguous index
+        ra[q] = *reinterpret_cast<const float4*>(&A[((size_t)tm * GT + m) * np + (size_t)kt * GK + k4]);
+        rb[q] = *reinterpret_cast<const float4*>(&B[gk * np + (size_t)tn * GT + c4]);
+      } else {
+        ra[q] = *reinterpret_cast<const float4*>(&A[gk * np + (size_t)tm * GT + c4]);   // Linv[i][a]: a contiguous
+        const float ri = vr[gk], qi = vq[gk];
+        float ph[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const size_t gj = (size_t)tn * GT + c4 + c;
+          const float v = -ri * vq[gj] + qi * vv[gj];
+          ph[c] = gk > gj ? v : (gk == gj ? 0.5f * v : 0.f);
+        }
+        rb[q] = make_float4(ph[0], ph[1], ph[2], ph[3]);
+      }
+    }
+  };
+  load(kt0);
+  for (int kt = kt0; kt < nkt; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + 256 * q;
+      const int k = e >> 5, c4 = (e & 31) * 4;
+      if (MODE == 0) {
+        const int m = e >> 2, k4 = (e & 3) * 4;
+        sA[k4 + 0][m] = ra[q].x; sA[k4 + 1][m] = ra[q].y; sA[k4 + 2][m] = ra[q].z; sA[k4 + 3][m] = ra[q].w;
+      } else {
+        *reinterpret_cast<float4*>(&sA[k][c4]) = ra[q];
+      }
+      *reinterpret_cast<float4*>(&sB[k][c4]) = rb[q];
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) load(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < GK / 4; ++ks) {
+      float af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { af[i] = sA[4 * ks + lk][wm + 16 * i + lr]; bf[i] = sB[4 * ks + lk][wn + 16 * i + lr]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // lane: rows wm + 16 i + 4 lk + r, column wn + 16 j + lr
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        C[((size_t)tm * GT + wm + 16 * i + 4 * lk + r) * np + (size_t)tn * GT + wn + 16 * j + lr] = acc[i][j][r];
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // kernel-matrix backward.  G = (S + S^T)/2 multiplies BOTH triangles of K(Z) (torch's cholesky_backward).
 // ---------------------------------------------------------------------------------------------
 // RBF: grid (ceil(M/64), Do), block 64: thread = row point n.
@@ -669,8 +764,14 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
   if (rhs_vjp(kernel, Di, Do, M, S, pack, Z, bws + b.gp_rows, M, bws + b.vjpZ, 1, st)) return 1;
   if (param_grad(kernel, Di, Do, M, S, pack, Z, bws + b.gp_rows, M, bws + b.slab, b.nchunkZ, gpack, 1, 1, st)) return 1;
   // g_K = sym(L^-T Phi L^-1)
-  hipLaunchKernelGGL(k_gemm_phiX, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, bws + b.Linv, bstride, b.np, b.nbn, vec, bws + b.X);
-  hipLaunchKernelGGL(k_gemm_S, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, bws + b.X, bws + b.Linv, bstride, b.np, b.nbn, bws + b.S);
+  if (b.np % GT == 0 && b.np >= 8 * GT) {            // big factor: both products on the matrix cores
+    const dim3 grid(b.np / GT, b.np / GT, b.batch);  // column tile on the slow axis: the longest k ranges start first
+    hipLaunchKernelGGL(k_gemm_mfma<1>, grid, 256, 0, st, bws + b.Linv, bws + b.Linv, bstride, b.np, vec, bws + b.X);
+    hipLaunchKernelGGL(k_gemm_mfma<0>, grid, 256, 0, st, bws + b.X, bws + b.Linv, bstride, b.np, vec, bws + b.S);
+  } else {
+    hipLaunchKernelGGL(k_gemm_phiX, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, bws + b.Linv, bstride, b.np, b.nbn, vec, bws + b.X);
+    hipLaunchKernelGGL(k_gemm_S, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, bws + b.X, bws + b.Linv, bstride, b.np, b.nbn, bws + b.S);
+  }
   if (check_launch("cache bwd: gK")) return 1;
   if (kernel == 0) {
     const int nbx = cdiv(M, 64);

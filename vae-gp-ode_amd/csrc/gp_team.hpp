@@ -229,6 +229,68 @@ template <int N> __device__ __forceinline__ float pick(const float (&v)[N], int 
   return r;
 }
 
+// DF inducing record, output columns b in [part*DQ, part*DQ + DQ) of NP column parts (DQ = ceil(D / NP)): the arithmetic of
+// df_ind_half_bwd with the column picked at run time (`part` is wave-uniform; register arrays are read through select
+// chains).  NP = 4 at D = 16 keeps the uniform-parameter partials at 2 x 16 x 4 registers instead of 2 x 16 x 8.
+template <int D, int NP, bool WITH_G>
+__device__ __forceinline__ void df_ind_part_bwd(const float4 (&r)[DfLayout<D>::RQ2], const float (&x)[D],
+                                                const float* __restrict__ uni, int part, const float (&a)[D],
+                                                float (&gx)[D], float (&g)[4 * DfLayout<D>::RQ2],
+                                                float (&gwab)[D][(D + NP - 1) / NP], float (&gil2)[D][(D + NP - 1) / NP],
+                                                float (&gvar)[(D + NP - 1) / NP]) {
+  constexpr int DQ = (D + NP - 1) / NP;
+  float f[4 * DfLayout<D>::RQ2];
+  unpack(r, f);
+  const float* wab = uni;
+  const float* il2 = uni + D * D;
+  const float* var = uni + 2 * D * D;
+  float dl[D];
+  float r2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < D; ++q) { dl[q] = x[q] - f[q]; r2 = fmaf(dl[q], dl[q], r2); }
+  float gd[D];
+  float gr2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < D; ++q) gd[q] = 0.f;
+#pragma unroll
+  for (int bb = 0; bb < DQ; ++bb) {
+    const int b = part * DQ + bb;                    // wave-uniform
+    const bool live = b < D;
+    const int bidx = live ? b : D - 1;
+    const float dlb = live ? pick<D>(dl, bidx) : 0.f;
+    const float ab = live ? pick<D>(a, bidx) : 0.f;
+    const float vb = var[bidx];
+    float gdb = 0.f, gv = 0.f;
+#pragma unroll
+    for (int aa = 0; aa < D; ++aa) {
+      const float il = il2[aa * D + bidx], wv = wab[aa * D + bidx];
+      const float E = exp2_fast(r2 * wv);
+      const bool diag = (aa == bidx);
+      const float term = dl[aa] * dlb * il + (diag ? ((float)(D - 1) - r2 * il) : 0.f);
+      const float G = ab * f[D + aa];
+      const float GE = G * vb * E * il;
+      gr2 = fmaf(GE, term * (GP_LN2 * wv) - (diag ? il : 0.f), gr2);
+      gd[aa] = fmaf(GE * il, dlb, gd[aa]);
+      gdb = fmaf(GE * il, dl[aa], gdb);
+      if (WITH_G) {
+        g[D + aa] = fmaf(ab, vb * E * il * term, g[D + aa]);
+        gv = fmaf(G, E * il * term, gv);
+        gwab[aa][bb] = fmaf(G * vb * il * term, E * GP_LN2 * r2, gwab[aa][bb]);
+        gil2[aa][bb] = fmaf(G * vb * E, term + il * (dl[aa] * dlb - (diag ? r2 : 0.f)), gil2[aa][bb]);
+      }
+    }
+    if (WITH_G) gvar[bb] += gv;
+#pragma unroll
+    for (int q = 0; q < D; ++q) gd[q] += (live && q == bidx) ? gdb : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < D; ++q) {
+    const float v = fmaf(2.f * gr2, dl[q], gd[q]);
+    gx[q] += v;
+    if (WITH_G) g[q] -= v;
+  }
+}
+
 template <int DI, int DO> struct RbfStreamTeam {
   using L = RbfLayout<DI, DO>;
   const float4* p4;
@@ -298,6 +360,7 @@ template <int DI, int DO> struct RbfStreamTeam {
 
 template <int D> struct DfStreamTeam {
   using L = DfLayout<D>;
+  static constexpr int NPB = D > 8 ? 4 : 2;          // column parts per inducing record in the backward (df_ind_part_bwd)
   const float4* p4;
   const float4* i4;
   const float* uni;
@@ -339,18 +402,18 @@ template <int D> struct DfStreamTeam {
     float acc[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) acc[i] = 0.f;
-    float g0[4 * L::RQ], g1[4 * L::RQ2], g2[D][(D + 1) / 2], g3[D][(D + 1) / 2], g4[(D + 1) / 2];
+    float g0[4 * L::RQ], g1[4 * L::RQ2], g2[D][(D + NPB - 1) / NPB], g3[D][(D + NPB - 1) / NPB], g4[(D + NPB - 1) / NPB];
     for (int rec = wave; rec < nrec; rec += TEAM) {
       float4 r[L::RQ];
       load_record<L::RQ>(p4, rec, lane, r);
       df_rff_bwd<D, false>(r, x, a, acc, g0);
     }
     if (!prior_only) {
-      for (int u = wave; u < nunit; u += TEAM) {
+      for (int u = wave; u < NPB * (nunit / 2); u += TEAM) {   // unit u = NPB * record + column part
         asm volatile("" ::: "memory");   // keep the 2 D^2 + D uniform-table loads inside the loop (hoisted they spill)
         float4 r[L::RQ2];
-        load_record<L::RQ2>(i4, u >> 1, lane, r);
-        df_ind_half_bwd<D, false>(r, x, uni, wave & 1, a, acc, g1, g2, g3, g4);
+        load_record<L::RQ2>(i4, u / NPB, lane, r);
+        df_ind_part_bwd<D, NPB, false>(r, x, uni, wave % NPB, a, acc, g1, g2, g3, g4);
       }
     }
     float part[D];
