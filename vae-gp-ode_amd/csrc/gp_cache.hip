@@ -286,7 +286,7 @@ __device__ __forceinline__ bool chol32_panel_wave(float (&row)[NB], int lane) {
 
 __global__ __launch_bounds__(256) void k_chol_rl(float* __restrict__ Aall, float* __restrict__ Lall, int np,
                                                   size_t batch_stride, float* __restrict__ Dfac_all, size_t dfac_stride,
-                                                  int k, int* __restrict__ info) {
+                                                  int k, int* __restrict__ info, int nblk, int jlim) {
   __shared__ float sD[NB][NB + 1], sI[NB][NB + 1], sJ[NB][NB + 1];     // loaded tiles A_kk, A_ik, A_jk
   __shared__ float lD[NB][NB + 1], lI[NB][NB + 1], lJ[NB][NB + 1];     // factored: L_kk, L_ik, L_jk
   float* A = Aall + (size_t)blockIdx.y * batch_stride;
@@ -294,11 +294,20 @@ __global__ __launch_bounds__(256) void k_chol_rl(float* __restrict__ Aall, float
   float* Dfac = Dfac_all + (size_t)blockIdx.y * dfac_stride + (size_t)k * NB * NB;
   // tile decode: t -> (ii, jj), jj <= ii, row-major over the lower triangle
   const int t = blockIdx.x;
-  int ii = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-  while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
-  while (ii * (ii + 1) / 2 > t) --ii;
-  const int jj = t - ii * (ii + 1) / 2;
-  const int i = k + ii, j = k + jj;
+  int i, j;
+  if (jlim >= nblk) {
+    int ii = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+    while (ii * (ii + 1) / 2 > t) --ii;
+    i = k + ii; j = k + (t - ii * (ii + 1) / 2);
+  } else {
+    // panelled factorisation: only the tile columns k <= j < jlim of the current 128-wide panel are updated here,
+    // column by column; everything to the right gets the whole panel's update from k_syrk_mfma afterwards
+    int rem = t;
+    j = k;
+    while (rem >= nblk - j) { rem -= nblk - j; ++j; }
+    i = j + rem;
+  }
   const bool hasI = i > k, hasJ = (j > k) && (j != i);
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
   const int c0 = k * NB;
@@ -352,6 +361,74 @@ __global__ __launch_bounds__(256) void k_chol_rl(float* __restrict__ Aall, float
       *dst = *dst - acc;
     }
   }
+}
+
+// Trailing update of the panelled factorisation on the matrix cores: for 128 x 128 tiles (tm >= tn) of the rows / columns
+// from r0 on, A -= P P^T with P = the 128 finished columns c0.. of L.  4 wavefronts x (4 x 4) v_mfma_f32_16x16x4_f32 tiles,
+// both operands staged [k][128 + 16] (k rows of an operand fetch on disjoint banks), next k-tile prefetched to registers.
+typedef float cf32x4 __attribute__((ext_vector_type(4)));
+constexpr int ST = 128, SK = 16, SLD = ST + 16;
+
+__global__ __launch_bounds__(256, 2) void k_syrk_mfma(float* __restrict__ Aall, const float* __restrict__ Lall, int np,
+                                                       size_t batch_stride, int r0, int c0) {
+  __shared__ __attribute__((aligned(16))) float sA[SK][SLD], sB[SK][SLD];
+  float* A = Aall + (size_t)blockIdx.y * batch_stride;
+  const float* Lm = Lall + (size_t)blockIdx.y * batch_stride;
+  const int t = blockIdx.x;
+  int tm = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+  while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
+  while (tm * (tm + 1) / 2 > t) --tm;
+  const int tn = t - tm * (tm + 1) / 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+  cf32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = cf32x4{0.f, 0.f, 0.f, 0.f};
+  const float* Pa = Lm + ((size_t)r0 + (size_t)tm * ST) * np + c0;
+  const float* Pb = Lm + ((size_t)r0 + (size_t)tn * ST) * np + c0;
+  float4 ra[2], rb[2];
+  auto load = [&](int kt) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + 256 * q, m = e >> 2, k4 = (e & 3) * 4;
+      ra[q] = *reinterpret_cast<const float4*>(&Pa[(size_t)m * np + kt * SK + k4]);
+      rb[q] = *reinterpret_cast<const float4*>(&Pb[(size_t)m * np + kt * SK + k4]);
+    }
+  };
+  load(0);
+  for (int kt = 0; kt < ST / SK; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + 256 * q, m = e >> 2, k4 = (e & 3) * 4;
+      sA[k4 + 0][m] = ra[q].x; sA[k4 + 1][m] = ra[q].y; sA[k4 + 2][m] = ra[q].z; sA[k4 + 3][m] = ra[q].w;
+      sB[k4 + 0][m] = rb[q].x; sB[k4 + 1][m] = rb[q].y; sB[k4 + 2][m] = rb[q].z; sB[k4 + 3][m] = rb[q].w;
+    }
+    __syncthreads();
+    if (kt + 1 < ST / SK) load(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < SK / 4; ++ks) {
+      float af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { af[i] = sA[4 * ks + lk][wm + 16 * i + lr]; bf[i] = sB[4 * ks + lk][wn + 16 * i + lr]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* C = A + ((size_t)r0 + (size_t)tm * ST) * np + r0 + (size_t)tn * ST;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* dst = C + (size_t)(wm + 16 * i + 4 * lk + r) * np + wn + 16 * j + lr;
+        *dst = *dst - acc[i][j][r];
+      }
 }
 
 // nu = L^-T (u - y),  y = row n of the factor (forward-solved rhs).  grid = batch, block = 256.
@@ -548,10 +625,27 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
     hipLaunchKernelGGL(k_Kzz_rbf, dim3(cdiv(w.np, 128), w.np, Do), 128, 0, st, Di, Do, M, w.np, Z, ws + w.ell, ws + w.var, up, A);
   else
     hipLaunchKernelGGL(k_Kzz_df, dim3(cdiv(w.np, 128), w.np, 1), 128, 0, st, Do, M, w.np, Z, ws + w.ell, ws + w.var, up, A);
-  for (int k = 0; k < w.nblk; ++k)
-  {
-    const int T = w.nblk - k;
-    hipLaunchKernelGGL(k_chol_rl, dim3(T * (T + 1) / 2, w.batch), 256, 0, st, A, Lmat, w.np, bstride, Dfac, dstride, k, info);
+  constexpr int PB = ST / NB;                          // 32-blocks per 128-wide panel
+  if (w.np % ST == 0 && w.np >= 8 * ST) {
+    // big factor (BASELINE configs[4]: 8192 x 8192): panels of 128 columns factored tile column by tile column, then ONE
+    // matrix-core rank-128 update of everything to their right -- n^3/3 of the flops on MFMA, and a launch's redundant
+    // panel factorisations confined to 4 tile columns instead of the whole trailing triangle
+    for (int K = 0; K < w.nblk / PB; ++K) {
+      const int jlim = (K + 1) * PB;
+      for (int k = K * PB; k < jlim; ++k) {
+        int tiles = 0;
+        for (int j = k; j < jlim; ++j) tiles += w.nblk - j;
+        hipLaunchKernelGGL(k_chol_rl, dim3(tiles, w.batch), 256, 0, st, A, Lmat, w.np, bstride, Dfac, dstride, k, info, w.nblk, jlim);
+      }
+      const int Tt = w.nblk / PB - (K + 1);
+      if (Tt > 0)
+        hipLaunchKernelGGL(k_syrk_mfma, dim3(Tt * (Tt + 1) / 2, w.batch), 256, 0, st, A, Lmat, w.np, bstride, jlim * NB, K * ST);
+    }
+  } else {
+    for (int k = 0; k < w.nblk; ++k) {
+      const int T = w.nblk - k;
+      hipLaunchKernelGGL(k_chol_rl, dim3(T * (T + 1) / 2, w.batch), 256, 0, st, A, Lmat, w.np, bstride, Dfac, dstride, k, info, w.nblk, w.nblk);
+    }
   }
   if (check_launch("cholesky")) return 1;
 

@@ -333,8 +333,8 @@ constexpr int GT = 128, GK = 16, GLD = GT + 16;
 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const float* __restrict__ A_all, const float* __restrict__ B_all,
-                                                       size_t batch_stride, int np, const float* __restrict__ vec_all,
-                                                       float* __restrict__ C_all) {
+                                                       size_t batch_stride, int np, int klim,
+                                                       const float* __restrict__ vec_all, float* __restrict__ C_all) {
   __shared__ __attribute__((aligned(16))) float sA[GK][GLD], sB[GK][GLD];
   const int tm = blockIdx.x, tn = blockIdx.y, b = blockIdx.z, nb = gridDim.z;
   const float* A = A_all + (size_t)b * batch_stride;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const float* __restrict__ 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = gf32x4{0.f, 0.f, 0.f, 0.f};
-  const int nkt = np / GK;
+  const int nkt = klim / GK;                         // L^-1 is defined on the first klim (= 32 nbn) rows only
   const int kt0 = (MODE == 0 ? tn : (tm > tn ? tm : tn)) * (GT / GK);
   float4 ra[2], rb[2];
   auto load = [&](int kt) {
@@ -765,9 +765,10 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
   if (param_grad(kernel, Di, Do, M, S, pack, Z, bws + b.gp_rows, M, bws + b.slab, b.nchunkZ, gpack, 1, 1, st)) return 1;
   // g_K = sym(L^-T Phi L^-1)
   if (b.np % GT == 0 && b.np >= 8 * GT) {            // big factor: both products on the matrix cores
-    const dim3 grid(b.np / GT, b.np / GT, b.batch);  // column tile on the slow axis: the longest k ranges start first
-    hipLaunchKernelGGL(k_gemm_mfma<1>, grid, 256, 0, st, bws + b.Linv, bws + b.Linv, bstride, b.np, vec, bws + b.X);
-    hipLaunchKernelGGL(k_gemm_mfma<0>, grid, 256, 0, st, bws + b.X, bws + b.Linv, bstride, b.np, vec, bws + b.S);
+    const int klim = b.nbn * NB, nt = cdiv(klim, GT);
+    const dim3 grid(nt, nt, b.batch);                // column tile on the slow axis: the longest k ranges start first
+    hipLaunchKernelGGL(k_gemm_mfma<1>, grid, 256, 0, st, bws + b.Linv, bws + b.Linv, bstride, b.np, klim, vec, bws + b.X);
+    hipLaunchKernelGGL(k_gemm_mfma<0>, grid, 256, 0, st, bws + b.X, bws + b.Linv, bstride, b.np, klim, vec, bws + b.S);
   } else {
     hipLaunchKernelGGL(k_gemm_phiX, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, bws + b.Linv, bstride, b.np, b.nbn, vec, bws + b.X);
     hipLaunchKernelGGL(k_gemm_S, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, bws + b.X, bws + b.Linv, bstride, b.np, b.nbn, bws + b.S);

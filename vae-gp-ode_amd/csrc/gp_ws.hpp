@@ -19,6 +19,7 @@ static inline WsLayout ws_layout(int kernel, int Di, int Do, int M, int S) {
   w.n = kernel == 0 ? M : M * Do;
   w.batch = kernel == 0 ? Do : 1;
   w.nblk = cdiv(w.n + 1, NB);
+  if (w.nblk >= 32) w.nblk = (w.nblk + 3) / 4 * 4;   // big factors: whole 128-wide panels for the matrix-core kernels (identity padding)
   w.np = w.nblk * NB;
   size_t o = 0;
   auto take = [&](size_t nfl) { size_t at = o; o += (nfl + 3) / 4 * 4; return at; };
