@@ -547,6 +547,83 @@ __global__ __launch_bounds__(256) void k_solve_back(const float* __restrict__ Aa
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Back-substitution for big factors (the single-workgroup kernel above is bandwidth-starved at n = 8192: 134 MB of L through
+// one CU).  One launch per 128-row panel, last panel first; workgroup c (<= P) owns residual entries 128 c .. 128 c + 127:
+//   launch P:  y_c -= L[panel P+1][cols c]^T nu[panel P+1]   (every workgroup; a 128 x 128 GEMV, coalesced along the columns)
+//              workgroup c == P then solves its 128 x 128 transposed triangular system and publishes nu[panel P].
+// The first launch initialises y = u - (row n of the factor).  y lives in the first np floats of the (consumed) A buffer.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float factor_elem(const float* __restrict__ Lm, const float* __restrict__ Dfac, int np, int r, int c) {
+  return (r / NB == c / NB) ? Dfac[(size_t)(r / NB) * NB * NB + (r % NB) * NB + c % NB] : Lm[(size_t)r * np + c];
+}
+
+__global__ __launch_bounds__(256) void k_solve_back_panel(const float* __restrict__ Lall, int n, int np, size_t batch_stride,
+                                                           const float* __restrict__ Dfac_all, size_t dfac_stride,
+                                                           const float* __restrict__ u, int u_stride, int u_bstride,
+                                                           float* __restrict__ yall, float* __restrict__ nu, int P, int first) {
+  constexpr int PW = 128;
+  __shared__ float sx[PW], spart[PW];
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* Lm = Lall + (size_t)b * batch_stride;
+  const float* Dfac = Dfac_all + (size_t)b * dfac_stride;
+  float* y = yall + (size_t)b * batch_stride;
+  float* nub = nu + (size_t)b * n;
+  const int col = c * PW + (tid & (PW - 1)), half = tid >> 7;
+  float res = 0.f;
+  if (first) {
+    if (half == 0 && col < n) res = u[(size_t)col * u_stride + (size_t)b * u_bstride] - factor_elem(Lm, Dfac, np, n, col);
+  } else {
+    const int r0 = (P + 1) * PW;
+    if (tid < PW) sx[tid] = r0 + tid < n ? nub[r0 + tid] : 0.f;
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll 8
+    for (int r = half * (PW / 2); r < (half + 1) * (PW / 2); ++r) acc = fmaf(Lm[(size_t)(r0 + r) * np + col], sx[r], acc);
+    if (half == 1) spart[tid - PW] = acc;
+    __syncthreads();
+    if (half == 0) res = y[col] - (acc + spart[tid]);
+  }
+  if (c != P) {                                     // workgroup-uniform
+    if (half == 0) y[col] = res;
+    return;
+  }
+  // thread t < 128 holds column t of the panel's diagonal block (rows >= t) and residual t
+  float colv[PW];
+  const int g0 = P * PW;
+  if (half == 0) {
+#pragma unroll
+    for (int r = 0; r < PW; ++r) colv[r] = (r >= tid && g0 + r < n) ? factor_elem(Lm, Dfac, np, g0 + r, g0 + tid) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = PW - 1; r >= 0; --r) {
+    if (tid == r) {
+      const float x = (g0 + r < n) ? res / colv[r] : 0.f;   // rows past n are padding (row n is the rhs row): x = 0
+      sx[r] = x;
+      res = x;
+    }
+    __syncthreads();
+    if (tid < r) res = fmaf(-colv[r], sx[r], res);
+  }
+  if (half == 0 && col < n) nub[col] = res;
+}
+
+// nu -> optional dense output and the coefficient fields of the pack's inducing records (as the tail of k_solve_back)
+__global__ void k_nu_publish(int n, const float* __restrict__ nu, float* __restrict__ nu_out, int kernel, int Di, int Do,
+                             const float* __restrict__ var, float* __restrict__ pack_ind) {
+  const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const float v = nu[(size_t)b * n + j];
+  if (nu_out) nu_out[(size_t)b * n + j] = v;
+  const int RQ2 = cdiv(Di + Do, 4);
+  int m, d;
+  float coef;
+  if (kernel == 0) { m = j; d = b; coef = var[d] * v; } else { m = j / Do; d = j % Do; coef = v; }
+  const int field = Di + d;
+  pack_ind[(((size_t)(m >> 6) * RQ2 + (field >> 2)) * 64 + (m & 63)) * 4 + (field & 3)] = coef;
+}
+
 // dense lower-triangular copy of the factor (zeros above the diagonal)
 __global__ void k_copy_L(const float* __restrict__ Aall, const float* __restrict__ Dfac_all, size_t dinv_stride,
                          int n, int np, size_t batch_stride, float* __restrict__ Lu) {
@@ -650,8 +727,14 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
   if (check_launch("cholesky")) return 1;
 
   // nu = L^-T (u - L^-1 u_prior), written to ws, to the optional output and into the pack
-  {
-    const int u_stride = kernel == 0 ? Do : 1, u_bstride = kernel == 0 ? 1 : 0;
+  const int u_stride = kernel == 0 ? Do : 1, u_bstride = kernel == 0 ? 1 : 0;
+  if (w.np % ST == 0 && w.np >= 8 * ST) {
+    const int npanel = cdiv(w.n, ST);
+    for (int P = npanel - 1; P >= 0; --P)
+      hipLaunchKernelGGL(k_solve_back_panel, dim3(P + 1, w.batch), 256, 0, st, Lmat, w.n, w.np, bstride, Dfac, dstride, ws + w.u,
+                         u_stride, u_bstride, A, ws + w.nu, P, P == npanel - 1 ? 1 : 0);
+    hipLaunchKernelGGL(k_nu_publish, dim3(cdiv(w.n, 256), w.batch), 256, 0, st, w.n, ws + w.nu, nu, kernel, Di, Do, ws + w.var, pack_ind);
+  } else {
     const size_t lds = sizeof(float) * w.np;
     const int cpt = cdiv(w.n, 1024);  // 4 columns per thread per unit
 #define GP_SOLVE(CPT)                                                                                              \
