@@ -260,6 +260,7 @@ STREAM_CASES = [                                   # shapes past the register-re
     ('DF', 6, 6, 1, 48, 320, 'rk4'),              # S > 256
     ('DF', 16, 16, 1, 72, 96, 'rk4'),             # BASELINE configs[4]'s latent width
     ('DF', 16, 16, 1, 24, 64, 'midpoint'),
+    ('DF', 16, 16, 1, 66, 64, 'euler'),           # n = 1056: the last 128-row tile of the big-factor kernels is partial
     ('RBF', 6, 6, 1, 200, 320, 'rk4'),
     ('RBF', 6, 3, 2, 136, 64, 'euler'),
     ('RBF', 16, 16, 1, 40, 64, 'rk4'),

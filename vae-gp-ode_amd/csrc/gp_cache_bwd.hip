@@ -415,6 +415,75 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const float* __restrict__ 
         C[((size_t)tm * GT + wm + 16 * i + 4 * lk + r) * np + (size_t)tn * GT + wn + 16 * j + lr] = acc[i][j][r];
 }
 
+// The two divide-and-conquer steps on the matrix cores for super-blocks of >= 128 rows (sb % 4 == 0, 128-aligned): the tile
+// engine of k_gemm_mfma with sub-block operands.  grid (sb / 4, sb / 4, npairs * batch).
+__global__ __launch_bounds__(256, 2) void k_linv_dc_mfma(int step, int sb, int npairs, int nbn, int n, int np,
+                                                          const float* __restrict__ Lall, float* __restrict__ Linv_all,
+                                                          float* __restrict__ T_all, size_t batch_stride) {
+  __shared__ __attribute__((aligned(16))) float sA[GK][GLD], sB[GK][GLD];
+  const int pair = blockIdx.z % npairs, b = blockIdx.z / npairs;
+  const int a0 = 2 * sb * pair, c0 = a0 + sb;
+  if (c0 >= nbn) return;
+  const int cs = min(sb, nbn - c0), tm = blockIdx.y, tn = blockIdx.x;
+  if (tm * (GT / NB) >= cs) return;
+  const float* P = (step == 0 ? Lall : Linv_all) + (size_t)b * batch_stride;
+  const float* Q = (step == 0 ? Linv_all : T_all) + (size_t)b * batch_stride;
+  float* out = (step == 0 ? T_all : Linv_all) + (size_t)b * batch_stride;
+  const int row0 = c0 * NB + tm * GT, col0 = a0 * NB + tn * GT;
+  const int kbase = (step == 0 ? a0 : c0) * NB;                       // P columns / Q rows of k = 0
+  const int klo = step == 0 ? tn * GT : 0;                            // Linv[A,A] lower triangular: k >= column tile
+  const int khi = step == 0 ? sb * NB : min((tm + 1) * GT, cs * NB);  // Linv[C,C] lower triangular: k <= row tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+  gf32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = gf32x4{0.f, 0.f, 0.f, 0.f};
+  float4 ra[2], rb[2];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + 256 * q;
+      const int m = e >> 2, k4 = (e & 3) * 4, k = e >> 5, c4 = (e & 31) * 4;
+      const bool live = step == 1 || row0 + m < n;                    // rows >= n of L are not part of the factor
+      ra[q] = live ? *reinterpret_cast<const float4*>(&P[(size_t)(row0 + m) * np + kbase + k0 + k4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[q] = *reinterpret_cast<const float4*>(&Q[(size_t)(kbase + k0 + k) * np + col0 + c4]);
+    }
+  };
+  if (klo < khi) load(klo);
+  for (int k0 = klo; k0 < khi; k0 += GK) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + 256 * q;
+      const int m = e >> 2, k4 = (e & 3) * 4, k = e >> 5, c4 = (e & 31) * 4;
+      sA[k4 + 0][m] = ra[q].x; sA[k4 + 1][m] = ra[q].y; sA[k4 + 2][m] = ra[q].z; sA[k4 + 3][m] = ra[q].w;
+      *reinterpret_cast<float4*>(&sB[k][c4]) = rb[q];
+    }
+    __syncthreads();
+    if (k0 + GK < khi) load(k0 + GK);
+#pragma unroll
+    for (int ks = 0; ks < GK / 4; ++ks) {
+      float af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { af[i] = sA[4 * ks + lk][wm + 16 * i + lr]; bf[i] = sB[4 * ks + lk][wn + 16 * i + lr]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(size_t)(row0 + wm + 16 * i + 4 * lk + r) * np + col0 + wn + 16 * j + lr] = step == 0 ? acc[i][j][r] : -acc[i][j][r];
+}
+
+
 
 // ---------------------------------------------------------------------------------------------
 // kernel-matrix backward.  G = (S + S^T)/2 multiplies BOTH triangles of K(Z) (torch's cholesky_backward).
@@ -727,6 +796,12 @@ int cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, const float* ws,
   hipLaunchKernelGGL(k_linv_init, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, b.np, bws + b.Dinv, dinv_stride, bws + b.Linv, bstride);
   for (int sb = 1; sb < b.nbn; sb *= 2) {            // T lives in the X buffer (written by k_gemm_phiX only afterwards)
     const int npairs = cdiv(b.nbn, 2 * sb);
+    if (sb >= GT / NB && b.np % GT == 0 && b.np >= 8 * GT) {   // super-blocks of whole 128-row tiles: matrix cores
+      const dim3 grid(sb / (GT / NB), sb / (GT / NB), npairs * b.batch);
+      hipLaunchKernelGGL(k_linv_dc_mfma, grid, 256, 0, st, 0, sb, npairs, b.nbn, b.n, b.np, Lmat, bws + b.Linv, bws + b.X, bstride);
+      hipLaunchKernelGGL(k_linv_dc_mfma, grid, 256, 0, st, 1, sb, npairs, b.nbn, b.n, b.np, Lmat, bws + b.Linv, bws + b.X, bstride);
+      continue;
+    }
     hipLaunchKernelGGL(k_linv_dc, dim3(sb, sb, npairs * b.batch), 256, 0, st, 0, sb, npairs, b.nbn, b.n, b.np, Lmat, bws + b.Linv, bws + b.X, bstride);
     hipLaunchKernelGGL(k_linv_dc, dim3(sb, sb, npairs * b.batch), 256, 0, st, 1, sb, npairs, b.nbn, b.n, b.np, Lmat, bws + b.Linv, bws + b.X, bstride);
   }
