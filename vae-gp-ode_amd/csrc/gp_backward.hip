@@ -47,12 +47,12 @@ __device__ __forceinline__ void ode_vjp(EV& ev, const float (&x)[DI], const floa
 }
 
 template <class EV, int DI, int DO, int ORDER, int METHOD>
-__global__ __launch_bounds__(256) void rollout_bwd_team_kernel(const float* __restrict__ pack, int M, int S,
+__global__ __launch_bounds__(64 * EV::kTeam) void rollout_bwd_team_kernel(const float* __restrict__ pack, int M, int S,
                                                                 const float* __restrict__ xstage, const float* __restrict__ gzt,
                                                                 const float* __restrict__ ts, int N, int T,
                                                                 float* __restrict__ gz0, float* __restrict__ astage) {
   constexpr int NS = METHOD == 0 ? 1 : (METHOD == 1 ? 4 : 2);
-  __shared__ float slots[2 * TEAM * TeamCombine::DP];
+  __shared__ float slots[2 * EV::kTeam * TeamCombine::DP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   EV ev;
   ev.init(pack, M, S, slots, wave, lane);
@@ -132,10 +132,10 @@ __global__ __launch_bounds__(256) void rollout_bwd_team_kernel(const float* __re
 
 // rows (R,DI), adjoints (R,DO) -> gx (R,DI) = J_f(x)^T a   (used for the f_prior(Z) path of the cache backward)
 template <class EV, int DI, int DO>
-__global__ __launch_bounds__(256) void rhs_vjp_team_kernel(const float* __restrict__ pack, int M, int S,
+__global__ __launch_bounds__(64 * EV::kTeam) void rhs_vjp_team_kernel(const float* __restrict__ pack, int M, int S,
                                                             const float* __restrict__ x, const float* __restrict__ a, int R,
                                                             float* __restrict__ gx, int prior_only) {
-  __shared__ float slots[2 * TEAM * TeamCombine::DP];
+  __shared__ float slots[2 * EV::kTeam * TeamCombine::DP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   EV ev;
   ev.init(pack, M, S, slots, wave, lane);
@@ -554,6 +554,7 @@ __global__ __launch_bounds__(1024) void reduce_slab_kernel(const float* __restri
 // host side
 // ---------------------------------------------------------------------------------------------
 static inline int team_grid_b(int N) { return N < 2048 ? N : 2048; }
+static const int kWideTeamRows = 256;  // streamed team: 8 wavefronts per row up to here (gp_forward.hip)
 
 // register-resident team when the quarter pack fits (S <= 256, M <= 128, D <= 8), streamed team otherwise
 template <int DI, int DO> static bool rbf_team_ok(int M, int S) {
@@ -575,8 +576,12 @@ static int launch_bwd_rbf(const float* pack, int M, int S, const float* xstage, 
       return check_launch("rollout_bwd_rbf");
     }
   }
-  hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfStreamTeam<DI, DO>, DI, DO, ORDER, METHOD>), team_grid_b(N), 256, 0, st,
-                     pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+  if (N <= kWideTeamRows)
+    hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfStreamTeam<DI, DO, 8>, DI, DO, ORDER, METHOD>), team_grid_b(N), 512, 0, st,
+                       pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+  else
+    hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfStreamTeam<DI, DO>, DI, DO, ORDER, METHOD>), team_grid_b(N), 256, 0, st,
+                       pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
   return check_launch("rollout_bwd_rbf_stream");
 }
 
@@ -590,8 +595,12 @@ static int launch_bwd_df(const float* pack, int M, int S, const float* xstage, c
       return check_launch("rollout_bwd_df");
     }
   }
-  hipLaunchKernelGGL((rollout_bwd_team_kernel<DfStreamTeam<D>, D, D, 1, METHOD>), team_grid_b(N), 256, 0, st,
-                     pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+  if (N <= kWideTeamRows)
+    hipLaunchKernelGGL((rollout_bwd_team_kernel<DfStreamTeam<D, 8>, D, D, 1, METHOD>), team_grid_b(N), 512, 0, st,
+                       pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+  else
+    hipLaunchKernelGGL((rollout_bwd_team_kernel<DfStreamTeam<D>, D, D, 1, METHOD>), team_grid_b(N), 256, 0, st,
+                       pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
   return check_launch("rollout_bwd_df_stream");
 }
 
@@ -640,7 +649,8 @@ static int launch_vjp_rbf(const float* pack, int M, int S, const float* x, const
       return check_launch("rhs_vjp_rbf");
     }
   }
-  hipLaunchKernelGGL((rhs_vjp_team_kernel<RbfStreamTeam<DI, DO>, DI, DO>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);
+  if (R <= kWideTeamRows) hipLaunchKernelGGL((rhs_vjp_team_kernel<RbfStreamTeam<DI, DO, 8>, DI, DO>), team_grid_b(R), 512, 0, st, pack, M, S, x, a, R, gx, prior_only);
+  else hipLaunchKernelGGL((rhs_vjp_team_kernel<RbfStreamTeam<DI, DO>, DI, DO>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);
   return check_launch("rhs_vjp_rbf_stream");
 }
 
@@ -652,7 +662,8 @@ static int launch_vjp_df(const float* pack, int M, int S, const float* x, const 
       return check_launch("rhs_vjp_df");
     }
   }
-  hipLaunchKernelGGL((rhs_vjp_team_kernel<DfStreamTeam<D>, D, D>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);
+  if (R <= kWideTeamRows) hipLaunchKernelGGL((rhs_vjp_team_kernel<DfStreamTeam<D, 8>, D, D>), team_grid_b(R), 512, 0, st, pack, M, S, x, a, R, gx, prior_only);
+  else hipLaunchKernelGGL((rhs_vjp_team_kernel<DfStreamTeam<D>, D, D>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);
   return check_launch("rhs_vjp_df_stream");
 }
 

@@ -18,33 +18,35 @@ namespace gp {
 // ----------------------------------------------------------------------------------------------
 constexpr int TEAM = 4;
 
-struct TeamCombine {
+template <int TS> struct TeamCombineT {
   static constexpr int DP = 16;  // floats per wave slot (D <= 16 for every compiled specialisation)
-  float* slots;                  // [2][TEAM][DP] in LDS
+  float* slots;                  // [2][TS][DP] in LDS
   int wave, lane, parity;
   __device__ __forceinline__ void init(float* s, int w, int l) { slots = s; wave = w; lane = l; parity = 0; }
   template <int NV> __device__ __forceinline__ void run(const float (&part)[NV], float (&f)[NV]) {
     static_assert(NV <= DP, "slot too small");
-    float* mine = slots + (parity * TEAM + wave) * DP;
+    float* mine = slots + (parity * TS + wave) * DP;
     if (lane == 0) {
 #pragma unroll
       for (int d = 0; d < NV; ++d) mine[d] = part[d];
     }
     __syncthreads();
-    const float* base = slots + parity * TEAM * DP;
+    const float* base = slots + parity * TS * DP;
 #pragma unroll
     for (int d = 0; d < NV; ++d) {
       float v = base[d];
 #pragma unroll
-      for (int w = 1; w < TEAM; ++w) v += base[w * DP + d];
+      for (int w = 1; w < TS; ++w) v += base[w * DP + d];
       f[d] = v;
     }
     parity ^= 1;
   }
 };
+using TeamCombine = TeamCombineT<TEAM>;
 
 template <int DI, int DO, int NJ> struct RbfTeamEval {
   using L = RbfLayout<DI, DO>;
+  static constexpr int kTeam = TEAM;
   float4 rff[NJ * DO][L::RQ];
   float4 ind[L::RQ2];
   const float* wl;
@@ -128,6 +130,7 @@ template <int DI, int DO, int NJ> struct RbfTeamEval {
 
 template <int D, int NJ> struct DfTeamEval {
   using L = DfLayout<D>;
+  static constexpr int kTeam = TEAM;
   float4 rff[NJ * D][L::RQ];
   float4 ind[L::RQ2];
   const float* uni;
@@ -209,7 +212,7 @@ template <int D, int NJ> struct DfTeamEval {
 };
 
 // ----------------------------------------------------------------------------------------------
-// STREAMED team evaluators: the same 4-wave team and combine, but the pack stays in
+// STREAMED team evaluators: the same team and combine (TS = 4 or 8 wavefronts), but the pack stays in
 // global memory -- it is L2-resident (0.66 MB at D=16, M=512, S=256) -- and every wave walks its share
 // of the records: rff records rec = wave, wave+4, ...; inducing work units u = 2 j + half = wave,
 // wave+4, ... (so `half` is still a per-wave constant).  Any S and M, and the D whose records no longer
@@ -291,13 +294,14 @@ __device__ __forceinline__ void df_ind_part_bwd(const float4 (&r)[DfLayout<D>::R
   }
 }
 
-template <int DI, int DO> struct RbfStreamTeam {
+template <int DI, int DO, int TS = TEAM> struct RbfStreamTeam {
   using L = RbfLayout<DI, DO>;
+  static constexpr int kTeam = TS;                   // wavefronts per trajectory (8 when few trajectories would leave CUs idle)
   const float4* p4;
   const float4* i4;
   const float* wl;
   int nrec, nunit, wave, lane;
-  TeamCombine comb;
+  TeamCombineT<TS> comb;
   __device__ __forceinline__ void init(const float* pack, int M, int S, float* lds, int w, int l) {
     p4 = reinterpret_cast<const float4*>(pack);
     i4 = p4 + L::rff_f4(S);
@@ -312,7 +316,7 @@ template <int DI, int DO> struct RbfStreamTeam {
 #pragma unroll
     for (int d = 0; d < DO; ++d) acc[d] = 0.f;
     if (MODE != 2) {
-      for (int rec = wave; rec < nrec; rec += TEAM) {
+      for (int rec = wave; rec < nrec; rec += TS) {
         float4 r[L::RQ];
         load_record<L::RQ>(p4, rec, lane, r);
         float v = 0.f;
@@ -323,7 +327,7 @@ template <int DI, int DO> struct RbfStreamTeam {
       }
     }
     if (MODE != 1) {
-      for (int u = wave; u < nunit; u += TEAM) {
+      for (int u = wave; u < nunit; u += TS) {
         asm volatile("" ::: "memory");
         float4 r[L::RQ2];
         load_record<L::RQ2>(i4, u >> 1, lane, r);
@@ -332,20 +336,20 @@ template <int DI, int DO> struct RbfStreamTeam {
     }
     float part[DO];
     wave_sum_all<DO>(acc, part);
-    comb.run<DO>(part, f);
+    comb.template run<DO>(part, f);
   }
   __device__ __forceinline__ void vjp(const float (&x)[DI], const float (&a)[DO], float (&gx)[DI], bool prior_only = false) {
     float acc[DI];
 #pragma unroll
     for (int i = 0; i < DI; ++i) acc[i] = 0.f;
     float g0[4 * L::RQ], g1[4 * L::RQ2], g2[(DO + 1) / 2][DI];
-    for (int rec = wave; rec < nrec; rec += TEAM) {
+    for (int rec = wave; rec < nrec; rec += TS) {
       float4 r[L::RQ];
       load_record<L::RQ>(p4, rec, lane, r);
       rbf_rff_bwd<DI, DO, false>(r, x, pick<DO>(a, rec % DO), acc, g0);
     }
     if (!prior_only) {
-      for (int u = wave; u < nunit; u += TEAM) {
+      for (int u = wave; u < nunit; u += TS) {
         asm volatile("" ::: "memory");   // as below: uniform-table loads stay in the loop
         float4 r[L::RQ2];
         load_record<L::RQ2>(i4, u >> 1, lane, r);
@@ -354,18 +358,20 @@ template <int DI, int DO> struct RbfStreamTeam {
     }
     float part[DI];
     wave_sum_all<DI>(acc, part);
-    comb.run<DI>(part, gx);
+    comb.template run<DI>(part, gx);
   }
 };
 
-template <int D> struct DfStreamTeam {
+template <int D, int TS = TEAM> struct DfStreamTeam {
   using L = DfLayout<D>;
+  static constexpr int kTeam = TS;
   static constexpr int NPB = D > 8 ? 4 : 2;          // column parts per inducing record in the backward (df_ind_part_bwd)
+  static_assert(TS % NPB == 0 && TS % 2 == 0, "a wavefront keeps one column part for the whole launch");
   const float4* p4;
   const float4* i4;
   const float* uni;
   int nrec, nunit, wave, lane;
-  TeamCombine comb;
+  TeamCombineT<TS> comb;
   __device__ __forceinline__ void init(const float* pack, int M, int S, float* lds, int w, int l) {
     p4 = reinterpret_cast<const float4*>(pack);
     i4 = p4 + L::rff_f4(S);
@@ -380,14 +386,14 @@ template <int D> struct DfStreamTeam {
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = 0.f;
     if (MODE != 2) {
-      for (int rec = wave; rec < nrec; rec += TEAM) {
+      for (int rec = wave; rec < nrec; rec += TS) {
         float4 r[L::RQ];
         load_record<L::RQ>(p4, rec, lane, r);
         df_rff_record<D>(r, x, acc);
       }
     }
     if (MODE != 1) {
-      for (int u = wave; u < nunit; u += TEAM) {
+      for (int u = wave; u < nunit; u += TS) {
         asm volatile("" ::: "memory");
         float4 r[L::RQ2];
         load_record<L::RQ2>(i4, u >> 1, lane, r);
@@ -396,20 +402,20 @@ template <int D> struct DfStreamTeam {
     }
     float part[D];
     wave_sum_all<D>(acc, part);
-    comb.run<D>(part, f);
+    comb.template run<D>(part, f);
   }
   __device__ __forceinline__ void vjp(const float (&x)[D], const float (&a)[D], float (&gx)[D], bool prior_only = false) {
     float acc[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) acc[i] = 0.f;
     float g0[4 * L::RQ], g1[4 * L::RQ2], g2[D][(D + NPB - 1) / NPB], g3[D][(D + NPB - 1) / NPB], g4[(D + NPB - 1) / NPB];
-    for (int rec = wave; rec < nrec; rec += TEAM) {
+    for (int rec = wave; rec < nrec; rec += TS) {
       float4 r[L::RQ];
       load_record<L::RQ>(p4, rec, lane, r);
       df_rff_bwd<D, false>(r, x, a, acc, g0);
     }
     if (!prior_only) {
-      for (int u = wave; u < NPB * (nunit / 2); u += TEAM) {   // unit u = NPB * record + column part
+      for (int u = wave; u < NPB * (nunit / 2); u += TS) {   // unit u = NPB * record + column part
         asm volatile("" ::: "memory");   // keep the 2 D^2 + D uniform-table loads inside the loop (hoisted they spill)
         float4 r[L::RQ2];
         load_record<L::RQ2>(i4, u / NPB, lane, r);
@@ -418,7 +424,7 @@ template <int D> struct DfStreamTeam {
     }
     float part[D];
     wave_sum_all<D>(acc, part);
-    comb.run<D>(part, gx);
+    comb.template run<D>(part, gx);
   }
 };
 
