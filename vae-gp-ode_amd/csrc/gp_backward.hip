@@ -554,7 +554,6 @@ __global__ __launch_bounds__(1024) void reduce_slab_kernel(const float* __restri
 // host side
 // ---------------------------------------------------------------------------------------------
 static inline int team_grid_b(int N) { return N < 2048 ? N : 2048; }
-static const int kWideTeamRows = 256;  // streamed team: 8 wavefronts per row up to here (gp_forward.hip)
 
 // register-resident team when the quarter pack fits (S <= 256, M <= 128, D <= 8), streamed team otherwise
 template <int DI, int DO> static bool rbf_team_ok(int M, int S) {
@@ -576,12 +575,8 @@ static int launch_bwd_rbf(const float* pack, int M, int S, const float* xstage, 
       return check_launch("rollout_bwd_rbf");
     }
   }
-  if (N <= kWideTeamRows)
-    hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfStreamTeam<DI, DO, 8>, DI, DO, ORDER, METHOD>), team_grid_b(N), 512, 0, st,
-                       pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
-  else
-    hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfStreamTeam<DI, DO>, DI, DO, ORDER, METHOD>), team_grid_b(N), 256, 0, st,
-                       pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+  hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfStreamTeam<DI, DO>, DI, DO, ORDER, METHOD>), team_grid_b(N), 256, 0, st,
+                     pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
   return check_launch("rollout_bwd_rbf_stream");
 }
 
@@ -595,12 +590,8 @@ static int launch_bwd_df(const float* pack, int M, int S, const float* xstage, c
       return check_launch("rollout_bwd_df");
     }
   }
-  if (N <= kWideTeamRows)
-    hipLaunchKernelGGL((rollout_bwd_team_kernel<DfStreamTeam<D, 8>, D, D, 1, METHOD>), team_grid_b(N), 512, 0, st,
-                       pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
-  else
-    hipLaunchKernelGGL((rollout_bwd_team_kernel<DfStreamTeam<D>, D, D, 1, METHOD>), team_grid_b(N), 256, 0, st,
-                       pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+  hipLaunchKernelGGL((rollout_bwd_team_kernel<DfStreamTeam<D>, D, D, 1, METHOD>), team_grid_b(N), 256, 0, st,
+                     pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
   return check_launch("rollout_bwd_df_stream");
 }
 
@@ -649,8 +640,7 @@ static int launch_vjp_rbf(const float* pack, int M, int S, const float* x, const
       return check_launch("rhs_vjp_rbf");
     }
   }
-  if (R <= kWideTeamRows) hipLaunchKernelGGL((rhs_vjp_team_kernel<RbfStreamTeam<DI, DO, 8>, DI, DO>), team_grid_b(R), 512, 0, st, pack, M, S, x, a, R, gx, prior_only);
-  else hipLaunchKernelGGL((rhs_vjp_team_kernel<RbfStreamTeam<DI, DO>, DI, DO>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);
+  hipLaunchKernelGGL((rhs_vjp_team_kernel<RbfStreamTeam<DI, DO>, DI, DO>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);
   return check_launch("rhs_vjp_rbf_stream");
 }
 
@@ -662,8 +652,7 @@ static int launch_vjp_df(const float* pack, int M, int S, const float* x, const 
       return check_launch("rhs_vjp_df");
     }
   }
-  if (R <= kWideTeamRows) hipLaunchKernelGGL((rhs_vjp_team_kernel<DfStreamTeam<D, 8>, D, D>), team_grid_b(R), 512, 0, st, pack, M, S, x, a, R, gx, prior_only);
-  else hipLaunchKernelGGL((rhs_vjp_team_kernel<DfStreamTeam<D>, D, D>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);
+  hipLaunchKernelGGL((rhs_vjp_team_kernel<DfStreamTeam<D>, D, D>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);
   return check_launch("rhs_vjp_df_stream");
 }
 

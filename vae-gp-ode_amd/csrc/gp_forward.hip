@@ -365,7 +365,6 @@ static inline void grid_for(int N, int& grid, int& block) {
   if (grid < 1) grid = 1;
 }
 
-static const int kWideTeamRows = 256;  // streamed team: up to here 8 wavefronts per trajectory (256 rows x 8 = 2 per SIMD), 4 beyond
 static const int kTeamMaxRows = 2048;  // below this, 4 waves per trajectory beat 1 (all 1024 SIMDs busy sooner)
 static inline int team_grid(int N) { return N < 2048 ? N : 2048; }
 
@@ -380,8 +379,7 @@ static int launch_rhs_rbf(const float* pack, int M, int S, const float* x, int N
     }
   }
   if (N <= kTeamMaxRows) {     // past the register-resident quarter pack: the same team, records streamed from L2
-    if (N <= kWideTeamRows) hipLaunchKernelGGL((rhs_team_kernel<RbfStreamTeam<DI, DO, 8>, DI, DO>), team_grid(N), 512, 0, st, pack, M, S, x, N, f, mode);
-    else hipLaunchKernelGGL((rhs_team_kernel<RbfStreamTeam<DI, DO>, DI, DO>), team_grid(N), 256, 0, st, pack, M, S, x, N, f, mode);
+    hipLaunchKernelGGL((rhs_team_kernel<RbfStreamTeam<DI, DO>, DI, DO>), team_grid(N), 256, 0, st, pack, M, S, x, N, f, mode);
     return check_launch("rhs_rbf_team_stream");
   }
   const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
@@ -414,8 +412,7 @@ static int launch_rhs_df(const float* pack, int M, int S, const float* x, int N,
     }
   }
   if (N <= kTeamMaxRows) {
-    if (N <= kWideTeamRows) hipLaunchKernelGGL((rhs_team_kernel<DfStreamTeam<D, 8>, D, D>), team_grid(N), 512, 0, st, pack, M, S, x, N, f, mode);
-    else hipLaunchKernelGGL((rhs_team_kernel<DfStreamTeam<D>, D, D>), team_grid(N), 256, 0, st, pack, M, S, x, N, f, mode);
+    hipLaunchKernelGGL((rhs_team_kernel<DfStreamTeam<D>, D, D>), team_grid(N), 256, 0, st, pack, M, S, x, N, f, mode);
     return check_launch("rhs_df_team_stream");
   }
   // one evaluation per row: staging the pack in LDS only pays when a workgroup evaluates many rows
@@ -441,8 +438,7 @@ static int launch_rollout_rbf(const float* pack, int M, int S, const float* z0, 
     }
   }
   if (N <= kTeamMaxRows) {
-    if (N <= kWideTeamRows) hipLaunchKernelGGL((rollout_team_kernel<RbfStreamTeam<DI, DO, 8>, DI, DO, ORDER, METHOD>), team_grid(N), 512, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
-    else hipLaunchKernelGGL((rollout_team_kernel<RbfStreamTeam<DI, DO>, DI, DO, ORDER, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
+    hipLaunchKernelGGL((rollout_team_kernel<RbfStreamTeam<DI, DO>, DI, DO, ORDER, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
     return check_launch("rollout_rbf_team_stream");
   }
   const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
@@ -475,8 +471,7 @@ static int launch_rollout_df(const float* pack, int M, int S, const float* z0, c
     }
   }
   if (N <= kTeamMaxRows) {     // e.g. BASELINE configs[4] (D = 16, M = 512): 4 wavefronts per trajectory, records streamed from L2
-    if (N <= kWideTeamRows) hipLaunchKernelGGL((rollout_team_kernel<DfStreamTeam<D, 8>, D, D, 1, METHOD>), team_grid(N), 512, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
-    else hipLaunchKernelGGL((rollout_team_kernel<DfStreamTeam<D>, D, D, 1, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
+    hipLaunchKernelGGL((rollout_team_kernel<DfStreamTeam<D>, D, D, 1, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
     return check_launch("rollout_df_team_stream");
   }
   if (f4 * 16 <= kLdsLimitBytes) {

@@ -212,7 +212,7 @@ template <int D, int NJ> struct DfTeamEval {
 };
 
 // ----------------------------------------------------------------------------------------------
-// STREAMED team evaluators: the same team and combine (TS = 4 or 8 wavefronts), but the pack stays in
+// STREAMED team evaluators: the same team and combine (TS wavefronts, 4 in every launch), but the pack stays in
 // global memory -- it is L2-resident (0.66 MB at D=16, M=512, S=256) -- and every wave walks its share
 // of the records: rff records rec = wave, wave+4, ...; inducing work units u = 2 j + half = wave,
 // wave+4, ... (so `half` is still a per-wave constant).  Any S and M, and the D whose records no longer
@@ -296,7 +296,7 @@ __device__ __forceinline__ void df_ind_part_bwd(const float4 (&r)[DfLayout<D>::R
 
 template <int DI, int DO, int TS = TEAM> struct RbfStreamTeam {
   using L = RbfLayout<DI, DO>;
-  static constexpr int kTeam = TS;                   // wavefronts per trajectory (8 when few trajectories would leave CUs idle)
+  static constexpr int kTeam = TS;                   // wavefronts per trajectory; 8 measured slower than 4 at D = 16 (256-VGPR cap: rollout 5.2 -> 8.1 ms)
   const float4* p4;
   const float4* i4;
   const float* wl;
