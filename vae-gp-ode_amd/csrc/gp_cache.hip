@@ -44,6 +44,7 @@ struct PrepArgs {
   float *pack, *pack_ind, *uni;
   float *ell_ws, *var_ws, *u_ws;
   float *ell_out, *var_out, *omega_out, *phase_out, *u_out;
+  int* info;                                         // status word of the factorisation, cleared here (no memset node)
   int nb_rff, nb_u, nb_ind, nb_hyp, nb_om;
 };
 
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
   }
   blk -= a.nb_ind;
   if (blk < a.nb_hyp) {
+    if (threadIdx.x < 4) a.info[threadIdx.x] = 0;
     for (int e = tid; e < Do * Di; e += 256) {
       float l = sEll[e];
       a.ell_ws[e] = l;
@@ -667,8 +669,6 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
   float* pack_ind = pack + 4 * rff_f4;
   float* uni = pack + 4 * (rff_f4 + ind_f4);
   int* info = reinterpret_cast<int*>(ws + w.info);
-  hipError_t e = hipMemsetAsync(info, 0, 16, st);
-  if (e != hipSuccess) return set_error("memset: %s", hipGetErrorString(e));
   {
     PrepArgs a;
     a.kernel = kernel; a.Di = Di; a.Do = Do; a.M = M; a.S = S;
@@ -677,6 +677,7 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
     a.pack = pack; a.pack_ind = pack_ind; a.uni = uni;
     a.ell_ws = ws + w.ell; a.var_ws = ws + w.var; a.u_ws = ws + w.u;
     a.ell_out = ell; a.var_out = var; a.omega_out = omega; a.phase_out = phase; a.u_out = u;
+    a.info = info;
     a.nb_rff = cdiv((int)(SJ * Do * 64), 256);
     a.nb_u = cdiv(M * Do, 4);
     a.nb_ind = cdiv((int)(MJ * 64), 256);
@@ -686,13 +687,10 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
     if (check_launch("cache prep")) return 1;
   }
 
-  // u_prior = f_prior(Z): the rhs kernel in prior-only mode on the M inducing locations
-  float* up = ws + w.u_prior;
+  // u_prior = f_prior(Z): the rhs kernel in prior-only mode on the M inducing locations (straight into the caller's
+  // buffer when one is given: no copy node on the critical path of the step)
+  float* up = u_prior ? u_prior : ws + w.u_prior;
   if (rhs_fwd(kernel, Di, Do, M, S, pack, Z, M, up, 1, st)) return 1;
-  if (u_prior) {
-    e = hipMemcpyAsync(u_prior, up, sizeof(float) * M * Do, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return set_error("memcpy: %s", hipGetErrorString(e));
-  }
 
   float* A = ws + w.A;
   float* Lmat = ws + w.Lmat;
