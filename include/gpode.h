@@ -110,6 +110,17 @@ int gpode_cache_info(const float* ws, int* host_info, void* stream);
 int gpode_kernel_matrix(int kernel, int Di, int Do, const float* raw_ell, const float* raw_var,
                         const float* X, int N, const float* X2, int M2, float* out, void* stream);
 
+/* SVGP_Layer.build_conditional (svpy.py:176-210), RBF kernel: q(f(x)) = N(m(x), Sigma(x)) at the rows of x (N,Di).
+ * raw_ell (Do,Di), raw_var (Do), Z (M,Di), Um (M,Do) as in gpode_cache_build_fwd.  us_rank1 = 0: Us = the packed lower
+ * triangle (Do, M(M+1)/2); us_rank1 = 1 (q_diag=True): Us = the constrained scale as (Do,M) columns s_d, and Us Us^T is the
+ * rank-one s_d s_d^T the reference forms from its (M,1) column (svpy.py:194-195).
+ * mean (N,Do).  full_cov = 0: var (N,Do) marginal variances; full_cov = 1: var (N,N,Do) (the layout `var.T` has in
+ * svpy.py:210).  ws: gpode_conditional_ws floats of scratch (the caller allocates). */
+int gpode_conditional_ws(int Di, int Do, int M, int N, size_t* ws_floats);
+int gpode_conditional(int Di, int Do, int M, int N, const float* raw_ell, const float* raw_var, const float* Z,
+                      const float* Um, const float* Us, int us_rank1, const float* x, int full_cov, float* mean,
+                      float* var, float* ws, void* stream);
+
 /* SVGP_Layer.kl (svpy.py:144-175, q_diag=False): Um (M,Do), Us_packed (Do, M(M+1)/2) -> kl (1 float).
  * _bwd: g = d loss / d kl (1 float, device) -> dUm (M,Do), dUs (Do, M(M+1)/2). */
 int gpode_svgp_kl_fwd(int M, int Do, const float* Um, const float* Us_packed, float* kl, void* stream);

@@ -252,6 +252,26 @@ def gp_forward(x, c):
     return gp_prior(x, c) + gp_update(x, c)
 
 
+def build_conditional(p, x, full_cov=False):
+    """svpy.py:176-210 (RBF): q(f(x)) = N(m, Sigma), A = L^-1 K(Z,x), m = A^T Um, Sigma = K(x,x) + A^T (Us Us^T - I) A.
+    Returns (mean (N,Do), var (N,Do)) or var (N,N,Do) with full_cov, the layouts of the reference's ``var.T``."""
+    p, _ = broadcast_shared(p, dict(rff_eps=torch.zeros(1, 1), rff_u=torch.zeros(1, 1)))
+    ell, var = softplus(p['raw_ell']) + 1e-12, softplus(p['raw_var']) + 1e-12          # kernels.py:56-62
+    Z, Um = p['Z'], p['Um']
+    M = Z.shape[0]
+    Ku = rbf_K(Z, Z, ell, var)
+    Lu = torch.linalg.cholesky(Ku + torch.eye(M, dtype=Ku.dtype) * JITTER)              # svpy.py:190
+    A = torch.linalg.solve_triangular(Lu, rbf_K(Z, x, ell, var), upper=False)            # (Do,M,N)
+    Us = softplus(p['Us']).T[:, :, None] if is_q_diag(p['Us'], Um) else tril_unpack(p['Us'], M)
+    SK = Us @ Us.permute(0, 2, 1) - torch.eye(M, dtype=Ku.dtype).unsqueeze(0)
+    B = torch.einsum('dme,den->dmn', SK, A)
+    if full_cov:
+        cov = rbf_K(x, x, ell, var) + torch.einsum('dme,dmn->den', A, B)
+    else:
+        cov = torch.diagonal(rbf_K(x, x, ell, var), dim1=1, dim2=2) + (A * B).sum(1)
+    return torch.einsum('dmn,md->nd', A, Um), cov.permute(*reversed(range(cov.dim())))
+
+
 def svgp_kl(Um, Us_packed):
     """svpy.py:144-175"""
     M = Um.shape[0]

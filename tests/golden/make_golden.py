@@ -268,6 +268,24 @@ def model_case_intermediates(name, kernel, order, N, M, S, q, T, L, solver, seed
     np.savez_compressed(os.path.join(OUT, name + '_fwd.npz'), **out)
 
 
+def cond_case(name, order, q, M, N, seed, q_diag=False, dimwise=True):
+    """SVGP_Layer.build_conditional (svpy.py:176-210) of the reference, marginal and full covariance, on a layer whose
+    variational parameters are moved off their initial values."""
+    model = build('RBF', order, M, 32, q, 'euler', seed, False, 0.25, q_diag, dimwise)
+    gp = model.flow.odefunc.diffeq
+    g = torch.Generator().manual_seed(seed + 5)
+    with torch.no_grad():
+        gp.Um.optvar.add_(0.3 * torch.randn(gp.Um.optvar.shape, generator=g))
+        gp.Us_sqrt.optvar.add_(0.2 * torch.randn(gp.Us_sqrt.optvar.shape, generator=g))
+    x = 1.5 * torch.randn(N, q * order, generator=g)
+    with torch.no_grad():
+        mean, var = gp.build_conditional(x)
+        mean_f, cov = gp.build_conditional(x, full_cov=True)
+    out = {'sd.' + k: npy(v) for k, v in model.state_dict().items() if k.startswith('flow.odefunc.diffeq')}
+    out.update(x=npy(x), mean=npy(mean), var=npy(var), mean_full=npy(mean_f), cov=npy(cov))
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+
+
 def data_case(name, seed):
     """Dataset items, rot_start, rotate_img of the reference on seeded random frames."""
     for modname in ('torchvision', 'torchvision.transforms'):
@@ -291,6 +309,11 @@ def data_case(name, seed):
 if __name__ == '__main__':
     torch.set_num_threads(1)
     data_case('data_path', 301)
+    # q(f(x)) of the sparse GP layer (build_conditional): dimwise RBF orders 1-2, diagonal inducing covariance, shared hyper-parameters
+    cond_case('cond_rbf1', 1, 6, 16, 5, 401)
+    cond_case('cond_rbf2', 2, 3, 16, 5, 402)
+    cond_case('cond_rbf1_qdiag', 1, 6, 16, 5, 403, q_diag=True)
+    cond_case('cond_rbf1_shared', 1, 6, 16, 5, 404, dimwise=False)
     # tiny shapes: every variant
     gp_case('gp_rbf1_tiny', 'RBF', 1, N=4, M=16, S=32, q=6, T=5, seed=101)
     gp_case('gp_rbf2_tiny', 'RBF', 2, N=4, M=16, S=32, q=3, T=5, seed=102)

@@ -202,3 +202,46 @@ def test_df_sixteen_dimensional_latent_forward():
     z32 = O.flow_forward(z0, ts, c32, 1, 'rk4')
     z64 = O.flow_forward(z0.double(), ts.double(), c64, 1, 'rk4')
     assert relerr(zt, z64) < 2e-4 + 3 * relerr(z32, z64), (relerr(zt, z64), relerr(z32, z64))
+
+
+@pytest.mark.parametrize('name,order,q_diag,dimwise', [('cond_rbf1', 1, False, True), ('cond_rbf2', 2, False, True),
+                                                      ('cond_rbf1_qdiag', 1, True, True), ('cond_rbf1_shared', 1, False, False)])
+def test_build_conditional_matches_reference(name, order, q_diag, dimwise):
+    """SVGP_Layer.build_conditional on the GPU (augmented Cholesky + two small kernels) against the reference's outputs and
+    the oracle's fp64 evaluation; tolerance |hip - ref| <= 1e-4 + 3 |ref - fp64|."""
+    from vae_gp_ode_amd.model.core.svpy import SVGP_Layer
+    g = load_golden(name)
+    sd = sub(g, 'sd.flow.odefunc.diffeq.')
+    M, Do = sd['Um.optvar'].shape
+    Di = g['x'].shape[1]
+    gp = SVGP_Layer(Di, Do, M, 32, q_diag=q_diag, dimwise=dimwise, kernel='RBF').cuda()
+    gp.load_state_dict(sd)
+    mean, var = gp.build_conditional(g['x'].cuda())
+    mean_f, cov = gp.build_conditional(g['x'].cuda(), full_cov=True)
+    p64 = O.to_dtype(O.gp_params_from_state_dict(sub(g, 'sd.')), torch.float64)
+    m64, v64 = O.build_conditional(p64, g['x'].double())
+    _, c64 = O.build_conditional(p64, g['x'].double(), full_cov=True)
+    for got, ref, twin in ((mean, g['mean'], m64), (var, g['var'], v64), (mean_f, g['mean_full'], m64), (cov, g['cov'], c64)):
+        assert got.shape == ref.shape
+        assert relerr(got, ref) < 1e-4 + 3 * relerr(ref, twin), (relerr(got, ref), relerr(ref, twin))
+
+
+def test_build_conditional_many_queries_and_errors():
+    """256 query points (an augmented system of 356 rows, 12 tile columns) against the fp64 oracle; the DF kernel refuses."""
+    from vae_gp_ode_amd.model.core.svpy import SVGP_Layer
+    torch.manual_seed(5)
+    gp = SVGP_Layer(6, 3, 100, 32, kernel='RBF').cuda()
+    with torch.no_grad():
+        gp.Um.optvar.add_(0.2 * torch.randn_like(gp.Um.optvar))
+        gp.Us_sqrt.optvar.add_(0.05 * torch.randn_like(gp.Us_sqrt.optvar))
+    x = torch.randn(256, 6)
+    mean, var = gp.build_conditional(x.cuda())
+    p = dict(raw_ell=gp.kern.unconstrained_lengthscales, raw_var=gp.kern.unconstrained_variance, Z=gp.inducing_loc.optvar,
+             Um=gp.Um.optvar, Us=gp.Us_sqrt.optvar)
+    p32 = {k: v.detach().cpu() for k, v in p.items()}
+    m64, v64 = O.build_conditional(O.to_dtype(p32, torch.float64), x.double())
+    m32, v32 = O.build_conditional(p32, x)
+    assert relerr(mean, m64) < 1e-4 + 3 * relerr(m32, m64) and relerr(var, v64) < 1e-4 + 3 * relerr(v32, v64)
+    assert (var > 0).all()
+    with pytest.raises(NotImplementedError):
+        SVGP_Layer(6, 6, 16, 32, kernel='DF').cuda().build_conditional(x[:4].cuda())

@@ -147,3 +147,20 @@ def test_fixed_grid_solvers_on_a_linear_ode(method, order_of_accuracy):
         errs.append((yT - exact).abs().max().item())
     rate = math.log2(errs[1] / errs[2])
     assert abs(rate - order_of_accuracy) < 0.25, (errs, rate)
+
+
+COND_CASES = ['cond_rbf1', 'cond_rbf2', 'cond_rbf1_qdiag', 'cond_rbf1_shared']
+
+
+@pytest.mark.parametrize('name', COND_CASES)
+def test_build_conditional_restatement_matches_reference(name):
+    """q(f(x)) of the sparse GP layer (svpy.py:176-210): mean, marginal variances and full covariance of the restatement against
+    the reference's outputs (fp32 on both sides; the two differ only in the triangular-solve routine)."""
+    g = load_golden(name)
+    p = O.gp_params_from_state_dict(sub(g, 'sd.'))
+    mean, var = O.build_conditional(p, g['x'])
+    mean_f, cov = O.build_conditional(p, g['x'], full_cov=True)
+    assert mean.shape == g['mean'].shape and var.shape == g['var'].shape and cov.shape == g['cov'].shape
+    for got, ref in ((mean, g['mean']), (var, g['var']), (mean_f, g['mean_full']), (cov, g['cov'])):
+        assert (got - ref).abs().max() <= 2e-5 * ref.abs().max()
+    assert torch.allclose(torch.diagonal(cov, dim1=0, dim2=1).T, var, rtol=1e-5, atol=1e-6)

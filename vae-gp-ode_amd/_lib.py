@@ -26,6 +26,8 @@ SIGNATURES = {
     'gpode_cache_bwd_prepare': (_i, [_i] * 5 + [_c_float_p] * 2 + [ctypes.c_void_p]),
     'gpode_cache_info': (_i, [_c_float_p, ctypes.POINTER(_i), ctypes.c_void_p]),
     'gpode_kernel_matrix': (_i, [_i, _i, _i, _c_float_p, _c_float_p, _c_float_p, _i, _c_float_p, _i, _c_float_p, ctypes.c_void_p]),
+    'gpode_conditional_ws': (_i, [_i, _i, _i, _i, _sz_p]),
+    'gpode_conditional': (_i, [_i, _i, _i, _i] + [_c_float_p] * 5 + [_i, _c_float_p, _i] + [_c_float_p] * 3 + [ctypes.c_void_p]),
     'gpode_svgp_kl_fwd': (_i, [_i, _i, _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p]),
     'gpode_svgp_kl_bwd': (_i, [_i, _i] + [_c_float_p] * 5 + [ctypes.c_void_p]),
     'gpode_rhs_fwd': (_i, [_i] * 5 + [_c_float_p, _c_float_p, _i, _c_float_p, _i, ctypes.c_void_p]),

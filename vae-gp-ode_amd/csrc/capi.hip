@@ -86,6 +86,17 @@ int gpode_kernel_matrix(int kernel, int Di, int Do, const float* raw_ell, const 
   return gp::kernel_matrix(kernel, Di, Do, raw_ell, raw_var, X, N, X2, M2, out, (hipStream_t)stream);
 }
 
+int gpode_conditional_ws(int Di, int Do, int M, int N, size_t* ws_floats) {
+  if (!ws_floats) return gp::set_error("gpode_conditional_ws: null pointer");
+  return gp::conditional_ws(Di, Do, M, N, ws_floats);
+}
+
+int gpode_conditional(int Di, int Do, int M, int N, const float* raw_ell, const float* raw_var, const float* Z, const float* Um,
+                      const float* Us, int us_rank1, const float* x, int full_cov, float* mean, float* var, float* ws, void* stream) {
+  if (!raw_ell || !raw_var || !Z || !Um || !Us || !x || !mean || !var || !ws) return gp::set_error("gpode_conditional: null pointer");
+  return gp::conditional(Di, Do, M, N, raw_ell, raw_var, Z, Um, Us, us_rank1, x, full_cov, mean, var, ws, (hipStream_t)stream);
+}
+
 int gpode_svgp_kl_fwd(int M, int Do, const float* Um, const float* Us_packed, float* kl, void* stream) {
   if (!Um || !Us_packed || !kl) return gp::set_error("gpode_svgp_kl_fwd: null pointer");
   return gp::svgp_kl_fwd(M, Do, Um, Us_packed, kl, (hipStream_t)stream);

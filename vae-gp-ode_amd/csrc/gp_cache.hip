@@ -17,6 +17,7 @@
 // panel solves for free (row n of the factor); only the transposed solve runs as its own kernel.
 #include "gp_eval.hpp"
 #include "gp_launch.hpp"
+#include "wave_reduce.hpp"
 #include "gp_ws.hpp"
 
 namespace gp {
@@ -655,6 +656,34 @@ int cache_sizes(int kernel, int Di, int Do, int M, int S, size_t* pack_floats, s
   return 0;
 }
 
+// Blocked Cholesky of `batch` np x np systems (A is consumed; L goes to Lmat below the diagonal tiles and to Dfac on them).
+static void cholesky_blocked(float* A, float* Lmat, float* Dfac, int np, int nblk, int batch, int* info, hipStream_t st) {
+  struct { int np, nblk, batch; } w{np, nblk, batch};
+  const size_t bstride = (size_t)np * np, dstride = (size_t)nblk * NB * NB;
+  constexpr int PB = ST / NB;                          // 32-blocks per 128-wide panel
+  if (w.np % ST == 0 && w.np >= 8 * ST) {
+    // big factor (BASELINE configs[4]: 8192 x 8192): panels of 128 columns factored tile column by tile column, then ONE
+    // matrix-core rank-128 update of everything to their right -- n^3/3 of the flops on MFMA, and a launch's redundant
+    // panel factorisations confined to 4 tile columns instead of the whole trailing triangle
+    for (int K = 0; K < w.nblk / PB; ++K) {
+      const int jlim = (K + 1) * PB;
+      for (int k = K * PB; k < jlim; ++k) {
+        int tiles = 0;
+        for (int j = k; j < jlim; ++j) tiles += w.nblk - j;
+        hipLaunchKernelGGL(k_chol_rl, dim3(tiles, w.batch), 256, 0, st, A, Lmat, w.np, bstride, Dfac, dstride, k, info, w.nblk, jlim);
+      }
+      const int Tt = w.nblk / PB - (K + 1);
+      if (Tt > 0)
+        hipLaunchKernelGGL(k_syrk_mfma, dim3(Tt * (Tt + 1) / 2, w.batch), 256, 0, st, A, Lmat, w.np, bstride, jlim * NB, K * ST);
+    }
+  } else {
+    for (int k = 0; k < w.nblk; ++k) {
+      const int T = w.nblk - k;
+      hipLaunchKernelGGL(k_chol_rl, dim3(T * (T + 1) / 2, w.batch), 256, 0, st, A, Lmat, w.np, bstride, Dfac, dstride, k, info, w.nblk, w.nblk);
+    }
+  }
+}
+
 int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
                     const float* raw_ell, const float* raw_var, const float* Z, const float* Um, const float* Us_packed,
                     const float* eps_u, const float* rff_w, const float* rff_eps, const float* rff_u,
@@ -700,28 +729,7 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
     hipLaunchKernelGGL(k_Kzz_rbf, dim3(cdiv(w.np, 128), w.np, Do), 128, 0, st, Di, Do, M, w.np, Z, ws + w.ell, ws + w.var, up, A);
   else
     hipLaunchKernelGGL(k_Kzz_df, dim3(cdiv(w.np, 128), w.np, 1), 128, 0, st, Do, M, w.np, Z, ws + w.ell, ws + w.var, up, A);
-  constexpr int PB = ST / NB;                          // 32-blocks per 128-wide panel
-  if (w.np % ST == 0 && w.np >= 8 * ST) {
-    // big factor (BASELINE configs[4]: 8192 x 8192): panels of 128 columns factored tile column by tile column, then ONE
-    // matrix-core rank-128 update of everything to their right -- n^3/3 of the flops on MFMA, and a launch's redundant
-    // panel factorisations confined to 4 tile columns instead of the whole trailing triangle
-    for (int K = 0; K < w.nblk / PB; ++K) {
-      const int jlim = (K + 1) * PB;
-      for (int k = K * PB; k < jlim; ++k) {
-        int tiles = 0;
-        for (int j = k; j < jlim; ++j) tiles += w.nblk - j;
-        hipLaunchKernelGGL(k_chol_rl, dim3(tiles, w.batch), 256, 0, st, A, Lmat, w.np, bstride, Dfac, dstride, k, info, w.nblk, jlim);
-      }
-      const int Tt = w.nblk / PB - (K + 1);
-      if (Tt > 0)
-        hipLaunchKernelGGL(k_syrk_mfma, dim3(Tt * (Tt + 1) / 2, w.batch), 256, 0, st, A, Lmat, w.np, bstride, jlim * NB, K * ST);
-    }
-  } else {
-    for (int k = 0; k < w.nblk; ++k) {
-      const int T = w.nblk - k;
-      hipLaunchKernelGGL(k_chol_rl, dim3(T * (T + 1) / 2, w.batch), 256, 0, st, A, Lmat, w.np, bstride, Dfac, dstride, k, info, w.nblk, w.nblk);
-    }
-  }
+  cholesky_blocked(A, Lmat, Dfac, w.np, w.nblk, w.batch, info, st);
   if (check_launch("cholesky")) return 1;
 
   // nu = L^-T (u - L^-1 u_prior), written to ws, to the optional output and into the pack
@@ -748,6 +756,165 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
   }
   if (Lu) hipLaunchKernelGGL(k_copy_L, dim3(cdiv(w.n, 128), w.n, w.batch), 128, 0, st, Lmat, Dfac, dstride, w.n, w.np, bstride, Lu);
   return check_launch("cache build");
+}
+
+// ---------------------------------------------------------------------------------------------
+// SVGP_Layer.build_conditional (svpy.py:176-210), RBF kernel: q(f(x)) = N(m(x), Sigma(x)) in whitened form,
+//   A = L^-1 K(Z,x),  m = A^T Um,  Sigma = K(x,x) + A^T (Us Us^T - I) A.
+// The triangular solve rides on the factorisation like the rhs row of the cache build: the N rows K(x_n, Z) are appended to
+// K_uu (huge diagonal, so that eliminating the appended columns touches nothing), and after the Cholesky rows M.. of the factor
+// hold A^T.  Then one workgroup per (query, output) forms t = Us^T a, the mean and the marginal variance
+// sigma^2 + |t|^2 - |a|^2; the full covariance pairs the same vectors.
+// ---------------------------------------------------------------------------------------------
+struct CondLayout { size_t info, A, Lmat, Dfac, a, t, total; int np, nblk; };
+static CondLayout cond_layout(int Do, int M, int N) {
+  CondLayout c;
+  c.nblk = cdiv(M + N, NB);
+  if (c.nblk >= 32) c.nblk = (c.nblk + 3) / 4 * 4;
+  c.np = c.nblk * NB;
+  size_t o = 0;
+  auto take = [&](size_t nfl) { size_t at = o; o += (nfl + 3) / 4 * 4; return at; };
+  c.info = take(4);
+  c.A = take((size_t)Do * c.np * c.np);
+  c.Lmat = take((size_t)Do * c.np * c.np);
+  c.Dfac = take((size_t)Do * c.nblk * NB * NB);
+  c.a = take((size_t)Do * N * M);
+  c.t = take((size_t)Do * N * M);
+  c.total = o;
+  return c;
+}
+
+__device__ __forceinline__ float rbf_k(int Di, const float* __restrict__ raw_ell_d, float var_d, const float* __restrict__ p,
+                                       const float* __restrict__ q) {
+  float s = 0.f;
+  for (int i = 0; i < Di; ++i) {
+    const float t = (p[i] - q[i]) / softplus_lower(raw_ell_d[i]);
+    s = fmaf(t, t, s);
+  }
+  return var_d * expf(-0.5f * s);
+}
+
+__global__ void k_cond_fill(int Di, int Do, int M, int N, int np, const float* __restrict__ raw_ell, const float* __restrict__ raw_var,
+                            const float* __restrict__ Z, const float* __restrict__ x, float* __restrict__ A, int* __restrict__ info) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y, d = blockIdx.z;
+  if (c == 0 && r == 0 && d == 0) info[0] = 0;
+  if (c >= np) return;
+  const float vd = softplus_lower(raw_var[d]);
+  float v;
+  if (r < M) v = c < M ? rbf_k(Di, raw_ell + d * Di, vd, Z + (size_t)r * Di, Z + (size_t)c * Di) + (r == c ? kJitter : 0.f) : 0.f;
+  else if (r < M + N) v = c < M ? rbf_k(Di, raw_ell + d * Di, vd, x + (size_t)(r - M) * Di, Z + (size_t)c * Di) : (c == r ? 1e30f : 0.f);
+  else v = (r == c) ? 1.f : 0.f;
+  A[((size_t)d * np + r) * np + c] = v;
+}
+
+// grid (N, Do), block 256, dynamic LDS M floats
+__global__ __launch_bounds__(256) void k_cond_rows(int Do, int M, int N, int np, const float* __restrict__ Lall, size_t bstride,
+                                                    const float* __restrict__ Dfac_all, size_t dstride,
+                                                    const float* __restrict__ raw_var, const float* __restrict__ Um,
+                                                    const float* __restrict__ Us, int us_rank1, float* __restrict__ Aws,
+                                                    float* __restrict__ Tws, float* __restrict__ mean, float* __restrict__ var_diag) {
+  extern __shared__ float sa[];
+  __shared__ float red[4][3];
+  const int n = blockIdx.x, d = blockIdx.y, tid = threadIdx.x;
+  const float* Lm = Lall + (size_t)d * bstride;
+  const float* Dfac = Dfac_all + (size_t)d * dstride;
+  float* arow = Aws + ((size_t)d * N + n) * M;
+  float* trow = Tws + ((size_t)d * N + n) * M;
+  for (int m = tid; m < M; m += 256) {
+    const float v = factor_elem(Lm, Dfac, np, M + n, m);
+    sa[m] = v;
+    arow[m] = v;
+  }
+  __syncthreads();
+  // us_rank1 (q_diag=True): the reference multiplies the (M,1) column s = softplus(raw)[:, d] with its transpose (svpy.py:194-195),
+  // i.e. Us Us^T = s s^T; t is then the single number s . a, kept in t[0] with zeros behind it
+  float acc[3] = {0.f, 0.f, 0.f};                                   // a . Um[:, d],  |t|^2,  |a|^2
+  if (us_rank1) {
+    const float* sd = Us + (size_t)d * M;
+    float part[1] = {0.f}, tot[1];
+    for (int j = tid; j < M; j += 256) {
+      part[0] = fmaf(sd[j], sa[j], part[0]);
+      acc[0] = fmaf(sa[j], Um[(size_t)j * Do + d], acc[0]);
+      acc[2] = fmaf(sa[j], sa[j], acc[2]);
+      trow[j] = 0.f;
+    }
+    wave_sum_multi<1>(part, tot);
+    if ((tid & 63) == 0) red[tid >> 6][0] = tot[0];
+    __syncthreads();
+    const float t0 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    __syncthreads();
+    if (tid == 0) { trow[0] = t0; acc[1] = t0 * t0; }
+  } else {
+    const float* Ud = Us + (size_t)d * ((size_t)M * (M + 1) / 2);   // packed lower triangle, row-major (transforms.py:67-69)
+    for (int j = tid; j < M; j += 256) {
+      float t = 0.f;
+      for (int m = j; m < M; ++m) t = fmaf(Ud[(size_t)m * (m + 1) / 2 + j], sa[m], t);   // (Us^T a)_j
+      trow[j] = t;
+      acc[0] = fmaf(sa[j], Um[(size_t)j * Do + d], acc[0]);
+      acc[1] = fmaf(t, t, acc[1]);
+      acc[2] = fmaf(sa[j], sa[j], acc[2]);
+    }
+  }
+  float out[3];
+  wave_sum_multi<3>(acc, out);
+  if ((tid & 63) == 0) { red[tid >> 6][0] = out[0]; red[tid >> 6][1] = out[1]; red[tid >> 6][2] = out[2]; }
+  __syncthreads();
+  if (tid == 0) {
+    const float m0 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    const float t2 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    const float a2 = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
+    mean[(size_t)n * Do + d] = m0;
+    if (var_diag) var_diag[(size_t)n * Do + d] = softplus_lower(raw_var[d]) + (t2 - a2);
+  }
+}
+
+// cov[n2][n1][d] = k_d(x_n1, x_n2) + t_n1 . t_n2 - a_n1 . a_n2   ((N,N,Do): the transpose the reference returns)
+__global__ __launch_bounds__(256) void k_cond_cov(int Di, int Do, int M, int N, const float* __restrict__ raw_ell,
+                                                   const float* __restrict__ raw_var, const float* __restrict__ x,
+                                                   const float* __restrict__ Aws, const float* __restrict__ Tws, float* __restrict__ cov) {
+  const int lane = threadIdx.x & 63;
+  const size_t pair = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wavefront per (n1, n2), all outputs d
+  if (pair >= (size_t)N * N) return;
+  const int n1 = (int)(pair / N), n2 = (int)(pair % N);
+  for (int d = 0; d < Do; ++d) {
+    const float* a1 = Aws + ((size_t)d * N + n1) * M;
+    const float* a2 = Aws + ((size_t)d * N + n2) * M;
+    const float* t1 = Tws + ((size_t)d * N + n1) * M;
+    const float* t2 = Tws + ((size_t)d * N + n2) * M;
+    float acc = 0.f;
+    for (int m = lane; m < M; m += 64) acc += t1[m] * t2[m] - a1[m] * a2[m];
+    const float in1[1] = {acc};
+    float out1[1];
+    wave_sum_multi<1>(in1, out1);
+    if (lane == 0)
+      cov[((size_t)n2 * N + n1) * Do + d] = rbf_k(Di, raw_ell + d * Di, softplus_lower(raw_var[d]), x + (size_t)n1 * Di, x + (size_t)n2 * Di) + out1[0];
+  }
+}
+
+int conditional_ws(int Di, int Do, int M, int N, size_t* ws_floats) {
+  if (Di <= 0 || Do <= 0 || M <= 0 || N <= 0) return set_error("gpode_conditional: Di=%d Do=%d M=%d N=%d", Di, Do, M, N);
+  *ws_floats = cond_layout(Do, M, N).total;
+  return 0;
+}
+
+int conditional(int Di, int Do, int M, int N, const float* raw_ell, const float* raw_var, const float* Z, const float* Um,
+                const float* Us_packed, int us_rank1, const float* x, int full_cov, float* mean, float* var, float* ws, hipStream_t st) {
+  size_t need = 0;
+  if (conditional_ws(Di, Do, M, N, &need)) return 1;
+  const CondLayout c = cond_layout(Do, M, N);
+  int* info = reinterpret_cast<int*>(ws + c.info);
+  const size_t bstride = (size_t)c.np * c.np, dstride = (size_t)c.nblk * NB * NB;
+  hipLaunchKernelGGL(k_cond_fill, dim3(cdiv(c.np, 128), c.np, Do), 128, 0, st, Di, Do, M, N, c.np, raw_ell, raw_var, Z, x, ws + c.A, info);
+  cholesky_blocked(ws + c.A, ws + c.Lmat, ws + c.Dfac, c.np, c.nblk, Do, info, st);
+  if (check_launch("conditional: cholesky")) return 1;
+  const size_t lds = sizeof(float) * M;
+  if (set_max_lds((const void*)k_cond_rows, lds)) return 1;
+  hipLaunchKernelGGL(k_cond_rows, dim3(N, Do), 256, lds, st, Do, M, N, c.np, ws + c.Lmat, bstride, ws + c.Dfac, dstride, raw_var, Um,
+                     Us_packed, us_rank1, ws + c.a, ws + c.t, mean, full_cov ? nullptr : var);
+  if (full_cov)
+    hipLaunchKernelGGL(k_cond_cov, (unsigned)(((size_t)N * N + 3) / 4), 256, 0, st, Di, Do, M, N, raw_ell, raw_var, x, ws + c.a, ws + c.t, var);
+  return check_launch("conditional");
 }
 
 }  // namespace gp

@@ -60,6 +60,9 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
 
 int kernel_matrix(int kernel, int Di, int Do, const float* raw_ell, const float* raw_var, const float* X, int N,
                   const float* X2, int M2, float* out, hipStream_t st);
+int conditional_ws(int Di, int Do, int M, int N, size_t* ws_floats);
+int conditional(int Di, int Do, int M, int N, const float* raw_ell, const float* raw_var, const float* Z, const float* Um,
+                const float* Us_packed, int us_rank1, const float* x, int full_cov, float* mean, float* var, float* ws, hipStream_t st);
 int svgp_kl_fwd(int M, int Do, const float* Um, const float* Us, float* kl, hipStream_t st);
 int svgp_kl_bwd(int M, int Do, const float* Um, const float* Us, const float* g, float* dUm, float* dUs, hipStream_t st);
 

@@ -117,6 +117,21 @@ class SVGP_Layer(torch.nn.Module):
             raise RuntimeError('call build_cache() first')
         return ops.rhs(self.cache, x, mode=0)
 
+    def build_conditional(self, x, full_cov=False):
+        """q(f(x)) = N(m(x), Sigma(x)) with m = A^T Um, Sigma = K(x,x) + A^T (Us Us^T - I) A, A = L^-1 K(Z,x)
+        (svpy.py:176-210): returns (mean (N,D_out), var (N,D_out)) or, with ``full_cov``, var (N,N,D_out).  RBF kernel (the
+        reference's einsums assume its (D,M,M) layout); computed without autograd."""
+        if self.kernel_n != 'RBF':
+            raise NotImplementedError('build_conditional: the reference formulates it for the RBF kernel (svpy.py:189-209)')
+        k = self.kern
+        raw_ell, raw_var = k.raw_dimwise() if hasattr(k, 'raw_dimwise') else (k.unconstrained_lengthscales, k.unconstrained_variance)
+        with torch.no_grad():
+            # q_diag: the reference turns the (M,D) scale into (D,M,1) columns, so Us Us^T is the rank-one s s^T (svpy.py:194-195)
+            Us = self.Us_sqrt().T.contiguous() if self.q_diag else self.us_packed()
+            return ops.conditional(raw_ell.detach(), raw_var.detach(), self.inducing_loc.optvar.detach(), self.Um.optvar.detach(),
+                                   Us.detach(), x.detach().to(self.inducing_loc.optvar.device, torch.float32), full_cov,
+                                   us_rank1=self.q_diag)
+
     def kl(self):
         """KL(q(u) || N(0,I)) in whitened form (svpy.py:144-175)."""
         return ops.svgp_kl(self.Um.optvar, self.us_packed(), self.M)

@@ -254,6 +254,24 @@ def svgp_kl(Um, Us_packed, M):
     return _SvgpKL.apply(Um, Us_packed, M)
 
 
+def conditional(raw_ell, raw_var, Z, Um, Us, x, full_cov=False, us_rank1=False):
+    """SVGP_Layer.build_conditional (svpy.py:176-210) for the RBF kernel: mean (N,Do) and the marginal variances (N,Do), or the
+    full covariance (N,N,Do) with ``full_cov``.  Forward only (the reference has no caller that differentiates it)."""
+    Do, Di = raw_ell.shape
+    M, N = Z.shape[0], x.shape[0]
+    raw_ell = _chk(raw_ell, 'raw_ell', (Do, Di)); raw_var = _chk(raw_var, 'raw_var', (Do,))
+    Z = _chk(Z, 'Z', (M, Di)); Um = _chk(Um, 'Um', (M, Do)); x = _chk(x, 'x', (N, Di))
+    Us = _chk(Us, 'Us', (Do, M) if us_rank1 else (Do, M * (M + 1) // 2))     # q_diag: columns s_d (the reference's rank-one Us Us^T)
+    wf = ctypes.c_size_t(0)
+    _lib.call('gpode_conditional_ws', Di, Do, M, N, ctypes.byref(wf))
+    new = lambda *s: torch.empty(s, dtype=torch.float32, device=x.device)
+    ws, mean = new(wf.value), new(N, Do)
+    var = new(N, N, Do) if full_cov else new(N, Do)
+    _lib.call('gpode_conditional', Di, Do, M, N, _ptr(raw_ell), _ptr(raw_var), _ptr(Z), _ptr(Um), _ptr(Us), int(bool(us_rank1)), _ptr(x),
+              int(bool(full_cov)), _ptr(mean), _ptr(var), _ptr(ws), _stream())
+    return mean, var
+
+
 class _Flow(torch.autograd.Function):
     """One GP function draw + fixed-grid integration (flow.py:68-86), differentiable w.r.t. z0 and the five
     GP parameter tensors.  Forward: gpode_cache_build_fwd + gpode_rollout_fwd.  Backward: gpode_rollout_bwd
