@@ -202,6 +202,32 @@ def test_main_trains_from_the_reference_dataset_file(tmp_path, monkeypatch):
         assert len(ck) == 1 and all(torch.isfinite(v).all() for v in torch.load(ck[0]).values() if v.is_floating_point())
 
 
+@pytest.mark.parametrize('graph', [False, True])
+def test_main_trains_data_parallel_on_two_ranks(tmp_path, graph):
+    """`torchrun ... -m vae_gp_ode_amd.main` with two ranks (gloo, both on this card: the N > 1 code path, not a measurement):
+    sharded minibatches (10 sequences in batches of 4: the last one is ragged) under one shared GP draw, gradient all-reduce,
+    rank 0 writes the checkpoint, and the ranks end with identical parameters."""
+    import glob
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPODE_DIST_BACKEND='gloo', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29547' if graph else '29546', '-m', 'vae_gp_ode_amd.main', '--task', 'synthetic', '--Ndata', '10', '--Ntest', '4',
+           '--batch', '4', '--T', '6', '--solver', 'rk4', '--num_inducing', '16', '--num_features', '32', '--lr', '1e-4',
+           '--log_freq', '1', '--Nepoch', '2', '--save', 'results/dp'] + (['--hip_graph', 'True'] if graph else [])
+    r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    logs = glob.glob(str(tmp_path / 'results' / 'dp_*' / 'logs*')) + glob.glob(str(tmp_path / 'results' / 'dp_*' / '*.log'))
+    text = r.stdout + r.stderr + ''.join(open(f).read() for f in logs if os.path.isfile(f))
+    assert 'Data parallel over 2 ranks' in text and 'Optimization completed' in text
+    dev = [float(l.rsplit(':', 1)[1]) for l in text.splitlines() if 'Largest parameter deviation between ranks' in l]
+    assert dev and max(dev) == 0.0, dev
+    ck = glob.glob(str(tmp_path / 'results' / 'dp_*' / 'odegpvae_mnist.pth'))
+    assert len(ck) == 1 and all(torch.isfinite(v).all() for v in torch.load(ck[0]).values() if v.is_floating_point())
+
+
 def test_training_trajectory_matches_the_oracle_over_several_steps():
     """Four full training steps (encoder, GP draw, rollout, decoder, ELBO, backward, Adam) from the reference's own initial
     state (fixture model_df1_tiny) with identical noise fed to both sides: the loss sequence and the parameters after the last

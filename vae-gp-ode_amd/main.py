@@ -4,6 +4,11 @@ NaN guard, per-epoch evaluation on the first test batch, ``odegpvae_mnist.pth`` 
 ``--continue_training`` / ``--pretrained`` wiring, same log lines.  Every arithmetic step runs in the HIP
 kernels behind ``model/``; the optimizer is the one-launch HIP Adam.
 
+Data parallelism (no flag: launch with ``python -m torch.distributed.run --nproc-per-node N -m vae_gp_ode_amd.main ...``): one
+process per GPU over RCCL, every rank takes its shard of each minibatch under the SAME GP draw (rank 0's host-RNG noise is
+broadcast; ``--hip_graph`` seeds the device generators identically), one all-reduce of the flat gradient bucket per step,
+rank 0 logs, evaluates and writes the checkpoint (vae_gp_ode_amd/parallel.py; BatchNorm statistics stay per rank).
+
 Data: ``--task mnist`` goes through ``data/wrappers.load_data`` (``<data_root>/rot_mnist/rot-mnist.mat``, the reference's
 file; the set is uploaded once and minibatches are gathered on the device) or, when that file is absent, tensors saved as
 ``<data_root>/rot_mnist_{train,test}.pt`` (shape (N,T,1,28,28), already z-normalised); ``--task synthetic`` generates rotating
@@ -119,8 +124,40 @@ def load_data(args):
                                     'use --task synthetic to exercise the loop'
                                     % (os.path.join(args.data_root, 'rot_mnist', 'rot-mnist.mat'), fn('train'), fn('test')))
         tr, te = torch.load(fn('train')), torch.load(fn('test'))
-    mk = lambda d, shuffle: torch.utils.data.DataLoader(torch.utils.data.TensorDataset(d), batch_size=args.batch, shuffle=shuffle)
+    # the shuffle has its own generator: identical order on every rank, whatever else consumes the global RNG
+    mk = lambda d, shuffle: torch.utils.data.DataLoader(torch.utils.data.TensorDataset(d), batch_size=args.batch, shuffle=shuffle,
+                                                        generator=torch.Generator().manual_seed(args.seed))
     return mk(tr, True), mk(te, False)
+
+
+def init_distributed():
+    """(dist module or None, rank, world, local device index).  WORLD_SIZE > 1 (torchrun): RCCL, one GPU per rank;
+    GPODE_DIST_BACKEND=gloo lets several ranks share one card (a rehearsal of the code path, as in bench.py)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1:
+        return None, 0, 1, 0
+    import torch.distributed as dist
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    backend = os.environ.get('GPODE_DIST_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local %= max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    else:
+        dist.init_process_group(backend)
+    return dist, dist.get_rank(), world, local
+
+
+class BroadcastNoise:
+    """Every rank integrates under rank 0's GP draw (the draw is shared by the whole minibatch, odegpvae.py:41-43)."""
+
+    def __init__(self, inner, dist):
+        self.inner, self.dist = inner, dist
+
+    def draw(self, *a, **k):
+        from .parallel import broadcast_noise
+        return broadcast_noise(self.inner.draw(*a, **k), self.dist)
 
 
 def main(argv=None):
@@ -130,14 +167,22 @@ def main(argv=None):
     from .model.misc.torch_utils import seed_everything
     from .optim import HipAdam
 
-    args.save = os.path.join(os.path.abspath(os.getcwd()), args.save + datetime.now().strftime('_%d_%m_%Y-%H:%M'), '')
-    os.makedirs(os.path.join(args.save, 'plots'), exist_ok=True)
-    logger = get_logger(os.path.join(args.save, 'logs'))
-    logger.info('Results stored in {}'.format(args.save))
-    seed_everything(args.seed)
     if not torch.cuda.is_available():
         raise SystemExit('this build runs on an MI355X (no CPU fallback)')
-    args.device = torch.device('cuda')
+    dist, rank, world, local = init_distributed()
+    args.save = os.path.join(os.path.abspath(os.getcwd()), args.save + datetime.now().strftime('_%d_%m_%Y-%H:%M'), '')
+    if rank == 0:
+        os.makedirs(os.path.join(args.save, 'plots'), exist_ok=True)
+        logger = get_logger(os.path.join(args.save, 'logs'))
+    else:                                            # one log / checkpoint per job: rank 0's
+        logger = logging.getLogger('gpode_rank%d' % rank)
+        logger.addHandler(logging.NullHandler())
+        logger.propagate = False
+    logger.info('Results stored in {}'.format(args.save))
+    seed_everything(args.seed)
+    args.device = torch.device('cuda', local) if dist is not None else torch.device('cuda')
+    if dist is not None:
+        logger.info('Data parallel over {} ranks ({})'.format(world, dist.get_backend()))
     logger.info('Running model on {}'.format(args.device))
     trainset, testset = load_data(args)
 
@@ -160,6 +205,14 @@ def main(argv=None):
 
     meters = {k: RunningAverage(10) for k in ('elbo', 'nll', 'reg_kl', 'inducing_kl')}
     optimizer = HipAdam(model.parameters(), lr=args.lr)
+    sync = None
+    if dist is not None:
+        from .parallel import GradAllReduce, shard_batch
+        sync = GradAllReduce(optimizer.flat_grads, dist, weight=1.0 / world)
+        gp_layer = model.flow.odefunc.diffeq
+        gp_layer.noise_source = BroadcastNoise(gp_layer.noise_source, dist)
+        torch.manual_seed(args.seed + 7919 * (rank + 1))     # encoder reparameterisation noise: independent per shard
+        torch.cuda.manual_seed(args.seed + 7919 * (rank + 1))
     kern = model.flow.odefunc.diffeq.kern
     graphs = {}     # --hip_graph: one captured step per (L, batch shape), replayed on a static input buffer
     if args.hip_graph:
@@ -178,7 +231,10 @@ def main(argv=None):
                 optimizer.zero_grad()
                 out = compute_loss(model, buf, L)
                 out[0].backward()
-                optimizer.step()
+                if sync is None:
+                    optimizer.step()
+                else:                                # the all-reduce and the Adam launch stay between the replays
+                    ops.join_side_stream()
                 return out
             buf.copy_(minibatch)
             gp = model.flow.odefunc.diffeq
@@ -195,36 +251,61 @@ def main(argv=None):
         L = 1 if ep < args.Nepoch // 2 else 5
         for itr, local_batch in enumerate(trainset):
             minibatch = _frames(local_batch).to(args.device)
+            if sync is not None and minibatch.shape[0] >= world:     # this rank's shard; its share weights the gradient mean
+                n_global = minibatch.shape[0]
+                minibatch = shard_batch(minibatch, rank, world)
+                sync.weight = minibatch.shape[0] / n_global
+            elif sync is not None:
+                sync.weight = 1.0 / world
             if args.hip_graph:
                 loss, nlhood, kl_reg, kl_u = graphed_step(minibatch, L)
             else:
                 loss, nlhood, kl_reg, kl_u = compute_loss(model, minibatch, L)
-            if torch.isnan(loss):
+            terms = torch.stack([t.detach().reshape(()) for t in (loss, nlhood, kl_reg, kl_u)])
+            if sync is not None:                     # the global-batch values: shard means weighted by shard size
+                terms = terms * sync.weight
+                dist.all_reduce(terms)
+            if torch.isnan(terms[0]):
                 logger.info('************** Obtained nan Loss at Epoch:{:4d}/{:4d}*************'.format(ep, args.Nepoch))
                 sys.exit()
             if not args.hip_graph:
                 optimizer.zero_grad()
                 loss.backward()
+            if sync is not None:
+                sync.all_reduce_grads()
+            if not args.hip_graph or sync is not None:
                 optimizer.step()
-            for k, v in zip(('elbo', 'nll', 'reg_kl', 'inducing_kl'), (loss, nlhood, kl_reg, kl_u)):
-                meters[k].update(v.item())
+            for k, v in zip(('elbo', 'nll', 'reg_kl', 'inducing_kl'), terms.tolist()):
+                meters[k].update(v)
             if itr % args.log_freq == 0:
                 logger.info('Iter:{:<2d} | Time {} | elbo {:8.2f}({:8.2f}) | nlhood:{:8.2f}({:8.2f}) | kl_reg:{:<8.2f}({:<8.2f}) | kl_u:{:8.5f}({:8.5f})'.format(
                     itr, timedelta(seconds=time.time() - begin), meters['elbo'].val, meters['elbo'].avg, meters['nll'].val, meters['nll'].avg,
                     meters['reg_kl'].val, meters['reg_kl'].avg, meters['inducing_kl'].val, meters['inducing_kl'].avg))
         with torch.no_grad():
-            for test_batch in testset:
+            for test_batch in testset:               # every rank evaluates (the GP draw is a collective); rank 0 keeps the file
                 test_batch = _frames(test_batch)
                 test_batch = test_batch.to(args.device)
                 Xrec, _, _ = model(test_batch)
                 test_mse = compute_test_error(test_batch, Xrec.squeeze(0))
-                torch.save(model.state_dict(), os.path.join(args.save, 'odegpvae_mnist.pth'))
+                if rank == 0:
+                    torch.save(model.state_dict(), os.path.join(args.save, 'odegpvae_mnist.pth'))
                 break
         logger.info('Epoch:{:4d}/{:4d}| tr_elbo:{:8.2f}({:8.2f}) | test_mse:{:5.3f}\n'.format(
             ep, args.Nepoch, meters['elbo'].val, meters['elbo'].avg, test_mse.item()))
     logger.info('********** Optimization completed **********')
+    if dist is not None:                             # the ranks must have taken identical steps
+        dev = torch.zeros((), device=args.device)
+        for p in model.parameters():
+            if p.requires_grad:
+                ref = p.detach().clone()
+                dist.broadcast(ref, src=0)
+                dev = torch.maximum(dev, (p.detach() - ref).abs().max())
+        dist.all_reduce(dev, op=dist.ReduceOp.MAX)
+        logger.info('Largest parameter deviation between ranks: {:.3e}'.format(dev.item()))
     logger.info('Kernel lengthscales {}'.format(kern.lengthscales.data))
     logger.info('Kernel variance {}'.format(kern.variance.data))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':
