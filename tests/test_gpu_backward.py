@@ -265,6 +265,7 @@ STREAM_CASES = [                                   # shapes past the register-re
     ('RBF', 6, 3, 2, 136, 64, 'euler'),
     ('RBF', 16, 16, 1, 40, 64, 'rk4'),
     ('RBF', 16, 8, 2, 40, 64, 'rk4'),
+    ('RBF', 8, 8, 1, 1056, 64, 'euler'),          # eight batched 1056-row factors on the big-factor (panelled / matrix-core) kernels
     ('DF', 16, 16, 1, 512, 256, 'rk4'),           # BASELINE configs[4] at full width: K_uu is 8192 x 8192 (oracle: ~30 s of CPU)
 ]
 

@@ -661,7 +661,7 @@ static void cholesky_blocked(float* A, float* Lmat, float* Dfac, int np, int nbl
   struct { int np, nblk, batch; } w{np, nblk, batch};
   const size_t bstride = (size_t)np * np, dstride = (size_t)nblk * NB * NB;
   constexpr int PB = ST / NB;                          // 32-blocks per 128-wide panel
-  if (w.np % ST == 0 && w.np >= 8 * ST) {
+  if (big_factor(w.np)) {
     // big factor (BASELINE configs[4]: 8192 x 8192): panels of 128 columns factored tile column by tile column, then ONE
     // matrix-core rank-128 update of everything to their right -- n^3/3 of the flops on MFMA, and a launch's redundant
     // panel factorisations confined to 4 tile columns instead of the whole trailing triangle
@@ -734,7 +734,7 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
 
   // nu = L^-T (u - L^-1 u_prior), written to ws, to the optional output and into the pack
   const int u_stride = kernel == 0 ? Do : 1, u_bstride = kernel == 0 ? 1 : 0;
-  if (w.np % ST == 0 && w.np >= 8 * ST) {
+  if (big_factor(w.np)) {
     const int npanel = cdiv(w.n, ST);
     for (int P = npanel - 1; P >= 0; --P)
       hipLaunchKernelGGL(k_solve_back_panel, dim3(P + 1, w.batch), 256, 0, st, Lmat, w.n, w.np, bstride, Dfac, dstride, ws + w.u,

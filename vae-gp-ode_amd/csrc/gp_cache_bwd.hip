@@ -796,7 +796,7 @@ int cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, const float* ws,
   hipLaunchKernelGGL(k_linv_init, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, b.np, bws + b.Dinv, dinv_stride, bws + b.Linv, bstride);
   for (int sb = 1; sb < b.nbn; sb *= 2) {            // T lives in the X buffer (written by k_gemm_phiX only afterwards)
     const int npairs = cdiv(b.nbn, 2 * sb);
-    if (sb >= GT / NB && b.np % GT == 0 && b.np >= 8 * GT) {   // super-blocks of whole 128-row tiles: matrix cores
+    if (sb >= GT / NB && big_factor(b.np)) {   // super-blocks of whole 128-row tiles: matrix cores
       const dim3 grid(sb / (GT / NB), sb / (GT / NB), npairs * b.batch);
       hipLaunchKernelGGL(k_linv_dc_mfma, grid, 256, 0, st, 0, sb, npairs, b.nbn, b.n, b.np, Lmat, bws + b.Linv, bws + b.X, bstride);
       hipLaunchKernelGGL(k_linv_dc_mfma, grid, 256, 0, st, 1, sb, npairs, b.nbn, b.n, b.np, Lmat, bws + b.Linv, bws + b.X, bstride);
@@ -839,7 +839,7 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
   if (rhs_vjp(kernel, Di, Do, M, S, pack, Z, bws + b.gp_rows, M, bws + b.vjpZ, 1, st)) return 1;
   if (param_grad(kernel, Di, Do, M, S, pack, Z, bws + b.gp_rows, M, bws + b.slab, b.nchunkZ, gpack, 1, 1, st)) return 1;
   // g_K = sym(L^-T Phi L^-1)
-  if (b.np % GT == 0 && b.np >= 8 * GT) {            // big factor: both products on the matrix cores
+  if (big_factor(b.np)) {            // big factor: both products on the matrix cores
     const int klim = b.nbn * NB, nt = cdiv(klim, GT);
     const dim3 grid(nt, nt, b.batch);                // column tile on the slow axis: the longest k ranges start first
     hipLaunchKernelGGL(k_gemm_mfma<1>, grid, 256, 0, st, bws + b.Linv, bws + b.Linv, bstride, b.np, klim, vec, bws + b.X);

@@ -1,5 +1,6 @@
 // gp_launch.hpp -- host-side helpers shared by the launchers (error slot, launch checks).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
@@ -108,5 +109,12 @@ int elbo_fwd(const float* lhood, int nl, const float* klrow, int nk, const float
 int elbo_bwd(const float* gout, int nl, int nk, float nobs, float* glhood, float* gklrow, float* gklu, hipStream_t st);
 int adam_multi(float* const* params, const float* const* grads, float* const* m1, float* const* m2, const long long* offs,
                int ntensors, long long total, float lr, float beta1, float beta2, float eps, int step, int* step_dev, hipStream_t st);
+
+// big factors (np a multiple of 128, >= 1024) take the panelled / matrix-core kernels; GPODE_SMALL_FACTOR_KERNELS=1 keeps the
+// 32-tile kernels for every size (an A/B switch for tests and profiling, same results up to summation order)
+inline bool big_factor(int np) {
+  static const bool off = [] { const char* e = getenv("GPODE_SMALL_FACTOR_KERNELS"); return e && e[0] == '1'; }();
+  return !off && np % 128 == 0 && np >= 1024;
+}
 
 }  // namespace gp
