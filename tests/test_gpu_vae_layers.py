@@ -45,7 +45,7 @@ def test_encoder_convs(B):
         check(lambda x, w, b: V.conv2d(x, w, b, 2, 2), lambda x, w, b: F.conv2d(x, w, b, stride=2, padding=2), (B, ci, h, h), (co, ci, 5, 5), (co,))
 
 
-@pytest.mark.parametrize('shape', [(4, 8, 14, 14), (40, 64, 6, 6), (130, 32, 13, 13), (65, 16, 28, 28)])
+@pytest.mark.parametrize('shape', [(4, 8, 14, 14), (40, 64, 6, 6), (130, 32, 13, 13), (65, 16, 28, 28), (70, 5, 7, 7), (9, 3, 1, 3)])
 def test_batchnorm_train_relu(shape):
     from vae_gp_ode_amd import vae_ops as V
     C = shape[1]
