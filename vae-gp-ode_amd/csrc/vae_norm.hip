@@ -19,7 +19,7 @@ namespace gp {
 
 namespace {
 
-// visit channel c of images [b0, b0 + nb): f4(16-byte aligned offset of 4 consecutive floats) and f1(offset of one float)
+// visit channel c of images [b0, b0 + nb): f4(offset of 4 consecutive floats) when HW % 4 == 0, else f1(offset)
 template <class F4, class F1>
 __device__ __forceinline__ void chan_slab(int C, int HW, int c, int b0, int nb, F4&& f4, F1&& f1) {
   if ((HW & 3) == 0) {
@@ -33,23 +33,14 @@ __device__ __forceinline__ void chan_slab(int C, int HW, int c, int b0, int nb, 
       if (p >= hw4) { p -= hw4; ++b; }
     }
   } else {
-    // planes of HW floats start at any 4-byte offset (13 x 13 = 169): per plane a scalar head up to the next 16-byte boundary,
-    // a float4 body and a scalar tail -- HW / 4 + 6 work slots per plane (vectors first, then the <= 5 scalars, the rest idle)
-    const int ipp = (HW >> 2) + 6, work = nb * ipp;
-    int q = threadIdx.x, b = q / ipp, sl = q - b * ipp;
-    const int sb = 256 / ipp, sp = 256 - sb * ipp;
-#pragma unroll 2
+    const int work = nb * HW;
+    int q = threadIdx.x, b = q / HW, p = q - b * HW;
+    const int sb = 256 / HW, sp = 256 - sb * HW;
+#pragma unroll 4
     for (; q < work; q += 256) {
-      const size_t base = ((size_t)(b0 + b) * C + c) * HW;
-      const int h0 = (4 - (int)(base & 3)) & 3, h = h0 < HW ? h0 : HW, nv = (HW - h) >> 2, t = (HW - h) & 3;
-      if (sl < nv) f4(base + h + 4 * sl);
-      else {
-        const int s = sl - nv;
-        if (s < h) f1(base + s);
-        else if (s - h < t) f1(base + h + 4 * nv + (s - h));
-      }
-      sl += sp; b += sb;
-      if (sl >= ipp) { sl -= ipp; ++b; }
+      f1(((size_t)(b0 + b) * C + c) * HW + p);
+      p += sp; b += sb;
+      if (p >= HW) { p -= HW; ++b; }
     }
   }
 }
@@ -297,7 +288,7 @@ size_t bn_scratch(int B, int C) { return (size_t)(B < 64 ? B : 64) * C * 4 + (si
 int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
            float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, int B, int C, int HW,
            int relu, float* scratch, hipStream_t st) {
-  if (!(aligned16(x) && aligned16(y))) return set_error("gpode_bn_fwd: x / y must be 16-byte aligned");
+  if ((HW & 3) == 0 && !(aligned16(x) && aligned16(y))) return set_error("gpode_bn_fwd: x / y must be 16-byte aligned");
   const Split sp = pick(B);
   float* shift = scratch + (size_t)sp.ns * C * 2 + (size_t)C * 2;
   hipLaunchKernelGGL(k_bn_stats, dim3(C, sp.used), 256, 0, st, x, B, C, HW, sp.bps, scratch, shift);
@@ -309,7 +300,7 @@ int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, floa
 int bn_stats(const float* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd, float* running_mean,
              float* running_var, long long* num_batches_tracked, float momentum, float eps, float* table, int B, int C, int HW,
              float* scratch, hipStream_t st) {
-  if (!aligned16(x)) return set_error("gpode_bn_stats: x must be 16-byte aligned");
+  if ((HW & 3) == 0 && !aligned16(x)) return set_error("gpode_bn_stats: x must be 16-byte aligned");
   const Split sp = pick(B);
   float* shift = scratch + (size_t)sp.ns * C * 2 + (size_t)C * 2;
   hipLaunchKernelGGL(k_bn_stats, dim3(C, sp.used), 256, 0, st, x, B, C, HW, sp.bps, scratch, shift);
@@ -322,7 +313,7 @@ int bn_stats(const float* x, const float* gamma, const float* beta, float* save_
 int bn_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
            const float* save_invstd, float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW, int relu,
            float* scratch, hipStream_t st) {
-  if (!(aligned16(x) && aligned16(gy) && aligned16(gx))) return set_error("gpode_bn_bwd: x / gy / gx must be 16-byte aligned");
+  if ((HW & 3) == 0 && !(aligned16(x) && aligned16(gy) && aligned16(gx))) return set_error("gpode_bn_bwd: x / gy / gx must be 16-byte aligned");
   const Split sp = pick(B);
   hipLaunchKernelGGL(k_bn_bwd_sums, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, save_mean, save_invstd, B, C, HW, sp.bps, relu, scratch);
   float* part_gx = gx_chansum ? scratch + (size_t)sp.ns * C * 2 + (size_t)C * 3 : nullptr;
@@ -335,7 +326,7 @@ int bn_bwd(const float* x, const float* gy, const float* gamma, const float* bet
 // gy == nullptr: forward (out = y); otherwise out = gx
 int bn_eval(const float* x, const float* gy, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
             float eps, float* out, int B, int C, int HW, int relu, hipStream_t st) {
-  if (!(aligned16(x) && aligned16(out) && (!gy || aligned16(gy)))) return set_error("gpode_bn_eval: tensors must be 16-byte aligned");
+  if ((HW & 3) == 0 && !(aligned16(x) && aligned16(out) && (!gy || aligned16(gy)))) return set_error("gpode_bn_eval: tensors must be 16-byte aligned");
   const Split sp = pick(B);
   hipLaunchKernelGGL(k_bn_eval, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, running_mean, running_var, eps, out, B, C, HW, sp.bps, relu);
   return check_launch("bn_eval");
@@ -343,7 +334,7 @@ int bn_eval(const float* x, const float* gy, const float* gamma, const float* be
 
 // out[c] = sum over (b, hw) of v[b,c,hw]   (bias gradient of ConvTranspose2d / Conv2d)
 int chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, hipStream_t st) {
-  if (!aligned16(v)) return set_error("gpode_chan_sum: v must be 16-byte aligned");
+  if ((HW & 3) == 0 && !aligned16(v)) return set_error("gpode_chan_sum: v must be 16-byte aligned");
   const Split sp = pick(B);
   hipLaunchKernelGGL(k_chan_sum, dim3(C, sp.used), 256, 0, st, v, B, C, HW, sp.bps, scratch);
   hipLaunchKernelGGL(k_reduce_chan, C, 64, 0, st, scratch, sp.used, C, out);
