@@ -231,7 +231,8 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
     # unbounded, so any learning rate that moves the decoder drives sigmoid outputs to exactly 1.0f within a few
     # thousand steps (lr 1e-4: non-finite loss before step 5000).  Adam moves a parameter by <= lr per step: 1e-6 keeps 1e5 steps
     # within 0.1 of the initial state.
-    opt = HipAdam(model.parameters(), lr=1e-6, bucketed=dist is not None)   # one GPU: no gradient bucket to all-reduce
+    # one GPU: no gradient bucket; N > 1: the bucket is filled in one launch from the produced gradients before the all-reduce
+    opt = HipAdam(model.parameters(), lr=1e-6, bucketed='gather' if dist is not None else False)
     sync = GradAllReduce(opt.flat_grads, dist) if dist is not None else None
     last = {}
 

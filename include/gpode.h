@@ -211,6 +211,11 @@ int gpode_elbo_bwd(const float* gout, int nl, int nk, float nobs, float* glhood,
 int gpode_adam_multi(void* params, void* grads, void* m1, void* m2, const long long* offs, int ntensors, long long total,
                      float lr, float beta1, float beta2, float eps, int step, int* step_dev, void* stream);
 
+/* The data-parallel gradient bucket in one launch: flat[offs[t] + i] = grads[t][i] (same DEVICE tables as gpode_adam_multi).
+ * What `loss.backward()` + DDP's bucket copy do in the reference's setting; the bucket is then all-reduced in place (RCCL)
+ * and handed to gpode_adam_multi through a pointer table into it. */
+int gpode_gather_multi(void* grads, const long long* offs, int ntensors, long long total, float* flat, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

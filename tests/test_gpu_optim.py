@@ -146,7 +146,8 @@ def test_graph_replay_equals_eager_steps():
     pe, be = run(False)
     try:
         # overlap: GP chains on the side stream; bucketed=False: gradients handed over by autograd, no flat bucket
-        for use_graph, overlap, bucketed in ((True, False, True), (False, True, True), (True, True, True), (False, False, False), (True, True, False)):
+        for use_graph, overlap, bucketed in ((True, False, True), (False, True, True), (True, True, True), (False, False, False), (True, True, False),
+                                              (False, False, 'gather'), (True, True, 'gather')):
             pg, bg = run(use_graph, overlap, bucketed)
             for a, b in zip(pe, pg):
                 assert torch.equal(a, b), (use_graph, overlap, bucketed)

@@ -66,6 +66,7 @@ SIGNATURES.update({
     'gpode_normal_kl_bwd': (_i, [_c_float_p, _c_float_p, _c_float_p, _i, _c_float_p, _c_float_p, _i, _i, _i, _vp]),
     'gpode_elbo_fwd': (_i, [_c_float_p, _i, _c_float_p, _i, _c_float_p, _f, _c_float_p, _vp]),
     'gpode_elbo_bwd': (_i, [_c_float_p, _i, _i, _f, _c_float_p, _c_float_p, _c_float_p, _vp]),
+    'gpode_gather_multi': (_i, [_vp, _vp, _i, ctypes.c_longlong, _c_float_p, _vp]),
     'gpode_adam_multi': (_i, [_vp, _vp, _vp, _vp, _vp, _i, ctypes.c_longlong, _f, _f, _f, _f, _i, _vp, _vp]),
     'gpode_loglik_rowsum_bwd': (_i, [_c_float_p] * 4 + [_sz, _sz, _sz, _vp]),
 })

@@ -238,6 +238,11 @@ int gpode_elbo_bwd(const float* gout, int nl, int nk, float nobs, float* glhood,
   if (!gout || !glhood || !gklrow || !gklu || nl < 1 || nk < 1) return gp::set_error("gpode_elbo_bwd: bad argument");
   return gp::elbo_bwd(gout, nl, nk, nobs, glhood, gklrow, gklu, GP_ST);
 }
+int gpode_gather_multi(void* grads, const long long* offs, int ntensors, long long total, float* flat, void* stream) {
+  if (!grads || !offs || !flat) return gp::set_error("gpode_gather_multi: null pointer");
+  return gp::gather_multi((const float* const*)grads, offs, ntensors, total, flat, (hipStream_t)stream);
+}
+
 int gpode_adam_multi(void* params, void* grads, void* m1, void* m2, const long long* offs, int ntensors, long long total,
                      float lr, float beta1, float beta2, float eps, int step, int* step_dev, void* stream) {
   if (!params || !grads || !m1 || !m2 || !offs) return gp::set_error("gpode_adam_multi: null pointer");

@@ -107,6 +107,7 @@ int normal_kl_fwd(const float* mu, const float* logvar, int ld, float* klrow, in
 int normal_kl_bwd(const float* grow, const float* mu, const float* logvar, int ld, float* gmu, float* glogvar, int ldg, int N, int q, hipStream_t st);
 int elbo_fwd(const float* lhood, int nl, const float* klrow, int nk, const float* kl_u, float nobs, float* out, hipStream_t st);
 int elbo_bwd(const float* gout, int nl, int nk, float nobs, float* glhood, float* gklrow, float* gklu, hipStream_t st);
+int gather_multi(const float* const* grads, const long long* offs, int ntensors, long long total, float* flat, hipStream_t st);
 int adam_multi(float* const* params, const float* const* grads, float* const* m1, float* const* m2, const long long* offs,
                int ntensors, long long total, float lr, float beta1, float beta2, float eps, int step, int* step_dev, hipStream_t st);
 

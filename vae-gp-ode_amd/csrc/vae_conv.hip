@@ -579,6 +579,22 @@ __global__ void k_adam_multi(float* const* __restrict__ params, const float* con
 
 __global__ void k_inc_step(int* step) { *step += 1; }
 
+// flat[offs[t] + i] = grads[t][i] for every tensor of the table: the data-parallel gradient bucket filled in ONE launch
+// from the tensors autograd handed over (instead of one accumulate kernel per parameter into persistent views)
+__global__ void k_gather_multi(const float* const* __restrict__ grads, const long long* __restrict__ offs, int ntensors,
+                               long long total, float* __restrict__ flat) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = ntensors - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (offs[mid] <= e) lo = mid; else hi = mid - 1; }
+    flat[e] = grads[lo][e - offs[lo]];
+  }
+}
+
+int gather_multi(const float* const* grads, const long long* offs, int ntensors, long long total, float* flat, hipStream_t st) {
+  hipLaunchKernelGGL(k_gather_multi, ew_grid((size_t)total), 256, 0, st, grads, offs, ntensors, total, flat);
+  return check_launch("gather_multi");
+}
+
 // step_dev != nullptr: *step_dev is incremented on the stream and used as the step count (host `step` ignored)
 int adam_multi(float* const* params, const float* const* grads, float* const* m1, float* const* m2, const long long* offs,
                int ntensors, long long total, float lr, float beta1, float beta2, float eps, int step, int* step_dev, hipStream_t st) {

@@ -204,7 +204,7 @@ def main(argv=None):
         logger.info('Resume training for model {}'.format(fname))
 
     meters = {k: RunningAverage(10) for k in ('elbo', 'nll', 'reg_kl', 'inducing_kl')}
-    optimizer = HipAdam(model.parameters(), lr=args.lr)
+    optimizer = HipAdam(model.parameters(), lr=args.lr, bucketed='gather' if dist is not None else True)
     sync = None
     if dist is not None:
         from .parallel import GradAllReduce, shard_batch

@@ -15,7 +15,9 @@ class HipAdam:
         """bucketed=True: every ``.grad`` is a persistent view into one flat buffer (what the data-parallel all-reduce
         needs); autograd then ADDS each produced gradient into it (one small kernel per parameter).  bucketed=False
         (single GPU): ``zero_grad`` drops the gradients, autograd hands over the tensors the backward kernels wrote,
-        and the update reads them through a pointer table -- no zero fill, no per-parameter add."""
+        and the update reads them through a pointer table -- no zero fill, no per-parameter add.
+        bucketed='gather' (data parallelism): gradients are handed over as with False; ``gather_grads()`` copies them into
+        the flat bucket in ONE launch (called by ``GradAllReduce`` before the collective) and the update reads the bucket."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params or not all(p.is_cuda and p.dtype == torch.float32 for p in self.params):
             raise _lib.GpodeError('HipAdam needs float32 CUDA/HIP parameters')
@@ -28,8 +30,12 @@ class HipAdam:
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         # persistent gradient storage: views into one flat bucket (all-reduced in place under data parallelism)
-        self.bucketed = bucketed
-        self.flat_grads = FlatGrads(self.params) if bucketed else None
+        self.gather = bucketed == 'gather'
+        self.bucketed = bool(bucketed) and not self.gather
+        self.flat_grads = FlatGrads(self.params, views=not self.gather) if bucketed else None
+        self._gathered = False
+        if self.gather:
+            self.flat_grads.gather = self.gather_grads
         self._zero = {}
         offs, tot = [], 0
         for p in self.params:
@@ -43,6 +49,9 @@ class HipAdam:
         self._g_host = torch.zeros(len(self.params), dtype=torch.int64).pin_memory()
         self._gptrs = None
         self._offs = torch.tensor(offs, dtype=torch.int64, device=dev)
+        if self.gather:                              # the update reads the (all-reduced) bucket: a static table of pointers into it
+            base = self.flat_grads.flat.data_ptr()
+            self._gflat = torch.tensor([base + 4 * o for o in offs], dtype=torch.int64, device=dev)
 
     def zero_grad(self):
         if not self.bucketed:
@@ -55,8 +64,7 @@ class HipAdam:
                 p.grad = fg.flat[o:o + p.numel()].view_as(p)
         fg.zero()
 
-    def step(self):
-        ops.join_side_stream()                       # overlap mode: deferred GP parameter gradients land in .grad here
+    def _refresh_grad_table(self):
         cur = []
         for i, p in enumerate(self.params):
             g = p.grad
@@ -71,8 +79,27 @@ class HipAdam:
             self._g_host.copy_(torch.tensor(cur, dtype=torch.int64))
             self._g.copy_(self._g_host, non_blocking=True)
             self._gptrs = cur
-        self.step_count += 1
+
+    def gather_grads(self):
+        """bucketed='gather': fill the flat bucket from the gradients autograd produced (one launch)."""
+        ops.join_side_stream()
+        self._refresh_grad_table()
         vp = lambda t: ctypes.c_void_p(t.data_ptr())
-        _lib.call('gpode_adam_multi', vp(self._p), vp(self._g), vp(self._m), vp(self._v), vp(self._offs), len(self.params),
+        _lib.call('gpode_gather_multi', vp(self._g), vp(self._offs), len(self.params), self.total, vp(self.flat_grads.flat), _stream())
+        self._gathered = True
+
+    def step(self):
+        ops.join_side_stream()                       # overlap mode: deferred GP parameter gradients land in .grad here
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())
+        if self.gather:
+            if not self._gathered:                   # no collective in between (single rank): the bucket is still to be filled
+                self.gather_grads()
+            self._gathered = False
+            gtab = self._gflat
+        else:
+            self._refresh_grad_table()
+            gtab = self._g
+        self.step_count += 1
+        _lib.call('gpode_adam_multi', vp(self._p), vp(gtab), vp(self._m), vp(self._v), vp(self._offs), len(self.params),
                   self.total, ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]),
                   ctypes.c_float(self.eps), self.step_count, vp(self.step_dev), _stream())

@@ -27,8 +27,10 @@ class FlatGrads:
     """One contiguous gradient buffer; every parameter's ``.grad`` is a view into it, so the bucket is
     all-reduced (and handed to the fused Adam) without gather/scatter copies."""
 
-    def __init__(self, params):
+    def __init__(self, params, views=True):
+        """views=False: only the bucket is allocated; ``gather`` (set by the optimiser) fills it from the produced gradients."""
         self.params = [p for p in params if p.requires_grad]
+        self.gather = None
         self.offsets, tot = [], 0
         for p in self.params:
             self.offsets.append(tot)
@@ -36,8 +38,9 @@ class FlatGrads:
         self.total = tot
         p0 = self.params[0]
         self.flat = torch.zeros(tot, dtype=p0.dtype, device=p0.device)
-        for p, o in zip(self.params, self.offsets):
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
+        if views:
+            for p, o in zip(self.params, self.offsets):
+                p.grad = self.flat[o:o + p.numel()].view_as(p)
 
     def zero(self):
         self.flat.zero_()
@@ -55,6 +58,8 @@ class GradAllReduce:
         if self.fg.flat.is_cuda:
             from . import ops
             ops.join_side_stream()                   # overlap mode: the GP parameter gradients must be in the bucket first
+        if self.fg.gather is not None:
+            self.fg.gather()                         # bucket filled in one launch from the tensors autograd handed over
         if self.avg:
             self.dist.all_reduce(self.fg.flat, op=self.dist.ReduceOp.AVG)
         else:
