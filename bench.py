@@ -168,6 +168,79 @@ def cpu_baseline_elbo(w, model, X, budget_s=15.0):
                 sample='%d full training steps (fwd + bwd + Adam, batch %d) of the torch-CPU oracle in %.1f s' % (n, N, el))
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one per GPU, rendezvous on
+    127.0.0.1), relay rank 0's JSON line, return the worst exit code.  Runs BEFORE anything touches the GPU in this process, and
+    the ranks are children -- a process that has initialised the GPU is never replaced."""
+    import signal
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=os.environ.get('MASTER_PORT') or str(_free_port()))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')    # dmabuf IPC: RCCL across processes needs it on this driver
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0 inherits stdout (its JSON line is the job's line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+    worst = 0
+    alive = set(range(n))
+    try:
+        while alive:
+            for r in sorted(alive):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                alive.discard(r)
+                if rc != 0:
+                    worst = worst or rc
+                    print('[bench] rank %d exited with code %d; stopping the other ranks' % (r, rc), file=sys.stderr, flush=True)
+                    for o in sorted(alive):              # exactly the PIDs started above
+                        procs[o].send_signal(signal.SIGTERM)
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return worst
+
+
+def run_dry(a, rank, world, dist):
+    """GPODE_BENCH_DRYRUN=1: the launcher / rendezvous / timing-protocol plumbing of the N > 1 path with an empty step, over
+    gloo on the CPU (tests/test_bench_launcher.py).  Not a measurement and labelled as such."""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+    for _ in range(a.warmup):
+        pass
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(1e-3)
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+    w = WORKLOADS[a.workload]
+    return {'metric': 'dry_run', 'value': w['batch'] * world * a.steps / el, 'unit': 'trajectories/s', 'n_gpus': world,
+            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': el / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'none (dry run of the launcher: empty step, gloo on the CPU)',
+            'config': {'workload': 'dry run', 'parallelism': 'dp%d' % world}, 'dry_run': True,
+            'dist_backend': dist.get_backend() if dist is not None else None,
+            'dist_ranks': dist.get_world_size() if dist is not None else 1}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -181,21 +254,49 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel of the step eagerly instead of replaying a captured HIP graph')
     a = ap.parse_args()
 
+    # --gpus N without a launcher (the driver's `python bench.py --gpus N`): this process only starts the N ranks.  Nothing
+    # above or inside spawn_ranks touches the GPU.
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (a.gpus, world))
+    if os.environ.get('GPODE_BENCH_DRYRUN') == '1':
+        if os.environ.get('GPODE_BENCH_DRYRUN_FAIL_RANK') == str(rank):     # tests: a rank that dies before the rendezvous
+            raise SystemExit(3)
+        dist = None
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group('gloo')
+        out = run_dry(a, rank, world, dist)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     # GPODE_BENCH_REHEARSE=1: all ranks share the visible card(s) and talk over gloo -- a rehearsal of the N > 1 code path
     # (sharded minibatch, gradient bucket, all-reduce between graph replays) on a one-GPU box; not a measurement
     rehearse = os.environ.get('GPODE_BENCH_REHEARSE') == '1'
+    ndev = torch.cuda.device_count()
     if rehearse:
-        local = local % torch.cuda.device_count()
+        local = local % ndev
+    elif local >= ndev:
+        raise SystemExit('bench.py: rank %d needs cuda:%d but only %d device(s) are visible (one process per GPU)' % (rank, local, ndev))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    # GPODE_BENCH_FORCE_DIST=1: take the distributed (RCCL) branch even with one rank -- proves the nccl code path on a one-GPU box
+    if world > 1 or os.environ.get('GPODE_BENCH_FORCE_DIST') == '1':
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', str(_free_port()))
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         if rehearse:
             dist.init_process_group('gloo')
         else:
@@ -213,8 +314,14 @@ def main():
         out = run_integrator(a, w, dev, rank, n_gpus, dist, barrier)
     else:
         out = run_elbo(a, w, dev, rank, n_gpus, dist, barrier)
+    if dist is not None:
+        out['dist_backend'] = dist.get_backend()
+        out['dist_ranks'] = dist.get_world_size()
+        out['rccl_ranks'] = dist.get_world_size() if dist.get_backend() == 'nccl' else 0
+    if out['n_gpus'] != a.gpus:
+        raise SystemExit('bench.py: measured on %d rank(s) but --gpus %d was asked for' % (out['n_gpus'], a.gpus))
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1,0 +1,195 @@
+"""GPU parity AT THE BASELINE.json BATCH SIZES.
+
+The matrix-core convolution kernels run a persistent grid of one workgroup per CU; with fewer image groups than CUs every
+workgroup executes its multi-group loop (register prefetch of the next group, tail group, weight-gradient slab loops) exactly
+once, which is all the small-batch tests of test_gpu_vae_layers.py reach.  BASELINE configs decode 512 (configs[0]), 4096
+(configs[1..3]) and 8192 (configs[4]) images per step: these tests run every decoder layer -- forward, d/d-input, d/d-weight,
+plain and with the fused BatchNorm+ReLU input -- at those image counts against torch's fp64 op, then one full ELBO training step
+(loss terms and EVERY parameter gradient) at configs[0] and configs[1] batch and the configs[4] forward at its real N=128, T=64
+against the pinned oracle in fp64.
+
+Tolerances are fixed numbers (relative to max|reference| of the tensor): outputs and input gradients 2e-5 (fp32 sums of <= 1600
+terms), weight / bias / BatchNorm-parameter gradients 1e-4 (fp32 sums over up to 8192 x 784 terms, tree-reduced)."""
+import types
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_forward import relerr
+
+pytestmark = pytest.mark.gpu
+
+# (name, input (C,H,W), weight shape, (stride, pad, out_pad))
+DECODER = [('decnn.1', (32, 4, 4), (32, 64, 3, 3), (1, 0, 0)), ('decnn.4', (64, 6, 6), (64, 32, 5, 5), (2, 1, 0)),
+           ('decnn.7', (32, 13, 13), (32, 16, 5, 5), (2, 1, 1)), ('decnn.10', (16, 28, 28), (16, 1, 5, 5), (1, 2, 0))]
+TOL_OUT, TOL_WGRAD = 2e-5, 1e-4
+
+
+def _ref_threads():
+    import os
+    try:
+        torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    except AttributeError:
+        pass
+
+
+@pytest.mark.parametrize('B', [512, 4096, 8192])
+@pytest.mark.parametrize('layer', DECODER, ids=[d[0] for d in DECODER])
+def test_decoder_layer_at_baseline_image_counts(B, layer):
+    """ConvTranspose2d forward, d/d-input, d/d-weight, d/d-bias vs torch fp64 at 512 / 4096 / 8192 images."""
+    from vae_gp_ode_amd import vae_ops as V
+    _ref_threads()
+    name, (C, H, _), wshape, (s, p, op) = layer
+    g = torch.Generator().manual_seed(B + C)
+    x, w, b = torch.randn(B, C, H, H, generator=g), torch.randn(wshape, generator=g) * 0.05, torch.randn(wshape[1], generator=g) * 0.1
+    a64 = [t.double().requires_grad_(True) for t in (x, w, b)]
+    y64 = F.conv_transpose2d(a64[0], a64[1], a64[2], stride=s, padding=p, output_padding=op)
+    gy = torch.randn(y64.shape, generator=g)
+    y64.backward(gy.double())
+    a = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    y = V.conv_transpose2d(a[0], a[1], a[2], s, p, op)
+    y.backward(gy.cuda())
+    errs = dict(y=relerr(y, y64), gx=relerr(a[0].grad, a64[0].grad), gw=relerr(a[1].grad, a64[1].grad), gb=relerr(a[2].grad, a64[2].grad))
+    print(name, B, {k: '%.1e' % v for k, v in errs.items()})
+    assert errs['y'] < TOL_OUT and errs['gx'] < TOL_OUT, errs
+    assert errs['gw'] < TOL_WGRAD and errs['gb'] < TOL_WGRAD, errs
+
+
+@pytest.mark.parametrize('B', [512, 4096, 8192])
+@pytest.mark.parametrize('layer', DECODER[1:], ids=[d[0] for d in DECODER[1:]])
+def test_fused_bn_relu_decoder_stage_at_baseline_image_counts(B, layer):
+    """One decoder stage ConvTranspose2d(ReLU(BatchNorm2d_train(c))) with the normalised activation never materialised
+    (`gpode_bn_stats` + `gpode_conv2d_bwd_data_bn` / `gpode_conv2d_bwd_weight_bn` + `gpode_bn_bwd`): output, running statistics
+    and the gradients of c, gamma, beta, weight and bias vs torch fp64."""
+    from vae_gp_ode_amd import vae_ops as V
+    _ref_threads()
+    name, (C, H, _), wshape, (s, p, op) = layer
+    g = torch.Generator().manual_seed(B + 7 * C)
+    c = torch.randn(B, C, H, H, generator=g) * 1.3 + 0.2
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    w, b = torch.randn(wshape, generator=g) * 0.05, torch.randn(wshape[1], generator=g) * 0.1
+    bn, ref = torch.nn.BatchNorm2d(C).cuda(), torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        bn.weight.copy_(gam); bn.bias.copy_(bet); ref.weight.copy_(gam); ref.bias.copy_(bet)
+    a64 = [t.double().requires_grad_(True) for t in (c, w, b)]
+    y64 = F.conv_transpose2d(F.relu(ref(a64[0])), a64[1], a64[2], stride=s, padding=p, output_padding=op)
+    gy = torch.randn(y64.shape, generator=g)
+    y64.backward(gy.double())
+    a = [t.cuda().requires_grad_(True) for t in (c, w, b)]
+    y = V.bn_relu_conv_transpose2d(a[0], bn, a[1], a[2], s, p, op)
+    y.backward(gy.cuda())
+    errs = dict(y=relerr(y, y64), gc=relerr(a[0].grad, a64[0].grad), gw=relerr(a[1].grad, a64[1].grad), gb=relerr(a[2].grad, a64[2].grad),
+                ggamma=relerr(bn.weight.grad, ref.weight.grad), gbeta=relerr(bn.bias.grad, ref.bias.grad),
+                rmean=relerr(bn.running_mean, ref.running_mean), rvar=relerr(bn.running_var, ref.running_var))
+    print(name, B, {k: '%.1e' % v for k, v in errs.items()})
+    assert errs['y'] < TOL_OUT and errs['gc'] < 5 * TOL_OUT, errs          # gc passes through the batch statistics
+    assert max(errs['gw'], errs['gb'], errs['ggamma'], errs['gbeta']) < TOL_WGRAD, errs
+    assert errs['rmean'] < 1e-5 and errs['rvar'] < 1e-5, errs
+
+
+CONFIGS = {
+    'configs[0]': dict(kernel='RBF', ode=1, q=6, M=100, S=256, T=16, N=32),
+    'configs[1]': dict(kernel='DF', ode=1, q=6, M=100, S=256, T=16, N=256),
+    'configs[2]': dict(kernel='RBF', ode=2, q=3, M=100, S=256, T=16, N=256),
+}
+
+
+def _model_and_draw(cfg, seed=121):
+    """build_model under seed_everything (the reference's construction order), README hyper-parameters, one explicit draw."""
+    from vae_gp_ode_amd.model.core.initialization import initialize_and_fix_kernel_parameters
+    from vae_gp_ode_amd.model.create_model import build_model
+    from vae_gp_ode_amd.model.misc.torch_utils import seed_everything
+    q, order, M, S = cfg['q'], cfg['ode'], cfg['M'], cfg['S']
+    Di = q * order
+    args = types.SimpleNamespace(D_in=Di, D_out=q, num_inducing=M, num_features=S, dimwise=True, q_diag=False, device='cuda',
+                                 kernel=cfg['kernel'], ode=order, solver='rk4', use_adjoint=False, frames=5, n_filt=8, latent_dim=q,
+                                 Ndata=360, dt=0.1)
+    seed_everything(seed)
+    m = build_model(args).cuda()
+    initialize_and_fix_kernel_parameters(m, 2.0, 1.0)
+    with torch.no_grad():      # as bench.py: keeps every sigmoid output off the fp32 saturation point at thousands of images
+        m.vae.decoder.decnn[10].weight.mul_(0.25)
+    g = torch.Generator().manual_seed(seed + 1)
+    N, T = cfg['N'], cfg['T']
+    X = torch.rand(N, T, 1, 28, 28, generator=g)
+    nz = dict(eps_u=torch.randn(M, q, generator=g), rff_w=torch.randn(S if cfg['kernel'] == 'RBF' else 2 * S, q, generator=g),
+              rff_eps=torch.randn(Di, S, q, generator=g), rff_u=torch.rand(1, S, q, generator=g))
+    eps_s = torch.randn(N, q, generator=g)
+    eps_v = torch.randn(N, q, generator=g) if order == 2 else None
+    return m, X, nz, eps_s, eps_v
+
+
+def _oracle_step(m, cfg, X, nz, eps_s, eps_v, dtype):
+    from oracle import gpode_oracle as O
+    sd = {k: (v.detach().cpu().to(dtype).clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k and '_num_evals' not in k
+              else v.detach().cpu().clone()) for k, v in m.state_dict().items()}
+    r = O.compute_loss(X.to(dtype), sd, [O.to_dtype(nz, dtype)], eps_s.to(dtype), eps_v.to(dtype) if eps_v is not None else None,
+                       kernel=cfg['kernel'], order=cfg['ode'], method='rk4', dt=0.1, Ndata=360)
+    r['loss'].backward()
+    return r, sd
+
+
+@pytest.mark.parametrize('name', list(CONFIGS))
+def test_full_elbo_step_at_config_batch(name):
+    """One training-path evaluation (encoder, GP draw, rk4 rollout, 512 / 4096 decoded images, ELBO, backward) at the BASELINE
+    batch vs the oracle: loss terms 2e-5 of the fp64 value; every parameter gradient within 2e-3 of the fp64 gradient
+    (relative to its max), and never further from fp64 than 4x the fp32 oracle (= the reference's own arithmetic) is."""
+    from vae_gp_ode_amd.model.create_model import compute_loss
+    _ref_threads()
+    cfg = CONFIGS[name]
+    m, X, nz, eps_s, eps_v = _model_and_draw(cfg)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    r64, sd64 = _oracle_step(m, cfg, X, nz, eps_s, eps_v, torch.float64)
+    r32, sd32 = _oracle_step(m, cfg, X, nz, eps_s, eps_v, torch.float32)
+    gp = m.flow.odefunc.diffeq
+    gp.set_noise({k: v.cuda() for k, v in nz.items()})
+    m.vae.encoder.next_eps = eps_s.cuda()
+    if eps_v is not None:
+        m.vae.encoder_v.next_eps = eps_v.cuda()
+    assert all(torch.equal(sd0[k], v) for k, v in m.state_dict().items() if 'running' not in k and 'num_batches' not in k)
+    out = compute_loss(m, X.cuda(), 1)
+    out[0].backward()
+    for got, key in zip(out, ('loss', 'nlhood', 'kl_reg', 'kl_u')):
+        e = abs(got.item() - r64[key].item()) / abs(r64[key].item())
+        assert e < 2e-5, (key, got.item(), r64[key].item())
+    dead_bias = ('cnn.0.bias', 'cnn.3.bias', 'decnn.1.bias', 'decnn.4.bias', 'decnn.7.bias')   # feed a BatchNorm: true gradient 0
+    worst, report = 0.0, {}
+    for k, p in m.named_parameters():
+        g64, g32 = sd64[k].grad, sd32[k].grad
+        if k.endswith(dead_bias):
+            wscale = sd64[k[:-4] + 'weight'].grad.abs().max().item()
+            assert p.grad.abs().max().item() <= 2e-3 * wscale + 1e-5, k
+            continue
+        e_hip, e_ref = relerr(p.grad, g64), relerr(g32, g64)
+        report[k.split('.', 2)[-1]] = (e_hip, e_ref)
+        worst = max(worst, e_hip)
+        assert e_hip < 2e-3, (k, e_hip, e_ref)
+        assert e_hip < max(4 * e_ref, 1e-4), (k, e_hip, e_ref)
+    print(name, 'worst gradient error vs fp64 %.1e;' % worst,
+          {k: '%.0e/%.0e' % v for k, v in report.items() if v[0] > 5e-5})
+
+
+def test_configs4_forward_at_its_real_size():
+    """configs[4]: DF kernel, q = 16, M = 512 (an 8192 x 8192 K_uu), T = 64, 128 trajectories per GPU, 8192 decoded images:
+    GP draw + rollout + decoder forward vs the fp64 oracle.  Trajectories 1e-3 of max (cond(K_uu) ~ 1e5 and 252 RHS evaluations
+    amplify the fp32 factorisation error; the fp32 oracle's own distance is printed), reconstructions 1e-3."""
+    from oracle import gpode_oracle as O
+    _ref_threads()
+    cfg = dict(kernel='DF', ode=1, q=16, M=512, S=256, T=64, N=128)
+    m, X, nz, eps_s, _ = _model_and_draw(cfg)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        Xrec64, zt64, _, _ = O.model_forward(X.double(), O.to_dtype(sd, torch.float64), [O.to_dtype(nz, torch.float64)], eps_s.double(), None,
+                                             kernel='DF', order=1, method='rk4', dt=0.1)
+        gp = m.flow.odefunc.diffeq
+        gp.set_noise({k: v.cuda() for k, v in nz.items()})
+        m.vae.encoder.next_eps = eps_s.cuda()
+        # the model's own forward, with the trajectories captured on the way to the decoder
+        z0, _, _ = m.encode_initial_state(X.cuda())
+        zt = m.sample_trajectories(z0, cfg['T'], 1)
+        Xrec = m.build_decoding(zt, (1, cfg['N'], cfg['T'], 1, 28, 28))
+    gp.cache.check_factorisation()
+    e_zt, e_x = relerr(zt, zt64), relerr(Xrec, Xrec64)
+    print('configs[4] N=128 T=64: trajectories %.1e, reconstructions %.1e from the fp64 oracle' % (e_zt, e_x))
+    assert e_zt < 1e-3 and e_x < 1e-3

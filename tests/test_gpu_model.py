@@ -120,3 +120,40 @@ def test_t_custom_extrapolation_prefix_property():
         b, _, _ = m(X, 1, T_custom=2 * T)
     assert tuple(a.shape) == (1, X.shape[0], T, 1, 28, 28) and tuple(b.shape) == (1, X.shape[0], 2 * T, 1, 28, 28)
     assert torch.equal(a, b[:, :, :T])
+
+
+@pytest.mark.parametrize('name,kw,L', [CASES[0], CASES[1], CASES[2]])
+def test_t_custom_rollout_matches_the_oracle(name, kw, L):
+    """ODEGPVAE.forward(X, L, T_custom=2T) in the reference's own mode (training-mode BatchNorm over all N x 2T decoded frames,
+    odegpvae.py:51-53 only changes the integration / decoding length) against the pinned oracle's model_forward(T_custom=...)
+    in fp64 on the fixture's state, draws and encoder noise."""
+    from oracle import gpode_oracle as O
+    m, g = make_model(name, kw, L)
+    a = dict(kernel='RBF', ode=1, solver='rk4'); a.update(kw)
+    T2 = 2 * g['X'].shape[1]
+    sd64 = O.to_dtype(sub(g, 'sd.'), torch.float64)
+    with torch.no_grad():
+        X64, zt64, _, _ = O.model_forward(g['X'].double(), sd64, [O.to_dtype(sub(g, 'noise%d.' % l), torch.float64) for l in range(L)],
+                                          g['eps_s'].double(), g['eps_v'].double() if 'eps_v' in g else None, kernel=a['kernel'],
+                                          order=a['ode'], method=a['solver'], dt=0.1, T_custom=T2)
+        X32, zt32, _, _ = O.model_forward(g['X'], sub(g, 'sd.'), [sub(g, 'noise%d.' % l) for l in range(L)],
+                                          g['eps_s'], g['eps_v'] if 'eps_v' in g else None, kernel=a['kernel'],
+                                          order=a['ode'], method=a['solver'], dt=0.1, T_custom=T2)
+        Xrec, _, _ = m(g['X'].cuda(), L, T_custom=T2)
+    assert tuple(Xrec.shape) == (L, g['X'].shape[0], T2, 1, 28, 28)
+    e, e32 = relerr(Xrec, X64), relerr(X32, X64)
+    print(name, 'T_custom=%d: reconstructions %.1e from fp64 (fp32 oracle: %.1e)' % (T2, e, e32))
+    assert e < 2e-4 + 3 * e32
+
+
+def test_df_kernel_matrix_matches_reference():
+    """`gpode_kernel_matrix(kernel=DF)` (DivergenceFreeKernel.K, kernels.py:289-303) through the public kern.K API against the
+    fixture's K(Z) (96 x 96, before the jitter) and K(Z, x) (96 x 24, the asymmetric DF block layout of SURVEY F7/F8)."""
+    from test_gpu_backward import make_layer
+    for name in ('gp_df1_tiny', 'gp_df1_tiny_q4', 'gp_df1_cfg2'):
+        g = load_golden(name)
+        flow, gp = make_layer(g, 'DF', 1, 'rk4')
+        Z = gp.inducing_loc.optvar.detach()
+        Ku, Kzx = gp.kern.K(Z), gp.kern.K(Z, g['x'].cuda())
+        assert tuple(Ku.shape) == tuple(g['Ku'].shape) and tuple(Kzx.shape) == tuple(g['Kzx'].shape)
+        assert relerr(Ku, g['Ku']) < 1e-5 and relerr(Kzx, g['Kzx']) < 1e-5, name

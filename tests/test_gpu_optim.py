@@ -229,6 +229,65 @@ def test_main_trains_data_parallel_on_two_ranks(tmp_path, graph):
     assert len(ck) == 1 and all(torch.isfinite(v).all() for v in torch.load(ck[0]).values() if v.is_floating_point())
 
 
+def _run_dp(tmp_path, tag, port, extra, nepoch=4):
+    import glob
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPODE_DIST_BACKEND='gloo', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), '-m', 'vae_gp_ode_amd.main', '--task', 'synthetic', '--Ndata', '10', '--Ntest', '4',
+           '--batch', '4', '--T', '6', '--solver', 'rk4', '--num_inducing', '16', '--num_features', '32', '--lr', '1e-3',
+           '--log_freq', '1', '--Nepoch', str(nepoch), '--save', 'results/' + tag] + extra
+    r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ck = glob.glob(str(tmp_path / 'results' / (tag + '_*') / 'odegpvae_mnist.pth'))
+    assert len(ck) == 1
+    return torch.load(ck[0], map_location='cpu')
+
+
+def test_graph_replayed_data_parallel_run_equals_the_eager_one(tmp_path):
+    """Two ranks, four epochs over 10 sequences in batches of 4 (ragged last batch; L switches from 1 to 5 after epoch 2): every
+    graph key is captured once and REVISITED in later epochs.  The gradient gather / all-reduce / Adam run between the replays
+    and read ``p.grad``: a replay must leave ``p.grad`` bound to the tensors that replay wrote (each captured graph has its own),
+    and the step that doubles as a capture warm-up must hand over the gradients it really computed.  Same device-side noise on
+    both runs, so the parameters after the last epoch must agree."""
+    a = _run_dp(tmp_path, 'eager', 29551, ['--device_noise', 'True'])
+    b = _run_dp(tmp_path, 'graph', 29552, ['--hip_graph', 'True'])
+    worst = 0.0
+    for k, v in a.items():
+        if not v.is_floating_point() or k.endswith('_num_evals'):
+            continue
+        err = relerr(b[k], v)
+        worst = max(worst, err)
+        assert err < 1e-5, (k, err)
+    print('graph-replayed vs eager data-parallel run, worst relative parameter difference: %.2e' % worst)
+
+
+def test_nan_guard_reloads_the_last_checkpoint(tmp_path, monkeypatch, caplog):
+    """main.py:205-207 -> cache_results (main.py:116-129): on a NaN loss the reference reloads the last per-epoch checkpoint,
+    logs its kernel hyper-parameters and exits."""
+    import logging
+    from vae_gp_ode_amd import main as M
+    from vae_gp_ode_amd.model import create_model as CM
+    monkeypatch.chdir(tmp_path)
+    real, calls = CM.compute_loss, {'n': 0}
+
+    def poisoned(model, data, L):
+        calls['n'] += 1
+        out = real(model, data, L)
+        return (out[0] * float('nan'),) + tuple(out[1:]) if calls['n'] > 3 else out
+    monkeypatch.setattr(CM, 'compute_loss', poisoned)
+    logging.getLogger('gpode').propagate = True
+    with caplog.at_level(logging.INFO, logger='gpode'), pytest.raises(SystemExit):
+        M.main(['--task', 'synthetic', '--Ndata', '8', '--Ntest', '4', '--batch', '4', '--T', '6', '--solver', 'rk4', '--num_inducing', '16',
+                '--num_features', '32', '--lr', '1e-4', '--log_freq', '1', '--Nepoch', '3', '--save', 'results/n'])
+    text = caplog.text
+    assert 'Obtained nan Loss at Epoch:   1/   3' in text and 'Laoding previous model for plotting' in text
+    assert 'Kernel lengthscales' in text and 'Kernel variance' in text
+
+
 def test_training_trajectory_matches_the_oracle_over_several_steps():
     """Four full training steps (encoder, GP draw, rollout, decoder, ELBO, backward, Adam) from the reference's own initial
     state (fixture model_df1_tiny) with identical noise fed to both sides: the loss sequence and the parameters after the last

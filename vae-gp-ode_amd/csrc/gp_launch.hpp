@@ -41,6 +41,18 @@ inline int set_max_lds(const void* kern, size_t bytes) {
   return 0;
 }
 
+// Compute units of the current device: the persistent kernels launch one (or two) workgroup(s) per CU.  Queried once (the first
+// eager run of a step, never inside a capture); clamped to 256 because the split-sum scratch buffers are sized for that.
+inline int num_cus() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      return 256;
+    return v < 256 ? v : 256;
+  }();
+  return n;
+}
+
 // entry points implemented across the .hip files
 int dims_supported(int kernel, int Di, int Do);
 int rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, int N, float* f, int mode, hipStream_t st);

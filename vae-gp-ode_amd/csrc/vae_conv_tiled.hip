@@ -398,7 +398,7 @@ static int launch_igemm(const float* x, const float* w, const float* bias, float
   auto km = k_conv_igemm<PL, IPB, TG, NCJ, PAIR, NTHR>;
   if (set_max_lds((const void*)km, lds)) return 1;
   const int ngroups = (B + IPB - 1) / IPB;
-  const int cap = 256 * (512 / NTHR);
+  const int cap = num_cus() * (512 / NTHR);
   hipLaunchKernelGGL(km, ngroups < cap ? ngroups : cap, NTHR, lds, st, x, w, bias, y, B, in_bn);
   return check_launch(what);
 }
@@ -444,7 +444,7 @@ static int launch_wgrad_mfma(const float* x, const float* gy, float* gw, float* 
   auto kb = k_convT_wgrad_mfma<L, IPBM, WM, WN, WT, PIPE, true, NTHR>;
   if (set_max_lds((const void*)km, ldsm) || set_max_lds((const void*)kb, ldsm)) return 1;
   const int ngroups = (B + IPBM - 1) / IPBM;
-  const int cap = 256 * (512 / NTHR);
+  const int cap = num_cus() * (512 / NTHR);
   const int nwg = ngroups < cap ? ngroups : cap;
   if (in_bn) hipLaunchKernelGGL(kb, nwg, NTHR, ldsm, st, x, gy, scratch, B, in_bn);
   else hipLaunchKernelGGL(km, nwg, NTHR, ldsm, st, x, gy, scratch, B, in_bn);
@@ -489,8 +489,8 @@ int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx
     if (use_mfma()) {
       const size_t ldsm = sizeof(float) * dec10::KK * dec10::PST;
       if (set_max_lds((const void*)dec10::k_fwd<true>, ldsm) || set_max_lds((const void*)dec10::k_fwd<false>, ldsm)) return 1;
-      if (in_bn) hipLaunchKernelGGL(dec10::k_fwd<true>, B < 256 ? B : 256, 512, ldsm, st, gy, w, bias, gx, B, in_bn);
-      else hipLaunchKernelGGL(dec10::k_fwd<false>, B < 256 ? B : 256, 512, ldsm, st, gy, w, bias, gx, B, in_bn);
+      if (in_bn) hipLaunchKernelGGL(dec10::k_fwd<true>, B < num_cus() ? B : num_cus(), 512, ldsm, st, gy, w, bias, gx, B, in_bn);
+      else hipLaunchKernelGGL(dec10::k_fwd<false>, B < num_cus() ? B : num_cus(), 512, ldsm, st, gy, w, bias, gx, B, in_bn);
       return check_launch("dec10_fwd_mfma");
     }
     constexpr int IPB = 2;
@@ -521,7 +521,7 @@ int tiled_fwd(const float* x, const float* w, const float* bias, float* y, int B
       constexpr int IPB = 8;
       const size_t ldsm = sizeof(float) * IPB * dec10::PLANE;
       const int ngroups = (B + IPB - 1) / IPB;
-      hipLaunchKernelGGL(dec10::k_bwd_data<IPB>, ngroups < 256 ? ngroups : 256, 512, ldsm, st, x, w, y, B);
+      hipLaunchKernelGGL(dec10::k_bwd_data<IPB>, ngroups < num_cus() ? ngroups : num_cus(), 512, ldsm, st, x, w, y, B);
       return check_launch("dec10_bwd_data_mfma");
     }
     return launch_T2<Dec10, 1, 1, 0, 16, 1, 1>(x, w, y, B, st);
@@ -543,7 +543,7 @@ int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch,
     constexpr int IPB = 1;
     const size_t fl = (size_t)IPB * dec10::PLANE > 8 * 16 * 32 ? (size_t)IPB * dec10::PLANE : 8 * 16 * 32;
     const int ngroups = (B + IPB - 1) / IPB;
-    const int nwg = ngroups < 256 ? ngroups : 256;
+    const int nwg = ngroups < num_cus() ? ngroups : num_cus();
     hipLaunchKernelGGL(dec10::k_wgrad<IPB>, nwg, 512, sizeof(float) * fl, st, gy, x, scratch, B, in_bn);
     hipLaunchKernelGGL(k_sum_splits4, (400 + 63) / 64, 1024, 0, st, scratch, nwg, (size_t)400, gw);
     return check_launch("dec10_wgrad_mfma");

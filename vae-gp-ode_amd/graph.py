@@ -22,8 +22,13 @@ def _detached(out):
 
 
 class GraphedStep:
-    def __init__(self, step_fn, generators=(), warmup=3):
-        """step_fn() -> tensor or tuple of tensors (static outputs, overwritten by every replay)."""
+    def __init__(self, step_fn, generators=(), warmup=3, grad_params=None):
+        """step_fn() -> tensor or tuple of tensors (static outputs, overwritten by every replay).
+        grad_params: parameters whose ``.grad`` the step (re)binds and a consumer OUTSIDE the graph reads (the data-parallel
+        gradient gather / all-reduce between replays).  Capturing rebinds ``p.grad`` to tensors of this graph's pool that only a
+        replay fills, and every graph has its own: ``warm_grads`` are the gradients the last eager warm-up step really computed,
+        ``grads`` the capture-time tensors; ``__call__`` rebinds ``p.grad`` to them after every replay, ``bind_warm_grads()``
+        to the former for the one step the warm-up itself stands for."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         self.warm_out = None
@@ -32,6 +37,8 @@ class GraphedStep:
                 self.warm_out = _detached(step_fn())   # these are real steps; the last one's outputs stay readable here
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self.grad_params = list(grad_params) if grad_params is not None else None
+        self.warm_grads = [p.grad for p in self.grad_params] if self.grad_params is not None else None
         self.graph = torch.cuda.CUDAGraph()
         for g in generators:
             if g is not None:
@@ -40,10 +47,22 @@ class GraphedStep:
         # runtime while this thread captures
         with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.out = _detached(step_fn())
+        self.grads = [p.grad for p in self.grad_params] if self.grad_params is not None else None
         self.eager_steps = warmup
+
+    def _bind(self, grads):
+        for p, g in zip(self.grad_params, grads):
+            p.grad = g
+
+    def bind_warm_grads(self):
+        """``p.grad`` := what the last warm-up step computed (valid once: the tensors are released afterwards)."""
+        self._bind(self.warm_grads)
+        self.warm_grads = None
 
     def __call__(self):
         self.graph.replay()
+        if self.grads is not None:
+            self._bind(self.grads)
         return self.out
 
 

@@ -58,6 +58,9 @@ FLAGS = [
 EXT_FLAGS = [
     ('hip_graph', eval, False, 'replay each training step as one captured HIP graph, GP chains on a side stream, GP noise drawn '
                                'on the device (INTEGRATION.md); the reference draws GP noise from host numpy generators'),
+    ('device_noise', eval, False, 'draw the GP noise on the device (seeded identically on every rank) without --hip_graph'),
+    ('sync_bn', eval, True, 'data parallel: BatchNorm normalises with the statistics of the GLOBAL minibatch (all ranks), as the '
+                            'single-process reference does (vae.py:55,58,113,116,119)'),
 ]
 CHOICES = {'kernel': KERNELS, 'solver': SOLVERS}  # default 'euler' is accepted only as a default, as in the reference
 
@@ -160,6 +163,26 @@ class BroadcastNoise:
         return broadcast_noise(self.inner.draw(*a, **k), self.dist)
 
 
+def cache_results(logger, args, ep, build_model):
+    """What the reference does when the loss turns NaN (main.py:116-129, called from :205-207) minus the plots: say so, rebuild
+    the model, reload the last per-epoch checkpoint in evaluation mode and log its kernel hyper-parameters; returns that model
+    (None when no epoch has completed yet -- the reference's torch.load would raise there).  The caller then exits."""
+    logger.info('************** Obtained nan Loss at Epoch:{:4d}/{:4d}*************'.format(ep, args.Nepoch))
+    logger.info('Laoding previous model for plotting')
+    fname = os.path.join(args.save, 'odegpvae_mnist.pth')
+    if not os.path.exists(fname):
+        logger.info('No checkpoint at {} yet (NaN before the first epoch completed)'.format(fname))
+        return None
+    model = build_model(args)
+    model.to(args.device)
+    model.load_state_dict(torch.load(fname, map_location=torch.device(args.device)))
+    model.eval()
+    kern = model.flow.odefunc.diffeq.kern
+    logger.info('Kernel lengthscales {}'.format(kern.lengthscales.data))
+    logger.info('Kernel variance {}'.format(kern.variance.data))
+    return model
+
+
 def main(argv=None):
     args = make_parser().parse_args(argv)
     from .model.core.initialization import initialize_and_fix_kernel_parameters
@@ -221,6 +244,9 @@ def main(argv=None):
         from .model.core.noise import DeviceNoise
         model.flow.odefunc.diffeq.noise_source = DeviceNoise(args.seed + 1)
         ops.set_overlap(True)
+    elif args.device_noise:
+        from .model.core.noise import DeviceNoise
+        model.flow.odefunc.diffeq.noise_source = DeviceNoise(args.seed + 1)
 
     def graphed_step(minibatch, L):
         key = (L, tuple(minibatch.shape))
@@ -239,8 +265,12 @@ def main(argv=None):
             buf.copy_(minibatch)
             gp = model.flow.odefunc.diffeq
             gp.noise_source.draw(gp.kernel_n, gp.D_in, gp.D_out, gp.M, gp.S, minibatch.device)   # creates the generator
-            graphs[key] = (buf, GraphedStep(step, generators=device_generators(model), warmup=1))
-            return graphs[key][1].warm_out           # the capture warm-up already took this minibatch's (eager) step
+            gs = GraphedStep(step, generators=device_generators(model), warmup=1,
+                             grad_params=optimizer.params if sync is not None else None)
+            graphs[key] = (buf, gs)
+            if sync is not None:                     # the gradients the gather / all-reduce below must see are the warm-up's
+                gs.bind_warm_grads()
+            return gs.warm_out                       # the capture warm-up already took this minibatch's (eager) step
         buf, g = graphs[key]
         buf.copy_(minibatch, non_blocking=True)
         return g()
@@ -266,7 +296,9 @@ def main(argv=None):
                 terms = terms * sync.weight
                 dist.all_reduce(terms)
             if torch.isnan(terms[0]):
-                logger.info('************** Obtained nan Loss at Epoch:{:4d}/{:4d}*************'.format(ep, args.Nepoch))
+                cache_results(logger, args, ep, build_model)
+                if dist is not None:
+                    dist.destroy_process_group()
                 sys.exit()
             if not args.hip_graph:
                 optimizer.zero_grad()

@@ -76,32 +76,43 @@ class SVGP_Layer(torch.nn.Module):
         self.build_cache()
         return self.cache.u
 
-    def build_cache(self, noise=None, want_Lu=False):
-        """Fix one function draw: Fourier features, inducing sample, nu (svpy.py:103-121)."""
+    def _cache_inputs(self, noise=None):
+        """Everything the cache-build kernels read, produced by torch on the CURRENT stream: the draw, and the derived tensors
+        of the operator variants (q_diag: softplus scale scattered onto the packed diagonal; dimwise=False: shared
+        hyper-parameters / frequencies repeated per output).  Returned tensors are kept referenced by the cache."""
         if noise is not None:
             self._next_noise.insert(0, noise)
         nz = self._take_noise()
-        k = self.kern
         if nz['rff_eps'].dim() == 2:   # dimwise=False draws one frequency / phase set (kernels.py:118-124,131-132): repeat it per output
             nz = dict(nz, rff_eps=nz['rff_eps'].unsqueeze(-1).expand(-1, -1, self.D_out).contiguous(),
                       rff_u=nz['rff_u'].unsqueeze(-1).expand(-1, -1, self.D_out).contiguous())
-        raw_ell, raw_var = k.raw_dimwise()
-        self.cache = ops.cache_build(self.kernel_n, raw_ell.detach(), raw_var.detach(),
-                                     self.inducing_loc.optvar.detach(), self.Um.optvar.detach(), self.us_packed().detach(),
-                                     nz['eps_u'], nz['rff_w'], nz['rff_eps'], nz['rff_u'], want_Lu=want_Lu)
+        raw_ell, raw_var = self.kern.raw_dimwise()
+        return nz, (raw_ell.detach(), raw_var.detach(), self.inducing_loc.optvar.detach(), self.Um.optvar.detach(),
+                    self.us_packed().detach())
+
+    def _launch_cache_build(self, nz, params, want_Lu=False):
+        self.cache = ops.cache_build(self.kernel_n, *params, nz['eps_u'], nz['rff_w'], nz['rff_eps'], nz['rff_u'], want_Lu=want_Lu)
         self.cache.noise = nz
-        k._set_cache(self.cache, nz)
+        self.cache.inputs = params      # alive for as long as a (side-stream) kernel may read them
+        self.kern._set_cache(self.cache, nz)
         return self.cache
+
+    def build_cache(self, noise=None, want_Lu=False):
+        """Fix one function draw: Fourier features, inducing sample, nu (svpy.py:103-121)."""
+        nz, params = self._cache_inputs(noise)
+        return self._launch_cache_build(nz, params, want_Lu)
 
     def prebuild_cache(self):
         """Overlap mode (ops.set_overlap): draw the noise now and build the cache on the side stream, so that the
         Cholesky chain runs next to the encoder; Flow.forward picks it up with take_prebuilt_cache()."""
         if not ops.overlap_enabled():
             return
-        nz = self._take_noise()                     # drawn (and allocated) on the current stream
+        # every tensor the side-stream kernels read is produced on the current stream BEFORE the fork (the side stream then
+        # waits for it) and stays referenced by the cache until the step's join
+        nz, params = self._cache_inputs()
         side = ops.fork_side_stream()
         with ops.launch_on(side):
-            self._prebuilt = self.build_cache(noise=nz)
+            self._prebuilt = self._launch_cache_build(nz, params)
 
     def take_prebuilt_cache(self):
         cache = getattr(self, '_prebuilt', None)

@@ -106,7 +106,7 @@ class GPCache:
     """Per-draw cache: the lane-major ``pack`` the kernels consume, plus the attributes the reference
     caches on ``kern`` (kernels.py:134-137,172)."""
     __slots__ = ('kernel', 'Di', 'Do', 'M', 'S', 'pack', 'ws', 'ell', 'var', 'omega', 'phase', 'u', 'Lu', 'nu',
-                 'u_prior', 'noise')
+                 'u_prior', 'noise', 'inputs')
 
     def check_factorisation(self):
         """Raise like torch.linalg.cholesky does when K_uu + jitter*I is not positive definite
@@ -202,8 +202,10 @@ def rhs_vjp(cache, x, a):
     return gx
 
 
-def param_grad(cache, x, a, gpack=None, nchunk=256):
-    """Gradient of sum_r <a_r, f(x_r)> w.r.t. every field of the pack, in pack layout."""
+def param_grad(cache, x, a, gpack=None, nchunk=256, keep=None):
+    """Gradient of sum_r <a_r, f(x_r)> w.r.t. every field of the pack, in pack layout.
+    ``keep`` (a list): the chunk scratch is appended to it -- a caller that launches on a side stream must hold it until that
+    stream has been joined (the caching allocator only knows the stream the block was allocated on)."""
     x = _chk(x, 'x'); a = _chk(a, 'a')
     R = x.shape[0]
     nchunk = max(1, min(nchunk, R))
@@ -214,6 +216,8 @@ def param_grad(cache, x, a, gpack=None, nchunk=256):
         gpack = torch.zeros(pf, dtype=torch.float32, device=x.device)
     _lib.call('gpode_param_grad', KERNEL_ID[cache.kernel], cache.Di, cache.Do, cache.M, cache.S, _ptr(cache.pack),
               _ptr(x), _ptr(a), R, _ptr(slab), nchunk, _ptr(gpack), acc, _stream())
+    if keep is not None:
+        keep.append(slab)
     return gpack
 
 
@@ -310,11 +314,15 @@ class _Flow(torch.autograd.Function):
         if _overlap['on'] and leaves:
             # parameter gradients on the side stream, next to the encoder's backward; join_side_stream() adds them
             side = fork_side_stream()
+            scratch = []
             with launch_on(side):
-                gpack = param_grad(c, xs.reshape(-1, c.Di), ast.reshape(-1, c.Do))
+                gpack = param_grad(c, xs.reshape(-1, c.Di), ast.reshape(-1, c.Do), keep=scratch)
                 g = cache_build_bwd(c, raw_ell, raw_var, Z, gpack, prepared=ctx.prepared)
             grads = [g['raw_ell'], g['raw_var'], g['Z'], g['Um'], g['Us']]
-            _overlap['pending'].append((ctx.params, [gg.view_as(p) for gg, p in zip(grads, ctx.params)], (g, gpack, xs, ast, c)))
+            # every buffer a side-stream kernel touches stays referenced until join_side_stream(): the allocator would
+            # otherwise hand the block to the encoder-backward kernels the main stream launches meanwhile
+            _overlap['pending'].append((ctx.params, [gg.view_as(p) for gg, p in zip(grads, ctx.params)],
+                                        (g, gpack, xs, ast, c, scratch, raw_ell, raw_var, Z, ctx.prepared)))
             return (gz0,) + (None,) * 9
         if ctx.prepared is not None:
             torch.cuda.current_stream().wait_stream(side_stream())
