@@ -251,6 +251,9 @@ def main():
     ap.add_argument('--seed', type=int, default=121)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-overlap', action='store_true', help='keep the GP cache build / cache backward on the main stream')
+    ap.add_argument('--no-sync-bn', action='store_true', help='N > 1: BatchNorm with per-rank statistics instead of the global minibatch')
+    ap.add_argument('--dp-graph', default='whole', choices=['whole', 'fwdbwd', 'off'],
+                    help='N > 1 over RCCL: what one HIP graph holds (whole step incl. collectives / forward+backward / nothing)')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel of the step eagerly instead of replaying a captured HIP graph')
     a = ap.parse_args()
 
@@ -258,6 +261,11 @@ def main():
     # above or inside spawn_ranks touches the GPU.
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:]))
+    # the job's stdout carries ONE JSON line: keep a private handle to it and point fd 1 at stderr, so that whatever the
+    # communication libraries print on stdout (gloo's "[Gloo] Rank 0 is connected ...") cannot end up in front of that line
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -272,7 +280,7 @@ def main():
             dist.init_process_group('gloo')
         out = run_dry(a, rank, world, dist)
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            print(json.dumps(out), file=json_out, flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -321,7 +329,7 @@ def main():
     if out['n_gpus'] != a.gpus:
         raise SystemExit('bench.py: measured on %d rank(s) but --gpus %d was asked for' % (out['n_gpus'], a.gpus))
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -341,6 +349,12 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
     # one GPU: no gradient bucket; N > 1: the bucket is filled in one launch from the produced gradients before the all-reduce
     opt = HipAdam(model.parameters(), lr=1e-6, bucketed='gather' if dist is not None else False)
     sync = GradAllReduce(opt.flat_grads, dist) if dist is not None else None
+    bn_sync = None
+    if dist is not None and not a.no_sync_bn:          # BatchNorm over the GLOBAL minibatch, as the single-process reference
+        from vae_gp_ode_amd import vae_ops
+        from vae_gp_ode_amd.parallel import BatchNormSync
+        bn_sync = BatchNormSync(dist)
+        vae_ops.set_bn_sync(bn_sync)
     last = {}
 
     from vae_gp_ode_amd import ops
@@ -364,19 +378,40 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
         opt.step()
         return loss
 
-    # One HIP graph per step instead of ~250 launches (vae_gp_ode_amd/graph.py).  N = 1: the whole step; N > 1: forward +
-    # backward are replayed, the gradient all-reduce (RCCL) and the Adam launch stay eager between replays.
-    step, graphed = eager_step, False
+    def dp_step():
+        loss = fwd_bwd()
+        sync.all_reduce_grads()
+        opt.step()
+        return loss
+
+    # One HIP graph per step instead of ~250 launches (vae_gp_ode_amd/graph.py).
+    #   N = 1: the whole step.
+    #   N > 1 over RCCL: the whole step as well -- the BatchNorm statistics all-gathers, the gradient all-reduce and the Adam
+    #     launch are stream operations on the captured stream and become nodes of the same graph (--dp-graph fwdbwd keeps the
+    #     gradient all-reduce and Adam eager between replays; off launches everything eagerly).
+    #   N > 1 over gloo (rehearsal on one card): gloo's collectives are host code and cannot be captured -- forward + backward
+    #     are replayed when they hold no collective (--no-sync-bn), otherwise the step runs eagerly.
+    step, graphed, mode = eager_step, False, 'eager'
     if not a.no_graph:
+        if sync is None:
+            mode = 'whole'
+        elif dist.get_backend() == 'nccl':
+            mode = a.dp_graph
+        else:
+            mode = 'fwdbwd' if bn_sync is None and a.dp_graph != 'off' else 'off'
+    if mode in ('whole', 'fwdbwd'):
         try:
             from vae_gp_ode_amd.graph import GraphedStep, device_generators
             model.flow.odefunc.diffeq.noise_source.draw(w['kernel'], w['q'] * w['order'], w['q'], w['M'], w['S'], dev)  # creates the generator
             gens = device_generators(model)
-            g = GraphedStep(whole_step if sync is None else fwd_bwd, generators=gens, warmup=2)
-            if sync is None:
+            if mode == 'whole':
+                g = GraphedStep(whole_step if sync is None else dp_step, generators=gens, warmup=2)
+
                 def step():
                     last['loss'] = g()
             else:
+                g = GraphedStep(fwd_bwd, generators=gens, warmup=2, grad_params=opt.params)
+
                 def step():
                     last['loss'] = g()
                     sync.all_reduce_grads()
@@ -387,7 +422,7 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
             traceback.print_exc(limit=14, file=sys.stderr)
             print('[bench] HIP graph capture failed (%s); running the step eagerly' % type(e).__name__, file=sys.stderr, flush=True)
             torch.cuda.synchronize()
-            step = eager_step
+            step, mode = eager_step, 'eager (capture failed)'
     for _ in range(a.warmup):
         step()
     barrier()
@@ -410,7 +445,8 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': w['desc'] + '; step = full ELBO training step (encoder, GP draw, rk4 rollout, decoder, ELBO, backward, Adam), L=1',
                    'global_batch': w['batch'] * n_gpus, 'solver': 'rk4 (3/8 rule)', 'parallelism': 'dp%d' % n_gpus,
-                   'hip_graph': graphed, 'gp_side_stream': not a.no_overlap},
+                   'hip_graph': graphed, 'graph_scope': mode, 'gp_side_stream': not a.no_overlap,
+                   'batchnorm': 'global-minibatch statistics (all-gather per layer)' if bn_sync is not None else 'per-process statistics'},
         'elbo_step_ms': el / a.steps * 1e3,
         'roofline': roof,
     }

@@ -167,6 +167,31 @@ int gpode_bn_bwd(const float* x, const float* gy, const float* gamma, const floa
 int gpode_bn_stats(const float* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd, float* running_mean,
                    float* running_var, long long* num_batches_tracked, float momentum, float eps, float* table, int B, int C, int HW,
                    float* scratch, void* stream);
+/* BatchNorm across ranks (data parallelism): the reference's training-mode BatchNorm normalises with the statistics of
+ * the WHOLE minibatch (vae.py:55,58,113,116,119).  The layer is split where the ranks exchange <= 2C+1 floats; the library does no
+ * communication itself (the host all-gathers with RCCL):
+ *   forward   gpode_bn_moments   this shard's per-channel {mean, M2 = sum (x - mean)^2} and its element count, moments[2C+1]
+ *             (all-gather moments over the W ranks -> gathered[W][2C+1])
+ *             gpode_bn_finalize  rank-ordered combination (Chan et al.), save_mean / save_invstd / running statistics / counter,
+ *                                table[C][4] = {mean, invstd, gamma, beta}
+ *             gpode_bn_apply     y = relu?(affine(x)) from the table -- or hand the table to gpode_conv2d_bwd_*_bn instead
+ *   backward  gpode_bn_bwd_sums  this shard's {sum g, sum g xhat} (g = gy under the ReLU mask), sums[2C]
+ *             (all-gather sums -> sums_gathered[W][2C])
+ *             gpode_bn_bwd_apply gx with the centring terms sum_r weights[r] sums_gathered[r] / count_all, where weights[r] =
+ *                                (rank r's share of the global batch) / (this rank's share) -- the data-parallel gradient average
+ *                                weights every rank's loss by its share -- and count_all the global element count; ggamma / gbeta
+ *                                stay this shard's sums.  Must be given the scratch gpode_bn_bwd_sums just used. */
+int gpode_bn_moments(const float* x, float* moments, int B, int C, int HW, float* scratch, void* stream);
+int gpode_bn_finalize(const float* gathered, int nranks, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
+                      float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, float* table,
+                      int C, void* stream);
+int gpode_bn_apply(const float* x, const float* table, float* y, int B, int C, int HW, int relu, void* stream);
+int gpode_bn_bwd_sums(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
+                      const float* save_invstd, float* sums, int B, int C, int HW, int relu, float* scratch, void* stream);
+int gpode_bn_bwd_apply(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
+                       const float* save_invstd, const float* sums_gathered, const float* weights, int nranks, float count_all,
+                       float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW, int relu, float* scratch,
+                       void* stream);
 /* nn.BatchNorm2d in EVALUATION mode (running statistics; main.py:157-163 puts the pre-trained VAE in eval()).
  * gy == NULL: out = y = relu?(affine(x)); gy != NULL: out = d/dx (frozen layer: no affine gradients). */
 int gpode_bn_eval(const float* x, const float* gy, const float* gamma, const float* beta, const float* running_mean,

@@ -1,0 +1,74 @@
+"""Worker of tests/test_gpu_sync_bn.py: `steps` full training steps (encoder, GP draw, rk4 rollout, decoder, ELBO, backward,
+gradient all-reduce, Adam) on this rank's shard of a FIXED global minibatch, with every random input derived from the global
+batch (encoder noise eps[shard], one GP draw shared by all ranks).  Run with WORLD_SIZE = 1 it is the reference's single-process
+step on the whole minibatch; with WORLD_SIZE = N over gloo (all ranks on one card) the N-rank step.  Rank 0 saves gradients of the
+first step and the parameters / BatchNorm buffers after the last one."""
+import os
+import sys
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out, n_global, steps, sync_bn = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] == '1'
+    kernel = sys.argv[5] if len(sys.argv) > 5 else 'RBF'
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    from vae_gp_ode_amd import vae_ops
+    from vae_gp_ode_amd.model.core.initialization import initialize_and_fix_kernel_parameters
+    from vae_gp_ode_amd.model.create_model import build_model, compute_loss
+    from vae_gp_ode_amd.model.misc.torch_utils import seed_everything
+    from vae_gp_ode_amd.optim import HipAdam
+    from vae_gp_ode_amd.parallel import BatchNormSync, GradAllReduce, shard_bounds
+    torch.cuda.set_device(0)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('gloo')
+    q, M, S, T = 6, 16, 32, 6
+    args = types.SimpleNamespace(D_in=q, D_out=q, num_inducing=M, num_features=S, dimwise=True, q_diag=False, device='cuda', kernel=kernel,
+                                 ode=1, solver='rk4', use_adjoint=False, frames=5, n_filt=8, latent_dim=q, Ndata=360, dt=0.1)
+    seed_everything(11)
+    m = build_model(args).cuda()
+    initialize_and_fix_kernel_parameters(m, 2.0, 1.0)
+    g = torch.Generator().manual_seed(12)
+    X = torch.rand(n_global, T, 1, 28, 28, generator=g)
+    lo, hi = shard_bounds(n_global, rank, world)
+    opt = HipAdam(m.parameters(), lr=1e-3, bucketed='gather')
+    sync = GradAllReduce(opt.flat_grads, dist, weight=(hi - lo) / n_global) if dist is not None else None
+    if dist is not None and sync_bn:
+        bs = BatchNormSync(dist, shares=[b - a for a, b in (shard_bounds(n_global, r, world) for r in range(world))])
+        vae_ops.set_bn_sync(bs)
+    gp = m.flow.odefunc.diffeq
+    first_grads = None
+    for it in range(steps):
+        nz = dict(eps_u=torch.randn(M, q, generator=g), rff_w=torch.randn(S if kernel == 'RBF' else 2 * S, q, generator=g),
+                  rff_eps=torch.randn(q, S, q, generator=g), rff_u=torch.rand(1, S, q, generator=g))
+        eps = torch.randn(n_global, q, generator=g)
+        gp.set_noise({k: v.cuda() for k, v in nz.items()})
+        m.vae.encoder.next_eps = eps[lo:hi].cuda()
+        opt.zero_grad()
+        loss, *_ = compute_loss(m, X[lo:hi].cuda(), 1)
+        loss.backward()
+        if sync is not None:
+            sync.all_reduce_grads()
+            flat = opt.flat_grads.flat
+        else:
+            opt.gather_grads()
+            flat = opt.flat_grads.flat
+        if first_grads is None:
+            first_grads = {k: flat[o:o + p.numel()].view_as(p).detach().cpu().clone()
+                           for (k, p), o in zip([(k, p) for k, p in m.named_parameters() if p.requires_grad], opt.flat_grads.offsets)}
+        opt.step()
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save(dict(grads=first_grads, state={k: v.detach().cpu() for k, v in m.state_dict().items()}), out)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -72,6 +72,14 @@ def test_fused_bn_relu_decoder_stage_at_baseline_image_counts(B, layer):
     bn, ref = torch.nn.BatchNorm2d(C).cuda(), torch.nn.BatchNorm2d(C).double()
     with torch.no_grad():
         bn.weight.copy_(gam); bn.bias.copy_(bet); ref.weight.copy_(gam); ref.bias.copy_(bet)
+        # Among 1e8 activations a few land within fp32 round-off of the ReLU kink, where fp32 and fp64 legitimately take different
+        # branches (tools/debug_dec10_bn.py: ONE element of 102,760,448 at 8192 images, which alone moves gbeta by 8e-4).  Move
+        # every pre-activation closer than 1e-4 to zero away from it; the batch statistics change by < 1e-9.
+        pre = F.batch_norm(c.double(), None, None, gam.double(), bet.double(), True, 0.0, 1e-5)
+        near = pre.abs() < 1e-4
+        c[near] += 1e-2 * torch.sign(gam)[None, :, None, None].expand_as(c)[near].float()
+        pre = F.batch_norm(c.double(), None, None, gam.double(), bet.double(), True, 0.0, 1e-5)
+        assert (pre.abs() < 1e-5).sum() == 0
     a64 = [t.double().requires_grad_(True) for t in (c, w, b)]
     y64 = F.conv_transpose2d(F.relu(ref(a64[0])), a64[1], a64[2], stride=s, padding=p, output_padding=op)
     gy = torch.randn(y64.shape, generator=g)

@@ -1,0 +1,63 @@
+"""1-vs-N equivalence: the reference's training-mode BatchNorm couples the whole minibatch
+(vae.py:55,58,113,116,119), so an N-rank data-parallel step equals the single-process step on the concatenated minibatch only
+if every BatchNorm layer normalises with the statistics of the global batch.  Two / three ranks over gloo on this card (the N > 1
+code path: sharding, cross-rank BatchNorm forward + backward, weighted gradient all-reduce, Adam) against one rank on the whole
+batch: the all-reduced gradients of the first step and the parameters and BatchNorm buffers after two steps."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from test_gpu_forward import relerr
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, 'tests', 'dp_equiv_worker.py')
+DEAD_BIAS = ('cnn.0.bias', 'cnn.3.bias', 'decnn.1.bias', 'decnn.4.bias', 'decnn.7.bias')   # feed a BatchNorm: true gradient 0
+
+
+def _run(tmp_path, tag, world, n_global, steps, sync_bn, port, kernel='RBF'):
+    out = str(tmp_path / (tag + '.pt'))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    argv = [WORKER, out, str(n_global), str(steps), '1' if sync_bn else '0', kernel]
+    if world == 1:
+        cmd = [sys.executable] + argv
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+               '--master-port', str(port)] + argv
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return torch.load(out)
+
+
+@pytest.mark.parametrize('world,n_global,kernel', [(2, 8, 'RBF'), (2, 7, 'DF'), (3, 8, 'RBF')])
+def test_n_rank_step_equals_the_single_process_step_on_the_global_batch(tmp_path, world, n_global, kernel):
+    """Even shards (8 over 2), uneven shards (7 over 2: 4 + 3; 8 over 3: 3 + 3 + 2 -- the weighted gradient mean and the weighted
+    BatchNorm backward sums), both kernels."""
+    one = _run(tmp_path, 'one', 1, n_global, 2, True, 0, kernel)
+    many = _run(tmp_path, 'many', world, n_global, 2, True, 29561 + world, kernel)
+    worst_g = worst_p = 0.0
+    for k, g1 in one['grads'].items():
+        if k.endswith(DEAD_BIAS):
+            continue
+        e = relerr(many['grads'][k], g1)
+        worst_g = max(worst_g, e)
+        assert e < 1e-5, ('gradient', k, e)
+    for k, v in one['state'].items():
+        if not v.is_floating_point() or k.endswith(DEAD_BIAS) or k.endswith('_num_evals'):
+            continue
+        e = relerr(many['state'][k], v)
+        worst_p = max(worst_p, e)
+        assert e < 1e-5, ('parameter / buffer after 2 steps', k, e)
+    assert all(int(many['state'][k]) == int(v) for k, v in one['state'].items() if k.endswith('num_batches_tracked'))
+    print('%d ranks vs 1, %s, %d sequences: worst gradient %.1e, worst parameter %.1e' % (world, kernel, n_global, worst_g, worst_p))
+
+
+def test_per_rank_statistics_are_a_different_step(tmp_path):
+    """The control: with per-rank BatchNorm statistics the same 2-rank run does NOT reproduce the single-process step."""
+    one = _run(tmp_path, 'one', 1, 8, 1, True, 0)
+    per_rank = _run(tmp_path, 'per', 2, 8, 1, False, 29569)
+    worst = max(relerr(per_rank['grads'][k], g1) for k, g1 in one['grads'].items() if not k.endswith(DEAD_BIAS))
+    assert worst > 1e-3, worst

@@ -43,6 +43,13 @@ def _worker(rank, world, port, q):
     nz = {'eps_u': torch.full((3, 2), float(rank)), 'rff_u': torch.full((1, 4, 2), float(rank) + 5)}
     broadcast_noise(nz, dist, src=0)
     ok = ok and float(nz['eps_u'][0, 0]) == 0.0 and float(nz['rff_u'][0, 0, 0]) == 5.0
+    # cross-rank BatchNorm plumbing: the gather is rank-ordered, weights are relative to the own share, counts need no communication
+    from vae_gp_ode_amd.parallel import BatchNormSync
+    bs = BatchNormSync(dist, shares=[3, 2])
+    got = bs.gather(torch.tensor([float(rank), 10.0 + rank]))
+    ok = ok and got.tolist() == [[0.0, 10.0], [1.0, 11.0]]
+    ok = ok and torch.allclose(bs.weights('cpu'), torch.tensor([1.0, 2.0 / 3.0] if rank == 0 else [1.5, 1.0]))
+    ok = ok and abs(bs.count_all(3 * 49 if rank == 0 else 2 * 49) - 5 * 49) < 1e-9
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

@@ -51,6 +51,11 @@ SIGNATURES.update({
     'gpode_conv2d_bwd_data_bn': (_i, [_c_float_p] * 5 + [_i] * 10 + [_vp]),
     'gpode_conv2d_bwd_weight_bn': (_i, [_c_float_p] * 6 + [_i] * 10 + [_vp]),
     'gpode_bn_stats': (_i, [_c_float_p] * 7 + [_vp, _f, _f, _c_float_p, _i, _i, _i, _c_float_p, _vp]),
+    'gpode_bn_moments': (_i, [_c_float_p, _c_float_p, _i, _i, _i, _c_float_p, _vp]),
+    'gpode_bn_finalize': (_i, [_c_float_p, _i] + [_c_float_p] * 6 + [_vp, _f, _f, _c_float_p, _i, _vp]),
+    'gpode_bn_apply': (_i, [_c_float_p, _c_float_p, _c_float_p, _i, _i, _i, _i, _vp]),
+    'gpode_bn_bwd_sums': (_i, [_c_float_p] * 7 + [_i, _i, _i, _i, _c_float_p, _vp]),
+    'gpode_bn_bwd_apply': (_i, [_c_float_p] * 8 + [_i, _f] + [_c_float_p] * 4 + [_i, _i, _i, _i, _c_float_p, _vp]),
     'gpode_bn_eval': (_i, [_c_float_p] * 6 + [_f, _c_float_p, _i, _i, _i, _i, _vp]),
     'gpode_chan_sum': (_i, [_c_float_p, _c_float_p, _i, _i, _i, _c_float_p, _vp]),
     'gpode_act_fwd': (_i, [_c_float_p, _c_float_p, _sz, _i, _vp]),

@@ -177,6 +177,35 @@ int gpode_bn_stats(const float* x, const float* gamma, const float* beta, float*
   return gp::bn_stats(x, gamma, beta, save_mean, save_invstd, running_mean, running_var, num_batches_tracked, momentum, eps, table, B, C, HW,
                       scratch, GP_ST);
 }
+int gpode_bn_moments(const float* x, float* moments, int B, int C, int HW, float* scratch, void* stream) {
+  if (!x || !moments || !scratch) return gp::set_error("gpode_bn_moments: null pointer");
+  return gp::bn_moments(x, moments, B, C, HW, scratch, GP_ST);
+}
+int gpode_bn_finalize(const float* gathered, int nranks, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
+                      float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, float* table,
+                      int C, void* stream) {
+  if (!gathered || !gamma || !beta || !save_mean || !save_invstd || !table) return gp::set_error("gpode_bn_finalize: null pointer");
+  return gp::bn_finalize(gathered, nranks, gamma, beta, save_mean, save_invstd, running_mean, running_var, num_batches_tracked, momentum, eps,
+                         table, C, GP_ST);
+}
+int gpode_bn_apply(const float* x, const float* table, float* y, int B, int C, int HW, int relu, void* stream) {
+  if (!x || !table || !y) return gp::set_error("gpode_bn_apply: null pointer");
+  return gp::bn_apply(x, table, y, B, C, HW, relu, GP_ST);
+}
+int gpode_bn_bwd_sums(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
+                      const float* save_invstd, float* sums, int B, int C, int HW, int relu, float* scratch, void* stream) {
+  if (!x || !gy || !gamma || !beta || !save_mean || !save_invstd || !sums || !scratch) return gp::set_error("gpode_bn_bwd_sums: null pointer");
+  return gp::bn_bwd_sums(x, gy, gamma, beta, save_mean, save_invstd, sums, B, C, HW, relu, scratch, GP_ST);
+}
+int gpode_bn_bwd_apply(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
+                       const float* save_invstd, const float* sums_gathered, const float* weights, int nranks, float count_all,
+                       float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW, int relu, float* scratch,
+                       void* stream) {
+  if (!x || !gy || !gamma || !beta || !save_mean || !save_invstd || !sums_gathered || !weights || !gx || !ggamma || !gbeta || !scratch)
+    return gp::set_error("gpode_bn_bwd_apply: null pointer");
+  return gp::bn_bwd_apply(x, gy, gamma, beta, save_mean, save_invstd, sums_gathered, weights, nranks, count_all, gx, ggamma, gbeta, gx_chansum, B, C, HW, relu,
+                          scratch, GP_ST);
+}
 int gpode_bn_eval(const float* x, const float* gy, const float* gamma, const float* beta, const float* running_mean,
                   const float* running_var, float eps, float* out, int B, int C, int HW, int relu, void* stream) {
   if (!x || !gamma || !beta || !running_mean || !running_var || !out) return gp::set_error("gpode_bn_eval: null pointer");

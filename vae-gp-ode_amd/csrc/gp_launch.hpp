@@ -102,6 +102,16 @@ int bn_bwd(const float* x, const float* gy, const float* gamma, const float* bet
 int bn_stats(const float* x, const float* gamma, const float* beta, float* save_mean, float* save_invstd, float* running_mean,
              float* running_var, long long* num_batches_tracked, float momentum, float eps, float* table, int B, int C, int HW,
              float* scratch, hipStream_t st);
+int bn_moments(const float* x, float* mom, int B, int C, int HW, float* scratch, hipStream_t st);
+int bn_finalize(const float* gathered, int W, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
+                float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, float* table, int C,
+                hipStream_t st);
+int bn_apply(const float* x, const float* table, float* y, int B, int C, int HW, int relu, hipStream_t st);
+int bn_bwd_sums(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                float* sums, int B, int C, int HW, int relu, float* scratch, hipStream_t st);
+int bn_bwd_apply(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                 const float* gathered, const float* wts, int W, float count, float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW, int relu,
+                 float* scratch, hipStream_t st);
 int bn_eval(const float* x, const float* gy, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
             float eps, float* out, int B, int C, int HW, int relu, hipStream_t st);
 int chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, hipStream_t st);

@@ -192,12 +192,23 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                        const float* __restrict__ invstd, const float* __restrict__ part, int nsplit,
                                                        float count, float* __restrict__ ggamma, float* __restrict__ gbeta,
                                                        float* __restrict__ gx, float* __restrict__ part_gx, int B, int C, int HW, int bps,
-                                                       int relu) {
+                                                       int relu, const float* __restrict__ gathered, const float* __restrict__ wts, int W) {
   const int c = blockIdx.x, b0 = blockIdx.y * bps, nb = min(B, b0 + bps) - b0;
   const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
   float sa, sb;                                      // sum g, sum g * xhat over all splits: also the affine gradients
   split_sums(part, nsplit, C, c, sa, sb);
   if (blockIdx.y == 0 && threadIdx.x == 0) { gbeta[c] = sa; ggamma[c] = sb; }
+  // cross-rank statistics: the centring terms come from the (weighted) sums over ALL ranks and the global element count; the
+  // affine gradients above stay this rank's own sums (the gradient all-reduce combines them like every other parameter)
+  if (gathered) {                                    // gathered[r][2C]: rank r's sums; wts[r] = its weight relative to this rank
+    const int lane = threadIdx.x & 63;
+    const float wr = lane < W ? wts[lane] : 0.f;
+    const float in2[2] = {lane < W ? wr * gathered[(size_t)lane * 2 * C + 2 * c] : 0.f, lane < W ? wr * gathered[(size_t)lane * 2 * C + 2 * c + 1] : 0.f};
+    float out2[2];
+    wave_sum_multi<2>(in2, out2);
+    sa = out2[0];
+    sb = out2[1];
+  }
   const float ic = 1.f / count, ca = sa * ic, cb = sb * ic, sc = g * is;
   auto one = [&](float xv, float gv) {
     const float xh = bn_xhat(xv, m, is);
@@ -270,6 +281,80 @@ __global__ __launch_bounds__(64) void k_reduce_chan(const float* __restrict__ pa
   if (threadIdx.x == 0) out[blockIdx.x] = a;
 }
 
+
+// ---- cross-rank BatchNorm (data parallelism: the statistics of the GLOBAL minibatch, vae.py:55,58,113,116,119) -------------
+// local moments of this rank's shard: mom[2c] = mean_c, mom[2c+1] = M2_c = sum (x - mean_c)^2, mom[2C] = element count.
+// One wavefront per channel; blockIdx.x == C writes the count.
+__global__ __launch_bounds__(64) void k_bn_moments(const float* __restrict__ part, const float* __restrict__ shift, int nsplit, int C,
+                                                   float count, float* __restrict__ mom) {
+  const int c = blockIdx.x;
+  if (c == C) { if (threadIdx.x == 0) mom[2 * C] = count; return; }
+  float s0, s1;
+  split_sums(part, nsplit, C, c, s0, s1);
+  if (threadIdx.x != 0) return;
+  const float d = s0 / count;
+  mom[2 * c] = shift[c] + d;
+  mom[2 * c + 1] = fmaxf(s1 - s0 * d, 0.f);
+}
+
+// gathered[r][2C+1] for r < W (<= 64) ranks, combined in rank order (Chan et al.: n = sum n_r, mean = sum n_r mean_r / n,
+// M2 = sum M2_r + n_r (mean_r - mean)^2) -- identical on every rank, no E[x^2] - E[x]^2 cancellation.  Then exactly what
+// k_bn_table does with the batch statistics.
+__global__ __launch_bounds__(64) void k_bn_finalize(const float* __restrict__ gathered, int W, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int C, float eps, float momentum,
+                                                    float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                    long long* __restrict__ num_batches_tracked, float* __restrict__ table) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const size_t stride = 2 * (size_t)C + 1;
+  const float nr = lane < W ? gathered[lane * stride + 2 * C] : 0.f;
+  const float mr = lane < W ? gathered[lane * stride + 2 * c] : 0.f;
+  const float qr = lane < W ? gathered[lane * stride + 2 * c + 1] : 0.f;
+  const float in2[2] = {nr, nr * mr};
+  float out2[2];
+  wave_sum_multi<2>(in2, out2);
+  const float count = out2[0], m = out2[1] / count;
+  const float dm = mr - m;
+  const float in1[1] = {fmaf(nr * dm, dm, qr)};
+  float out1[1];
+  wave_sum_multi<1>(in1, out1);
+  if (lane != 0) return;
+  const float var = fmaxf(out1[0] / count, 0.f);
+  const float is = rsqrtf(var + eps);
+  save_mean[c] = m;
+  save_invstd[c] = is;
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count / (count - 1.f));
+  }
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  table[4 * c + 0] = m; table[4 * c + 1] = is; table[4 * c + 2] = gamma[c]; table[4 * c + 3] = beta[c];
+}
+
+// y = relu?(affine(x)) with the per-channel table {mean, invstd, gamma, beta}: the output pass of k_bn_apply on its own
+__global__ __launch_bounds__(256) void k_bn_apply_table(const float* __restrict__ x, const float* __restrict__ table, float* __restrict__ y,
+                                                         int B, int C, int HW, int bps, int relu) {
+  const int c = blockIdx.x, b0 = blockIdx.y * bps, nb = min(B, b0 + bps) - b0;
+  const float m = table[4 * c], is = table[4 * c + 1], g = table[4 * c + 2], bt = table[4 * c + 3];
+  const float lo = relu ? 0.f : -INFINITY;
+  chan_slab(C, HW, c, b0, nb,
+            [&](size_t i) {
+              const float4 v = *reinterpret_cast<const float4*>(x + i);
+              float4 o;
+              o.x = fmaxf(bn_affine(v.x, m, is, g, bt), lo); o.y = fmaxf(bn_affine(v.y, m, is, g, bt), lo);
+              o.z = fmaxf(bn_affine(v.z, m, is, g, bt), lo); o.w = fmaxf(bn_affine(v.w, m, is, g, bt), lo);
+              *reinterpret_cast<float4*>(y + i) = o;
+            },
+            [&](size_t i) { y[i] = fmaxf(bn_affine(x[i], m, is, g, bt), lo); });
+}
+
+// out[c][0..1] = sum_s part[s][c][0..1]; one wavefront per channel
+__global__ __launch_bounds__(64) void k_reduce_chan2(const float* __restrict__ part, int nsplit, int C, float* __restrict__ out) {
+  float a, b;
+  split_sums(part, nsplit, C, blockIdx.x, a, b);
+  if (threadIdx.x == 0) { out[2 * blockIdx.x] = a; out[2 * blockIdx.x + 1] = b; }
+}
+
 struct Split { int ns, bps, used; };
 inline Split pick(int B) {
   Split s;
@@ -318,9 +403,59 @@ int bn_bwd(const float* x, const float* gy, const float* gamma, const float* bet
   hipLaunchKernelGGL(k_bn_bwd_sums, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, save_mean, save_invstd, B, C, HW, sp.bps, relu, scratch);
   float* part_gx = gx_chansum ? scratch + (size_t)sp.ns * C * 2 + (size_t)C * 3 : nullptr;
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, save_mean, save_invstd, scratch, sp.used, (float)B * HW,
-                     ggamma, gbeta, gx, part_gx, B, C, HW, sp.bps, relu);
+                     ggamma, gbeta, gx, part_gx, B, C, HW, sp.bps, relu, (const float*)nullptr, (const float*)nullptr, 0);
   if (gx_chansum) hipLaunchKernelGGL(k_reduce_chan, C, 64, 0, st, part_gx, sp.used, C, gx_chansum);
   return check_launch("bn_bwd");
+}
+
+// ---- the same layer split at the points where ranks exchange statistics (include/gpode.h: "BatchNorm across ranks") ----------
+int bn_moments(const float* x, float* mom, int B, int C, int HW, float* scratch, hipStream_t st) {
+  if ((HW & 3) == 0 && !aligned16(x)) return set_error("gpode_bn_moments: x must be 16-byte aligned");
+  const Split sp = pick(B);
+  float* shift = scratch + (size_t)sp.ns * C * 2 + (size_t)C * 2;
+  hipLaunchKernelGGL(k_bn_stats, dim3(C, sp.used), 256, 0, st, x, B, C, HW, sp.bps, scratch, shift);
+  hipLaunchKernelGGL(k_bn_moments, C + 1, 64, 0, st, scratch, shift, sp.used, C, (float)B * HW, mom);
+  return check_launch("bn_moments");
+}
+
+int bn_finalize(const float* gathered, int W, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
+                float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, float* table, int C,
+                hipStream_t st) {
+  if (W < 1 || W > 64) return set_error("gpode_bn_finalize: %d ranks (1..64 supported)", W);
+  hipLaunchKernelGGL(k_bn_finalize, C, 64, 0, st, gathered, W, gamma, beta, C, eps, momentum, save_mean, save_invstd, running_mean, running_var,
+                     num_batches_tracked, table);
+  return check_launch("bn_finalize");
+}
+
+int bn_apply(const float* x, const float* table, float* y, int B, int C, int HW, int relu, hipStream_t st) {
+  if ((HW & 3) == 0 && !(aligned16(x) && aligned16(y))) return set_error("gpode_bn_apply: x / y must be 16-byte aligned");
+  const Split sp = pick(B);
+  hipLaunchKernelGGL(k_bn_apply_table, dim3(C, sp.used), 256, 0, st, x, table, y, B, C, HW, sp.bps, relu);
+  return check_launch("bn_apply");
+}
+
+int bn_bwd_sums(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                float* sums, int B, int C, int HW, int relu, float* scratch, hipStream_t st) {
+  if ((HW & 3) == 0 && !(aligned16(x) && aligned16(gy))) return set_error("gpode_bn_bwd_sums: x / gy must be 16-byte aligned");
+  const Split sp = pick(B);
+  hipLaunchKernelGGL(k_bn_bwd_sums, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, save_mean, save_invstd, B, C, HW, sp.bps, relu, scratch);
+  hipLaunchKernelGGL(k_reduce_chan2, C, 64, 0, st, scratch, sp.used, C, sums);
+  return check_launch("bn_bwd_sums");
+}
+
+// after gpode_bn_bwd_sums on the same scratch (its split sums are still there): gathered = every rank's sums, wts their weights
+// relative to this rank, count = global element count
+int bn_bwd_apply(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                 const float* gathered, const float* wts, int W, float count, float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW, int relu,
+                 float* scratch, hipStream_t st) {
+  if ((HW & 3) == 0 && !(aligned16(x) && aligned16(gy) && aligned16(gx))) return set_error("gpode_bn_bwd_apply: x / gy / gx must be 16-byte aligned");
+  if (W < 1 || W > 64) return set_error("gpode_bn_bwd_apply: %d ranks (1..64 supported)", W);
+  const Split sp = pick(B);
+  float* part_gx = gx_chansum ? scratch + (size_t)sp.ns * C * 2 + (size_t)C * 3 : nullptr;
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, save_mean, save_invstd, scratch, sp.used, count,
+                     ggamma, gbeta, gx, part_gx, B, C, HW, sp.bps, relu, gathered, wts, W);
+  if (gx_chansum) hipLaunchKernelGGL(k_reduce_chan, C, 64, 0, st, part_gx, sp.used, C, gx_chansum);
+  return check_launch("bn_bwd_apply");
 }
 
 // gy == nullptr: forward (out = y); otherwise out = gx

@@ -7,7 +7,8 @@ kernels behind ``model/``; the optimizer is the one-launch HIP Adam.
 Data parallelism (no flag: launch with ``python -m torch.distributed.run --nproc-per-node N -m vae_gp_ode_amd.main ...``): one
 process per GPU over RCCL, every rank takes its shard of each minibatch under the SAME GP draw (rank 0's host-RNG noise is
 broadcast; ``--hip_graph`` seeds the device generators identically), one all-reduce of the flat gradient bucket per step,
-rank 0 logs, evaluates and writes the checkpoint (vae_gp_ode_amd/parallel.py; BatchNorm statistics stay per rank).
+rank 0 logs, evaluates and writes the checkpoint (vae_gp_ode_amd/parallel.py); training-mode BatchNorm normalises with the
+statistics of the global minibatch (``--sync_bn``, default on), so an N-rank step is the reference's step on the whole minibatch.
 
 Data: ``--task mnist`` goes through ``data/wrappers.load_data`` (``<data_root>/rot_mnist/rot-mnist.mat``, the reference's
 file; the set is uploaded once and minibatches are gathered on the device) or, when that file is absent, tensors saved as
@@ -227,11 +228,18 @@ def main(argv=None):
         logger.info('Resume training for model {}'.format(fname))
 
     meters = {k: RunningAverage(10) for k in ('elbo', 'nll', 'reg_kl', 'inducing_kl')}
+    bn_sync = None
     optimizer = HipAdam(model.parameters(), lr=args.lr, bucketed='gather' if dist is not None else True)
     sync = None
     if dist is not None:
         from .parallel import GradAllReduce, shard_batch
         sync = GradAllReduce(optimizer.flat_grads, dist, weight=1.0 / world)
+        if args.sync_bn and any(isinstance(m, torch.nn.BatchNorm2d) and m.training for m in model.modules()):
+            from . import vae_ops
+            from .parallel import BatchNormSync, shard_bounds
+            bn_sync = BatchNormSync(dist)
+            vae_ops.set_bn_sync(bn_sync)
+            logger.info('BatchNorm statistics over the global minibatch ({} ranks)'.format(world))
         gp_layer = model.flow.odefunc.diffeq
         gp_layer.noise_source = BroadcastNoise(gp_layer.noise_source, dist)
         torch.manual_seed(args.seed + 7919 * (rank + 1))     # encoder reparameterisation noise: independent per shard
@@ -248,8 +256,13 @@ def main(argv=None):
         from .model.core.noise import DeviceNoise
         model.flow.odefunc.diffeq.noise_source = DeviceNoise(args.seed + 1)
 
+    # gloo's collectives are host code: a step that holds them (cross-rank BatchNorm) cannot be stream-captured
+    capture_ok = not (bn_sync is not None and dist.get_backend() != 'nccl')
+    if args.hip_graph and not capture_ok:
+        logger.info('cross-rank BatchNorm over {}: steps are launched eagerly (device noise and side stream stay on)'.format(dist.get_backend()))
+
     def graphed_step(minibatch, L):
-        key = (L, tuple(minibatch.shape))
+        key = (L, tuple(minibatch.shape), bn_sync.shares if bn_sync is not None else None)
         if key not in graphs:
             buf = torch.empty_like(minibatch)
 
@@ -285,9 +298,13 @@ def main(argv=None):
                 n_global = minibatch.shape[0]
                 minibatch = shard_batch(minibatch, rank, world)
                 sync.weight = minibatch.shape[0] / n_global
-            elif sync is not None:
+                if bn_sync is not None:
+                    bn_sync.set_shares([hi - lo for lo, hi in (shard_bounds(n_global, r, world) for r in range(world))])
+            elif sync is not None:       # fewer sequences than ranks: every rank takes the whole minibatch
                 sync.weight = 1.0 / world
-            if args.hip_graph:
+                if bn_sync is not None:
+                    bn_sync.set_shares(None)
+            if args.hip_graph and capture_ok:
                 loss, nlhood, kl_reg, kl_u = graphed_step(minibatch, L)
             else:
                 loss, nlhood, kl_reg, kl_u = compute_loss(model, minibatch, L)
@@ -300,12 +317,13 @@ def main(argv=None):
                 if dist is not None:
                     dist.destroy_process_group()
                 sys.exit()
-            if not args.hip_graph:
+            graphed = args.hip_graph and capture_ok
+            if not graphed:
                 optimizer.zero_grad()
                 loss.backward()
             if sync is not None:
                 sync.all_reduce_grads()
-            if not args.hip_graph or sync is not None:
+            if not graphed or sync is not None:
                 optimizer.step()
             for k, v in zip(('elbo', 'nll', 'reg_kl', 'inducing_kl'), terms.tolist()):
                 meters[k].update(v)
@@ -313,6 +331,8 @@ def main(argv=None):
                 logger.info('Iter:{:<2d} | Time {} | elbo {:8.2f}({:8.2f}) | nlhood:{:8.2f}({:8.2f}) | kl_reg:{:<8.2f}({:<8.2f}) | kl_u:{:8.5f}({:8.5f})'.format(
                     itr, timedelta(seconds=time.time() - begin), meters['elbo'].val, meters['elbo'].avg, meters['nll'].val, meters['nll'].avg,
                     meters['reg_kl'].val, meters['reg_kl'].avg, meters['inducing_kl'].val, meters['inducing_kl'].avg))
+        if bn_sync is not None:                      # every rank evaluates the SAME test batch: its own statistics are the global ones
+            vae_ops.set_bn_sync(None)
         with torch.no_grad():
             for test_batch in testset:               # every rank evaluates (the GP draw is a collective); rank 0 keeps the file
                 test_batch = _frames(test_batch)
@@ -322,6 +342,8 @@ def main(argv=None):
                 if rank == 0:
                     torch.save(model.state_dict(), os.path.join(args.save, 'odegpvae_mnist.pth'))
                 break
+        if bn_sync is not None:
+            vae_ops.set_bn_sync(bn_sync)
         logger.info('Epoch:{:4d}/{:4d}| tr_elbo:{:8.2f}({:8.2f}) | test_mse:{:5.3f}\n'.format(
             ep, args.Nepoch, meters['elbo'].val, meters['elbo'].avg, test_mse.item()))
     logger.info('********** Optimization completed **********')

@@ -5,8 +5,10 @@ model on its own shard of the minibatch under the SAME draw (``DeviceNoise`` see
 or rank 0's noise broadcast with ``broadcast_noise``).  The only data-path collective is one all-reduce
 (mean) of the flat gradient bucket per step: 0.56 MB at cfg1-4.  ``kl_u`` is rank-invariant, the
 log-likelihood and KL(z0) terms are per-rank means, so the averaged gradient is exactly the gradient of the
-reference loss (create_model.py:72) on the global batch -- except for BatchNorm, which normalises with
-per-rank batch statistics here (the reference's train-mode BatchNorm couples the whole batch).
+reference loss (create_model.py:72) on the global batch.  BatchNorm is the one operator that couples the samples of a
+minibatch (the reference never leaves training mode, vae.py:55,58,113,116,119): ``BatchNormSync`` makes every
+BatchNorm layer normalise with the statistics of the GLOBAL minibatch -- an all-gather of 2C+1 floats per layer in the forward
+pass and of 2C floats in the backward pass (C <= 64) -- so that an N-rank step is the reference's step on the concatenated batch.
 """
 import torch
 
@@ -72,3 +74,43 @@ def broadcast_noise(noise, dist, src=0):
     for k in sorted(noise):
         dist.broadcast(noise[k], src=src)
     return noise
+
+
+class BatchNormSync:
+    """Cross-rank training-mode BatchNorm (activate with ``vae_ops.set_bn_sync``).  The library splits the layer where the ranks
+    exchange numbers (include/gpode.h: gpode_bn_moments / _finalize / _apply, gpode_bn_bwd_sums / _bwd_apply); this class does the
+    exchange: an all-gather, so that every rank combines the same values in the same (rank) order.
+
+    ``shares``: sequences per rank of the current global minibatch (default: equal shards).  The data-parallel gradient mean
+    weights rank r's loss by shares[r] / sum(shares) (``GradAllReduce.weight``); the backward centring terms need the other
+    ranks' sums with that weight relative to this rank's own."""
+
+    def __init__(self, dist, shares=None):
+        self.dist = dist
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        if self.world > 64:
+            raise ValueError('BatchNormSync: at most 64 ranks (one wavefront combines the gathered statistics)')
+        self._wts = {}
+        self.set_shares(shares)
+
+    def set_shares(self, shares=None):
+        self.shares = tuple(float(v) for v in shares) if shares is not None else (1.0,) * self.world
+        if len(self.shares) != self.world or min(self.shares) <= 0:
+            raise ValueError('BatchNormSync.set_shares: one positive share per rank')
+
+    def gather(self, t):
+        """t (K,) on every rank -> (world, K), row r = rank r's t."""
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self.dist.all_gather(list(out.unbind(0)), t)
+        return out
+
+    def weights(self, device):
+        """(world,) device tensor shares[r] / shares[rank] (cached per share pattern)."""
+        key = (self.shares, str(device))
+        if key not in self._wts:
+            self._wts[key] = torch.tensor([v / self.shares[self.rank] for v in self.shares], dtype=torch.float32, device=device)
+        return self._wts[key]
+
+    def count_all(self, local_count):
+        """global element count of a layer whose local element count is ``local_count`` (host arithmetic, no communication)."""
+        return float(local_count) * (sum(self.shares) / self.shares[self.rank])

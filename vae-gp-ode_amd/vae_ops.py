@@ -24,6 +24,47 @@ def _bn_scratch(B, C, like):
     return _scratch(_lib.load().gpode_bn_scratch(B, C), like)
 
 
+_bn_sync = None        # parallel.BatchNormSync while data-parallel training normalises with global-minibatch statistics
+
+
+def set_bn_sync(group):
+    """group: parallel.BatchNormSync (or None = per-process statistics, the single-GPU path)."""
+    global _bn_sync
+    _bn_sync = group
+
+
+def _bn_global_stats(x, gamma, beta, running_mean, running_var, nbt, momentum, eps, scratch):
+    """Forward half of the cross-rank BatchNorm: local moments -> all-gather -> rank-ordered combination.
+    Returns (mean, invstd, table[C][4])."""
+    B, C = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    mom = _new((2 * C + 1,), x)
+    _lib.call('gpode_bn_moments', _ptr(x), _ptr(mom), B, C, HW, _ptr(scratch), _stream())
+    gathered = _bn_sync.gather(mom)
+    mean, invstd, table = _new((C,), x), _new((C,), x), _new((C, 4), x)
+    _lib.call('gpode_bn_finalize', _ptr(gathered), _bn_sync.world, _ptr(_chk(gamma, 'gamma')), _ptr(_chk(beta, 'beta')), _ptr(mean),
+              _ptr(invstd), _ptr(running_mean), _ptr(running_var), _ptr(nbt), ctypes.c_float(momentum), ctypes.c_float(eps), _ptr(table), C,
+              _stream())
+    return mean, invstd, table
+
+
+def _bn_global_bwd(sync, x, gy, gamma, beta, mean, invstd, relu):
+    """Backward half: local sums -> all-gather -> gx with the global centring terms.  Returns (gx, ggamma, gbeta, chansum)."""
+    B, C = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    scratch = _bn_scratch(B, C, x)
+    sums = _new((2 * C,), x)
+    gy = gy.contiguous()
+    _lib.call('gpode_bn_bwd_sums', _ptr(x), _ptr(gy), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(sums), B, C, HW, int(relu),
+              _ptr(scratch), _stream())
+    gathered = sync.gather(sums)
+    gx, gg, gb, cs = _new(x.shape, x), _new((C,), x), _new((C,), x), _new((C,), x)
+    _lib.call('gpode_bn_bwd_apply', _ptr(x), _ptr(gy), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(gathered),
+              _ptr(sync.weights(x.device)), sync.world, ctypes.c_float(sync.count_all(B * HW)), _ptr(gx), _ptr(gg), _ptr(gb), _ptr(cs),
+              B, C, HW, int(relu), _ptr(scratch), _stream())
+    return gx, gg, gb, cs
+
+
 fused_bias_grads = 0   # how many bias gradients arrived ready-made from a BatchNorm backward (see _BatchNormTrain.backward)
 
 
@@ -118,10 +159,14 @@ class _BnReluConvT(torch.autograd.Function):
         B, Cin, Hi, Wi = c.shape
         _, Cout, K, _ = w.shape
         Ht, Wt = (Hi - 1) * stride - 2 * pad + K + out_pad, (Wi - 1) * stride - 2 * pad + K + out_pad
-        mean, invstd, table = _new((Cin,), c), _new((Cin,), c), _new((Cin, 4), c)
-        _lib.call('gpode_bn_stats', _ptr(c), _ptr(_chk(gamma, 'gamma')), _ptr(_chk(beta, 'beta')), _ptr(mean), _ptr(invstd),
-                  _ptr(running_mean), _ptr(running_var), _ptr(nbt), ctypes.c_float(momentum), ctypes.c_float(eps), _ptr(table),
-                  B, Cin, Hi * Wi, _ptr(_bn_scratch(B, Cin, c)), _stream())
+        ctx.sync = _bn_sync
+        if _bn_sync is not None:
+            mean, invstd, table = _bn_global_stats(c, gamma, beta, running_mean, running_var, nbt, momentum, eps, _bn_scratch(B, Cin, c))
+        else:
+            mean, invstd, table = _new((Cin,), c), _new((Cin,), c), _new((Cin, 4), c)
+            _lib.call('gpode_bn_stats', _ptr(c), _ptr(_chk(gamma, 'gamma')), _ptr(_chk(beta, 'beta')), _ptr(mean), _ptr(invstd),
+                      _ptr(running_mean), _ptr(running_var), _ptr(nbt), ctypes.c_float(momentum), ctypes.c_float(eps), _ptr(table),
+                      B, Cin, Hi * Wi, _ptr(_bn_scratch(B, Cin, c)), _stream())
         y = _new((B, Cout, Ht, Wt), c)
         _lib.call('gpode_conv2d_bwd_data_bn', _ptr(c), _ptr(table), _ptr(w), _ptr(b), _ptr(y), B, Cout, Ht, Wt, Cin, K, stride, pad, Hi, Wi,
                   _stream())
@@ -147,9 +192,12 @@ class _BnReluConvT(torch.autograd.Function):
         # gradient w.r.t. the (never materialised) normalised activation, then through the BatchNorm to c
         ga = _new(c.shape, c)
         _lib.call('gpode_conv2d_fwd', _ptr(gy), _ptr(w), _ptr(None), _ptr(ga), B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, _stream())
-        gc, gg, gbeta, cs = _new(c.shape, c), _new((Cin,), c), _new((Cin,), c), _new((Cin,), c)
-        _lib.call('gpode_bn_bwd', _ptr(c), _ptr(ga), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(gc), _ptr(gg), _ptr(gbeta),
-                  _ptr(cs), B, Cin, Hi * Wi, 1, _ptr(_bn_scratch(B, Cin, c)), _stream())
+        if ctx.sync is not None:
+            gc, gg, gbeta, cs = _bn_global_bwd(ctx.sync, c, ga, gamma, beta, mean, invstd, 1)
+        else:
+            gc, gg, gbeta, cs = _new(c.shape, c), _new((Cin,), c), _new((Cin,), c), _new((Cin,), c)
+            _lib.call('gpode_bn_bwd', _ptr(c), _ptr(ga), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(gc), _ptr(gg), _ptr(gbeta),
+                      _ptr(cs), B, Cin, Hi * Wi, 1, _ptr(_bn_scratch(B, Cin, c)), _stream())
         gc._gpode_chansum = cs
         return gc, gg, gbeta, None, None, None, None, None, gw, gb, None, None, None
 
@@ -164,9 +212,14 @@ class _BatchNormTrain(torch.autograd.Function):
         mean, invstd = _new((C,), x), _new((C,), x)
         if nbt is not None and not (nbt.is_cuda and nbt.dtype == torch.int64):
             raise _lib.GpodeError('num_batches_tracked must be an int64 CUDA/HIP scalar')
-        _lib.call('gpode_bn_fwd', _ptr(x), _ptr(_chk(gamma, 'gamma')), _ptr(_chk(beta, 'beta')), _ptr(y), _ptr(mean), _ptr(invstd),
-                  _ptr(running_mean), _ptr(running_var), _ptr(nbt), ctypes.c_float(momentum), ctypes.c_float(eps), B, C, HW, int(relu),
-                  _ptr(_bn_scratch(B, C, x)), _stream())
+        ctx.sync = _bn_sync
+        if _bn_sync is not None:
+            mean, invstd, table = _bn_global_stats(x, gamma, beta, running_mean, running_var, nbt, momentum, eps, _bn_scratch(B, C, x))
+            _lib.call('gpode_bn_apply', _ptr(x), _ptr(table), _ptr(y), B, C, HW, int(relu), _stream())
+        else:
+            _lib.call('gpode_bn_fwd', _ptr(x), _ptr(_chk(gamma, 'gamma')), _ptr(_chk(beta, 'beta')), _ptr(y), _ptr(mean), _ptr(invstd),
+                      _ptr(running_mean), _ptr(running_var), _ptr(nbt), ctypes.c_float(momentum), ctypes.c_float(eps), B, C, HW, int(relu),
+                      _ptr(_bn_scratch(B, C, x)), _stream())
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         ctx.relu = int(relu)
         return y
@@ -176,9 +229,12 @@ class _BatchNormTrain(torch.autograd.Function):
         x, gamma, beta, mean, invstd = ctx.saved_tensors
         B, C = x.shape[0], x.shape[1]
         HW = x[0, 0].numel()
-        gx, gg, gb, cs = _new(x.shape, x), _new((C,), x), _new((C,), x), _new((C,), x)
-        _lib.call('gpode_bn_bwd', _ptr(x), _ptr(gy.contiguous()), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(gx), _ptr(gg),
-                  _ptr(gb), _ptr(cs), B, C, HW, ctx.relu, _ptr(_bn_scratch(B, C, x)), _stream())
+        if ctx.sync is not None:
+            gx, gg, gb, cs = _bn_global_bwd(ctx.sync, x, gy, gamma, beta, mean, invstd, ctx.relu)
+        else:
+            gx, gg, gb, cs = _new(x.shape, x), _new((C,), x), _new((C,), x), _new((C,), x)
+            _lib.call('gpode_bn_bwd', _ptr(x), _ptr(gy.contiguous()), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(gx), _ptr(gg),
+                      _ptr(gb), _ptr(cs), B, C, HW, ctx.relu, _ptr(_bn_scratch(B, C, x)), _stream())
         # the channel sums of gx ride along with it: the convolution that produced x needs exactly these as its bias gradient
         gx._gpode_chansum = cs
         return gx, gg, gb, None, None, None, None, None, None
