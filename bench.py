@@ -27,19 +27,20 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# BASELINE.json configs; flops per trajectory from SURVEY.md section 8(d) (integrator, rk4, T=16)
+# BASELINE.json configs; flops per trajectory from SURVEY.md section 8(d): mflop = integrator (rk4), elbo_mflop = full ELBO step
+# (forward + backward, the 3x rule)
 WORKLOADS = {
     # name: kernel, order, q, M, S, T, batch per GPU, integrator MFLOP/traj
-    'cfg1': dict(kernel='RBF', order=1, q=6, M=100, S=256, T=16, batch=32, mflop=2.252,
+    'cfg1': dict(kernel='RBF', order=1, q=6, M=100, S=256, T=16, batch=32, mflop=2.252, elbo_mflop=452.0,
                  desc='configs[0]: ode1 RBF q=6 M=100 S=256 T=16 batch=32'),
-    'cfg2': dict(kernel='DF', order=1, q=6, M=100, S=256, T=16, batch=256, mflop=5.864,
+    'cfg2': dict(kernel='DF', order=1, q=6, M=100, S=256, T=16, batch=256, mflop=5.864, elbo_mflop=463.0,
                  desc='configs[1]: ode1 DF q=6 M=100 S=256 T=16 batch=256'),
-    'cfg3': dict(kernel='RBF', order=2, q=3, M=100, S=256, T=16, batch=256, mflop=1.127,
+    'cfg3': dict(kernel='RBF', order=2, q=3, M=100, S=256, T=16, batch=256, mflop=1.127, elbo_mflop=452.0,
                  desc='configs[2]: ode2 RBF Din=6 Dout=3 M=100 S=256 T=16 batch=256'),
-    'cfg4': dict(kernel='RBF', order=1, q=6, M=100, S=256, T=16, batch=256, mflop=2.252,
+    'cfg4': dict(kernel='RBF', order=1, q=6, M=100, S=256, T=16, batch=256, mflop=2.252, elbo_mflop=452.0,
                  desc='configs[3] per-GPU shard: ode1 RBF q=6 M=100 S=256 T=16 batch=256/GPU (2048 over 8)'),
     # K_uu is 8192 x 8192; forward and backward take the streamed 4-wavefront team (pack read from L2)
-    'cfg5': dict(kernel='DF', order=1, q=16, M=512, S=256, T=64, batch=128, mflop=438.7,
+    'cfg5': dict(kernel='DF', order=1, q=16, M=512, S=256, T=64, batch=128, mflop=438.7, elbo_mflop=3094.0,
                  desc='configs[4] per-GPU shard: ode1 DF q=16 M=512 S=256 T=64 batch=128/GPU (1024 over 8)'),
 }
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
@@ -250,6 +251,7 @@ def main():
     ap.add_argument('--mode', default='elbo', choices=['elbo', 'integrator'])
     ap.add_argument('--seed', type=int, default=121)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip extra.configs (configs[0], configs[2], integrator-only figures)')
     ap.add_argument('--no-overlap', action='store_true', help='keep the GP cache build / cache backward on the main stream')
     ap.add_argument('--no-sync-bn', action='store_true', help='N > 1: BatchNorm with per-rank statistics instead of the global minibatch')
     ap.add_argument('--dp-graph', default='whole', choices=['whole', 'fwdbwd', 'off'],
@@ -450,11 +452,122 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
         'elbo_step_ms': el / a.steps * 1e3,
         'roofline': roof,
     }
+    # whole-step roofline: SURVEY 8(d)'s algorithmic flops per trajectory (forward + backward) x trajectories/s over the fp32 peak
+    roof['step_frac'] = w['elbo_mflop'] * 1e6 * (value / n_gpus) / 1e12 / PEAK_FP32_TFLOPS
+    roof['step_note'] = '%.0f MFLOP per trajectory (SURVEY 8d, full ELBO step) x per-GPU trajectories/s / %.1f TFLOP/s' % (w['elbo_mflop'], PEAK_FP32_TFLOPS)
     if rank == 0:
         print('[bench] gpu leg done: %.1f traj/s, %.3f ms/step' % (value, el / a.steps * 1e3), file=sys.stderr, flush=True)
+        if n_gpus == 1 and not a.no_extra:
+            ops.set_overlap(False)
+            extra = other_configs(a, dev, a.workload)
+            ops.set_overlap(not a.no_overlap)
+            main = extra.pop(a.workload)
+            out['integrator_ms'] = main['integrator_ms']
+            out['integrator_traj_per_s'] = main['integrator_traj_per_s']
+            roof['integrator'] = {'bound': 'valu', 'kernel': 'rollout_team_kernel (rk4 rollout of the GP-ODE, one launch per draw)',
+                                  'achieved': main['rollout_valu_frac'] * PEAK_FP32_TFLOPS, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
+                                  'frac': main['rollout_valu_frac'], 'ms_per_launch': main['rollout_ms'],
+                                  'note': '%.3f MFLOP/trajectory x %d trajectories (SURVEY 8d; transcendentals count as 1 flop)' % (w['mflop'], w['batch'])}
+            out['extra'] = {'configs': extra}
         if not a.no_cpu_baseline and n_gpus == 1:
             out['cpu_baseline'] = cpu_baseline_elbo(w, model, X)
             out['gpu_over_cpu'] = value / out['cpu_baseline']['value']
+    return out
+
+
+def quick_integrator(w, dev, seed, steps=50, warmup=5):
+    """GP draw + rk4 rollout of workload `w` on one GPU: (ms per graph-replayed draw + rollout, ms of the rollout launch alone
+    bracketed by events on the launch stream, the inputs for a CPU leg)."""
+    from vae_gp_ode_amd import ops
+    from vae_gp_ode_amd.graph import GraphedStep
+    flow, p, nz, z0, ts, nzd, z0d, tsd = make_inputs(w, seed, dev, 0)
+    gp = flow.odefunc.diffeq
+    with torch.no_grad():
+        def step(ev=None):
+            c = gp.build_cache(noise=nzd)
+            if ev is not None:
+                ev[0].record()
+            zt = ops.rollout(c, z0d, tsd, w['order'], 'rk4')
+            if ev is not None:
+                ev[1].record()
+            return zt
+        for _ in range(3):
+            step()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for ev in evs:
+            step(ev)
+        torch.cuda.synchronize()
+        roll_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+        g = GraphedStep(step, warmup=1)
+        for _ in range(warmup):
+            g()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            zt = g()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    if not torch.isfinite(zt).all():
+        raise SystemExit('non-finite trajectories (%s)' % w['desc'])
+    return ms, roll_ms, (p, nz, z0, ts)
+
+
+def quick_elbo(w, dev, seed, steps=30, warmup=5):
+    """Full ELBO training step of workload `w` on one GPU, graph-replayed: (ms per step, model, X)."""
+    from vae_gp_ode_amd.graph import GraphedStep, device_generators
+    from vae_gp_ode_amd.model.create_model import compute_loss
+    from vae_gp_ode_amd.optim import HipAdam
+    model, X = make_model_inputs(w, seed, dev, 0)
+    Xd = X.to(dev)
+    opt = HipAdam(model.parameters(), lr=1e-6, bucketed=False)
+
+    def whole_step():
+        opt.zero_grad()
+        loss, *_ = compute_loss(model, Xd, 1)
+        loss.backward()
+        opt.step()
+        return loss
+    model.flow.odefunc.diffeq.noise_source.draw(w['kernel'], w['q'] * w['order'], w['q'], w['M'], w['S'], dev)
+    g = GraphedStep(whole_step, generators=device_generators(model), warmup=2)
+    for _ in range(warmup):
+        g()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = g()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    if not torch.isfinite(loss).all():
+        raise SystemExit('non-finite loss (%s)' % w['desc'])
+    return ms, model, X
+
+
+def other_configs(a, dev, main_name):
+    """`extra.configs` of the line: configs[0] (the reference's CPU-runnable case and the north-star configuration, with the CPU
+    oracle timed beside it in both modes) and configs[2], plus the integrator-only figures of the headline workload; one GPU."""
+    out = {}
+    for name in dict.fromkeys(('cfg1', 'cfg3', main_name)):
+        w = WORKLOADS[name]
+        rec = {'workload': w['desc']}
+        ims, roll_ms, cpu_in = quick_integrator(w, dev, a.seed)
+        rec['integrator_ms'] = ims
+        rec['integrator_traj_per_s'] = w['batch'] / (ims * 1e-3)
+        rec['rollout_ms'] = roll_ms
+        rec['rollout_valu_frac'] = w['mflop'] * 1e6 * w['batch'] / (roll_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS
+        if name != main_name:
+            ems, model, X = quick_elbo(w, dev, a.seed)
+            rec['elbo_step_ms'] = ems
+            rec['elbo_traj_per_s'] = w['batch'] / (ems * 1e-3)
+            rec['elbo_step_frac'] = w['elbo_mflop'] * 1e6 * rec['elbo_traj_per_s'] / 1e12 / PEAK_FP32_TFLOPS
+        if name == 'cfg1' and not a.no_cpu_baseline:
+            rec['cpu_baseline_integrator'] = cpu_baseline(w, *cpu_in, budget_s=4.0)
+            rec['integrator_gpu_over_cpu'] = rec['integrator_traj_per_s'] / rec['cpu_baseline_integrator']['value']
+            if name != main_name:                    # (the headline workload's own ELBO step has its CPU leg in the main line)
+                rec['cpu_baseline_elbo'] = cpu_baseline_elbo(w, model, X, budget_s=6.0)
+                rec['elbo_gpu_over_cpu'] = rec['elbo_traj_per_s'] / rec['cpu_baseline_elbo']['value']
+        out[name] = rec
+        print('[bench] %s: %s' % (name, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in rec.items() if not isinstance(v, (dict, str))}),
+              file=sys.stderr, flush=True)
     return out
 
 

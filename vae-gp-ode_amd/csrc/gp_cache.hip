@@ -551,6 +551,183 @@ __global__ __launch_bounds__(256) void k_solve_back(const float* __restrict__ Aa
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_draw_lds: K(Z) + jitter I, its Cholesky factor and nu = L^-T (u - L^-1 f_prior(Z)) in ONE launch, one 512-thread
+// workgroup per system (RBF: one per output dimension; DF: the single (M D)^2 system), the whole matrix resident in LDS
+// (np <= 192: M <= 191 for RBF -- BASELINE configs[0], [2], [3]: six 128 x 128 systems of 66 KB).  Replaces the chain
+// k_Kzz + nblk x k_chol_rl + k_solve_back (6 dependent launches at M = 100, ~11 us each) by their sum of arithmetic (~20 us):
+//   fill      every thread evaluates kernel entries straight into LDS (tile rows >= tile columns), the rhs row n = f_prior(Z),
+//             identity padding -- the formulas of k_Kzz_rbf / k_Kzz_df, term for term
+//   factor    per block column k: wavefront w runs chol32_panel_wave on [D_k ; A_(k+1+w),k] (the register-resident fused
+//             factor + panel solve of k_chol_rl), results go back to LDS in place; then the trailing tiles A_ij -= L_ik L_jk^T
+//             on the matrix cores (v_mfma_f32_16x16x4_f32, operands read from LDS with row stride np + 2: the four 16-lane
+//             groups of an operand fetch hit disjoint banks), 16 x 16 quadrants dealt to the 8 wavefronts
+//   solve     block back-substitution in LDS (the wave-0 triangular solve of k_solve_back)
+//   publish   factor tiles to Lmat / Dfac (the backward's L^-1 and the optional Lu read them), nu to ws / output / pack
+// ---------------------------------------------------------------------------------------------
+template <int KERNEL>
+__global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, int np, int nblk, const float* __restrict__ Z,
+                                                   const float* __restrict__ ell, const float* __restrict__ var,
+                                                   const float* __restrict__ u_prior, const float* __restrict__ u,
+                                                   float* __restrict__ Lall, size_t batch_stride, float* __restrict__ Dfac_all,
+                                                   size_t dfac_stride, float* __restrict__ nu_ws, float* __restrict__ nu_out,
+                                                   float* __restrict__ pack_ind, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  const int LD = np + 2;
+  float* sA = dsm;                                   // [np][LD]
+  float* sv = dsm + (size_t)np * LD;                 // [np] residual / solution
+  float* sx = sv + np;                               // [NB]
+  float* sZ = sx + NB;                               // [M][Di]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int e = tid; e < M * Di; e += 512) sZ[e] = Z[e];
+  __syncthreads();
+  // ---- fill -----------------------------------------------------------------------------------
+  for (int e = tid; e < np * np; e += 512) {
+    const int r = e / np, c = e - r * np;
+    if ((r >> 5) < (c >> 5)) continue;               // tiles above the diagonal are never read
+    float v;
+    if (r < n && c < n) {
+      if (KERNEL == 0) {
+        float q = 0.f;
+        for (int i = 0; i < Di; ++i) {
+          const float t = (sZ[r * Di + i] - sZ[c * Di + i]) / ell[b * Di + i];
+          q = fmaf(t, t, q);
+        }
+        v = var[b] * expf(-0.5f * q) + (r == c ? kJitter : 0.f);
+      } else {
+        const int D = Do, nn = r / D, a = r % D, mm = c / D, bb = c % D;
+        float r2 = 0.f;
+        for (int i = 0; i < D; ++i) { const float t = sZ[mm * D + i] - sZ[nn * D + i]; r2 = fmaf(t, t, r2); }
+        const float l = ell[a * D + bb];
+        const float il2 = 1.f / (l * l);
+        const float da = sZ[mm * D + a] - sZ[nn * D + a], db = sZ[mm * D + bb] - sZ[nn * D + bb];
+        const float term = da * db * il2 + ((a == bb) ? ((float)(D - 1) - r2 * il2) : 0.f);
+        v = var[bb] * expf(-0.5f * r2 * il2) * term * il2 + (r == c ? kJitter : 0.f);
+      }
+    } else if (r == n) {
+      v = c < n ? (KERNEL == 0 ? u_prior[c * Do + b] : u_prior[c]) : (c == n ? 1e30f : 0.f);
+    } else {
+      v = (r == c) ? 1.f : 0.f;
+    }
+    sA[r * LD + c] = v;
+  }
+  __syncthreads();
+  // ---- factor ---------------------------------------------------------------------------------
+  const int lr = lane & 15, lk = lane >> 4;
+  for (int k = 0; k < nblk; ++k) {
+    const int c0 = k * NB, below = nblk - k - 1;     // panel tiles under the diagonal tile
+    // panel tiles are dealt round-robin to the wavefronts (np <= 192: at most 5, one round); wave 0 always runs (it owns D_k)
+    for (int t0 = 0; t0 < (below > 0 ? below : 1); t0 += 8) {
+      const int t = t0 + wave;
+      const bool active = t < below || (wave == 0 && t0 == 0);
+      float row[NB];
+      const bool panel = lane >= 32;
+      const int rr = lane & 31;
+      const int grow = panel ? (t < below ? (k + 1 + t) * NB + rr : c0 + rr) : c0 + rr;
+      if (active) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) row[c] = sA[grow * LD + c0 + c];
+      }
+      __syncthreads();                               // every wavefront holds its copy of D_k before anyone overwrites it
+      if (active) {
+        const bool bad = chol32_panel_wave(row, lane);
+        if (bad && wave == 0 && t0 == 0 && lane == 0) atomicOr(info, 1);
+        if (!panel) {
+          if (wave == 0 && t0 == 0) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) sA[grow * LD + c0 + c] = c <= rr ? row[c] : 0.f;
+          }
+        } else if (t < below) {
+#pragma unroll
+          for (int c = 0; c < NB; ++c) sA[grow * LD + c0 + c] = row[c];
+        }
+      }
+    }
+    __syncthreads();
+    // trailing update: tiles (i, j), k < j <= i < nblk, as 16 x 16 quadrants; job = (tile, quadrant)
+    const int T = below * (below + 1) / 2;
+    for (int job = wave; job < 4 * T; job += 8) {
+      const int tt = job >> 2, qd = job & 3;
+      int ii = (int)((sqrtf(8.f * (float)tt + 1.f) - 1.f) * 0.5f);
+      while ((ii + 1) * (ii + 2) / 2 <= tt) ++ii;
+      while (ii * (ii + 1) / 2 > tt) --ii;
+      const int i = k + 1 + ii, j = k + 1 + (tt - ii * (ii + 1) / 2);
+      const int r0 = i * NB + 16 * (qd >> 1), q0 = j * NB + 16 * (qd & 1);
+      cf32x4 acc = cf32x4{0.f, 0.f, 0.f, 0.f};
+      const float* pa = sA + (r0 + lr) * LD + c0 + lk;
+      const float* pb = sA + (q0 + lr) * LD + c0 + lk;
+#pragma unroll
+      for (int ks = 0; ks < NB / 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * ks], pb[4 * ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* dst = sA + (r0 + 4 * lk + r) * LD + q0 + lr;
+        *dst = *dst - acc[r];
+      }
+    }
+    __syncthreads();
+  }
+  // ---- nu = L^-T (u - y), y = row n of the factor ------------------------------------------------
+  for (int j = tid; j < np; j += 512)
+    sv[j] = j < n ? (KERNEL == 0 ? u[(size_t)j * Do + b] : u[j]) - sA[n * LD + j] : 0.f;
+  __syncthreads();
+  for (int k = cdiv(n, NB) - 1; k >= 0; --k) {
+    const int c0 = k * NB;
+    if (tid < 64) {
+      const int c = lane & 31;
+      float Lc[NB];
+#pragma unroll
+      for (int r = 0; r < NB; ++r) Lc[r] = sA[(c0 + r) * LD + c0 + c];
+      float res = sv[c0 + c];
+      float dg = 1.f;
+#pragma unroll
+      for (int r = 0; r < NB; ++r) dg = (r == c) ? Lc[r] : dg;   // static register indices only
+      const float myinv = 1.f / dg;
+#pragma unroll
+      for (int r = NB - 1; r >= 0; --r) {
+        const float t = res * myinv;                 // in lane r: x_r = res_r / L_rr (one broadcast per row instead of two)
+        float xr = GP_BCAST(t, r);
+        xr = (c0 + r < n) ? xr : 0.f;                // rows past n are padding (row n is the rhs row): x = 0
+        res = (c == r) ? xr : fmaf(-Lc[r], xr, res);
+      }
+      if (lane < NB) { sx[lane] = res; sv[c0 + lane] = res; }
+    }
+    __syncthreads();
+    for (int c = tid; c < c0; c += 512) {
+      float acc = sv[c];
+#pragma unroll 8
+      for (int r = 0; r < NB; ++r) acc = fmaf(-sA[(c0 + r) * LD + c], sx[r], acc);
+      sv[c] = acc;
+    }
+    __syncthreads();
+  }
+  // ---- publish --------------------------------------------------------------------------------
+  float* Lm = Lall + (size_t)b * batch_stride;
+  float* Dfac = Dfac_all + (size_t)b * dfac_stride;
+  for (int e = tid; e < np * np; e += 512) {
+    const int r = e / np, c = e - r * np, tr = r >> 5, tc = c >> 5;
+    if (tr > tc) Lm[(size_t)r * np + c] = sA[r * LD + c];
+    else if (tr == tc) Dfac[(size_t)tr * NB * NB + (r & 31) * NB + (c & 31)] = sA[r * LD + c];
+  }
+  for (int j = tid; j < n; j += 512) {
+    const float v = sv[j];
+    nu_ws[(size_t)b * n + j] = v;
+    if (nu_out) nu_out[(size_t)b * n + j] = v;
+    const int RQ2 = cdiv(Di + Do, 4);
+    int m, d;
+    float coef;
+    if (KERNEL == 0) { m = j; d = b; coef = var[d] * v; } else { m = j / Do; d = j % Do; coef = v; }
+    const int field = Di + d;
+    pack_ind[(((size_t)(m >> 6) * RQ2 + (field >> 2)) * 64 + (m & 63)) * 4 + (field & 3)] = coef;
+  }
+}
+
+// LDS bytes of k_draw_lds; it takes systems up to np = 192 (GPODE_DRAW_CHAIN=1 keeps the launch chain for every size: A/B switch)
+static inline size_t draw_lds_bytes(int np, int M, int Di) { return sizeof(float) * ((size_t)np * (np + 2) + np + NB + (size_t)M * Di); }
+static inline bool draw_in_lds(int np, int M, int Di) {
+  static const bool off = [] { const char* e = getenv("GPODE_DRAW_CHAIN"); return e && e[0] == '1'; }();
+  return !off && np <= 192 && draw_lds_bytes(np, M, Di) <= 160 * 1024;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Back-substitution for big factors (the single-workgroup kernel above is bandwidth-starved at n = 8192: 134 MB of L through
 // one CU).  One launch per 128-row panel, last panel first; workgroup c (<= P) owns residual entries 128 c .. 128 c + 127:
 //   launch P:  y_c -= L[panel P+1][cols c]^T nu[panel P+1]   (every workgroup; a 128 x 128 GEMV, coalesced along the columns)
@@ -725,6 +902,21 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
   float* Lmat = ws + w.Lmat;
   float* Dfac = ws + w.Dfac;
   const size_t bstride = (size_t)w.np * w.np, dstride = (size_t)w.nblk * NB * NB;
+  if (draw_in_lds(w.np, M, Di)) {
+    // small systems: kernel matrix, factorisation and both solves in one launch, LDS-resident
+    const size_t lds = draw_lds_bytes(w.np, M, Di);
+    if (kernel == 0) {
+      if (set_max_lds((const void*)k_draw_lds<0>, lds)) return 1;
+      hipLaunchKernelGGL(k_draw_lds<0>, w.batch, 512, lds, st, Di, Do, M, w.n, w.np, w.nblk, Z, ws + w.ell, ws + w.var, up, ws + w.u, Lmat,
+                         bstride, Dfac, dstride, ws + w.nu, nu, pack_ind, info);
+    } else {
+      if (set_max_lds((const void*)k_draw_lds<1>, lds)) return 1;
+      hipLaunchKernelGGL(k_draw_lds<1>, w.batch, 512, lds, st, Di, Do, M, w.n, w.np, w.nblk, Z, ws + w.ell, ws + w.var, up, ws + w.u, Lmat,
+                         bstride, Dfac, dstride, ws + w.nu, nu, pack_ind, info);
+    }
+    if (Lu) hipLaunchKernelGGL(k_copy_L, dim3(cdiv(w.n, 128), w.n, w.batch), 128, 0, st, Lmat, Dfac, dstride, w.n, w.np, bstride, Lu);
+    return check_launch("cache build (LDS-resident draw)");
+  }
   if (kernel == 0)
     hipLaunchKernelGGL(k_Kzz_rbf, dim3(cdiv(w.np, 128), w.np, Do), 128, 0, st, Di, Do, M, w.np, Z, ws + w.ell, ws + w.var, up, A);
   else
