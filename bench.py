@@ -404,7 +404,7 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
     if mode in ('whole', 'fwdbwd'):
         try:
             from vae_gp_ode_amd.graph import GraphedStep, device_generators
-            model.flow.odefunc.diffeq.noise_source.draw(w['kernel'], w['q'] * w['order'], w['q'], w['M'], w['S'], dev)  # creates the generator
+            model.flow.odefunc.diffeq.noise_source.generator(dev)   # exists before capture, so that it can be registered with the graph
             gens = device_generators(model)
             if mode == 'whole':
                 g = GraphedStep(whole_step if sync is None else dp_step, generators=gens, warmup=2)
@@ -527,7 +527,7 @@ def quick_elbo(w, dev, seed, steps=30, warmup=5):
         loss.backward()
         opt.step()
         return loss
-    model.flow.odefunc.diffeq.noise_source.draw(w['kernel'], w['q'] * w['order'], w['q'], w['M'], w['S'], dev)
+    model.flow.odefunc.diffeq.noise_source.generator(dev)
     g = GraphedStep(whole_step, generators=device_generators(model), warmup=2)
     for _ in range(warmup):
         g()

@@ -192,9 +192,12 @@ ZT_TOL = {'configs[0]': 5e-5, 'configs[1]': 5e-4, 'configs[2]': 5e-5}
 
 
 def test_configs4_forward_at_its_real_size():
-    """configs[4]: DF kernel, q = 16, M = 512 (an 8192 x 8192 K_uu), T = 64, 128 trajectories per GPU, 8192 decoded images:
-    GP draw + rollout + decoder forward vs the fp64 oracle.  Trajectories 1e-3 of max (cond(K_uu) ~ 1e5 and 252 RHS evaluations
-    amplify the fp32 factorisation error; the fp32 oracle's own distance is printed), reconstructions 1e-3."""
+    """configs[4]: DF kernel, q = 16, M = 512 (an 8192 x 8192 K_uu), T = 64, 128 trajectories per GPU, 8192 decoded images.
+    GP draw + rollout + decoder forward vs the pinned oracle in fp64 AND fp32.  At these shapes the latent ODE amplifies a
+    perturbation by ~2x every two steps (tools/debug_cfg5_fwd.py: the reference's own fp32 arithmetic is 7e-5 from fp64 at t = 16,
+    3e-2 at t = 40 and 0.6 at t = 63), so the trajectory tolerance is per time index: fixed 1e-4 (relative to max |z_t|) up to
+    t = 16, and from there never further from fp64 than 1.5x the fp32 oracle is.  The decoder (8192 images through the
+    matrix-core kernels, training-mode BatchNorm) is checked on the ORACLE's latents, where chaos plays no part: 1e-4."""
     from oracle import gpode_oracle as O
     _ref_threads()
     cfg = dict(kernel='DF', ode=1, q=16, M=512, S=256, T=64, N=128)
@@ -203,14 +206,29 @@ def test_configs4_forward_at_its_real_size():
     with torch.no_grad():
         Xrec64, zt64, _, _ = O.model_forward(X.double(), O.to_dtype(sd, torch.float64), [O.to_dtype(nz, torch.float64)], eps_s.double(), None,
                                              kernel='DF', order=1, method='rk4', dt=0.1)
+        s32 = O.to_dtype(sd, torch.float32)
+        mu, lv = O.encoder_forward(X[:, 0], s32, 'vae.encoder.')
+        c32 = O.build_cache(O.gp_params_from_state_dict(s32), nz, 'DF')
+        zt32 = O.flow_forward(O.reparam(mu, lv, eps_s), 0.1 * torch.arange(cfg['T'], dtype=torch.float), c32, 1, 'rk4')
         gp = m.flow.odefunc.diffeq
         gp.set_noise({k: v.cuda() for k, v in nz.items()})
         m.vae.encoder.next_eps = eps_s.cuda()
-        # the model's own forward, with the trajectories captured on the way to the decoder
         z0, _, _ = m.encode_initial_state(X.cuda())
         zt = m.sample_trajectories(z0, cfg['T'], 1)
-        Xrec = m.build_decoding(zt, (1, cfg['N'], cfg['T'], 1, 28, 28))
-    gp.cache.check_factorisation()
-    e_zt, e_x = relerr(zt, zt64), relerr(Xrec, Xrec64)
-    print('configs[4] N=128 T=64: trajectories %.1e, reconstructions %.1e from the fp64 oracle' % (e_zt, e_x))
-    assert e_zt < 1e-3 and e_x < 1e-3
+        gp.cache.check_factorisation()
+        Xrec = m.build_decoding(zt64.float().cuda(), (1, cfg['N'], cfg['T'], 1, 28, 28))
+    zt, zt64 = zt[0].double().cpu(), zt64[0]
+    worst_early = worst_ratio = 0.0
+    for t in range(cfg['T']):
+        sc = zt64[:, t].abs().max()
+        e_hip, e_ref = ((zt[:, t] - zt64[:, t]).abs().max() / sc).item(), ((zt32[:, t].double() - zt64[:, t]).abs().max() / sc).item()
+        if t <= 16:
+            worst_early = max(worst_early, e_hip)
+            assert e_hip < 1e-4, (t, e_hip, e_ref)
+        else:
+            worst_ratio = max(worst_ratio, e_hip / e_ref)
+            assert e_hip < 1.5 * e_ref, (t, e_hip, e_ref)
+    e_x = relerr(Xrec, Xrec64)
+    print('configs[4] N=128 T=64: trajectories <= %.1e up to t=16, then <= %.2f x the fp32 oracle\'s distance to fp64; '
+          'decoder on the oracle\'s latents %.1e' % (worst_early, worst_ratio, e_x))
+    assert e_x < 1e-4

@@ -277,7 +277,7 @@ def main(argv=None):
                 return out
             buf.copy_(minibatch)
             gp = model.flow.odefunc.diffeq
-            gp.noise_source.draw(gp.kernel_n, gp.D_in, gp.D_out, gp.M, gp.S, minibatch.device)   # creates the generator
+            gp.noise_source.generator(minibatch.device)          # exists before capture: registered with the graph, no draw consumed
             gs = GraphedStep(step, generators=device_generators(model), warmup=1,
                              grad_params=optimizer.params if sync is not None else None)
             graphs[key] = (buf, gs)

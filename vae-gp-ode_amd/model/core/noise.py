@@ -43,12 +43,17 @@ class DeviceNoise:
         self._gen = None
         self._device = device
 
-    def draw(self, kernel, Di, Do, M, S, device, dimwise=True):
+    def generator(self, device):
+        """The device generator (created on first use, WITHOUT consuming a draw): a HIP graph that replays draws must have it
+        registered before capture (graph.device_generators)."""
         if self._gen is None or self._gen.device != torch.device(device):
             self._gen = torch.Generator(device=device)
             self._gen.manual_seed(self.seed)
+        return self._gen
+
+    def draw(self, kernel, Di, Do, M, S, device, dimwise=True):
         sh = draw_shapes(kernel, Di, Do, M, S, dimwise)
-        g = self._gen
+        g = self.generator(device)
         # one launch for all normal draws (the three tensors are contiguous slices of one buffer), one for the uniform phase
         names = ('rff_w', 'rff_eps', 'eps_u')
         sizes = [int(np.prod(sh[k])) for k in names]
