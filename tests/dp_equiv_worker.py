@@ -1,5 +1,5 @@
 """Worker of tests/test_gpu_sync_bn.py: `steps` full training steps (encoder, GP draw, rk4 rollout, decoder, ELBO, backward,
-gradient all-reduce, Adam) on this rank's shard of a FIXED global minibatch, with every random input derived from the global
+gradient all-reduce, a normalised gradient step) on this rank's shard of a FIXED global minibatch, with every random input derived from the global
 batch (encoder noise eps[shard], one GP draw shared by all ranks).  Run with WORLD_SIZE = 1 it is the reference's single-process
 step on the whole minibatch; with WORLD_SIZE = N over gloo (all ranks on one card) the N-rank step.  Rank 0 saves gradients of the
 first step and the parameters / BatchNorm buffers after the last one."""
@@ -63,7 +63,13 @@ def main():
         if first_grads is None:
             first_grads = {k: flat[o:o + p.numel()].view_as(p).detach().cpu().clone()
                            for (k, p), o in zip([(k, p) for k, p in m.named_parameters() if p.requires_grad], opt.flat_grads.offsets)}
-        opt.step()
+        # A per-tensor normalised gradient step instead of Adam: Adam divides every entry by its own magnitude, so an entry whose
+        # gradient is round-off noise (the zero-initialised off-diagonals of Us_sqrt, 1e-9 of the largest) moves by +-lr whatever
+        # its sign -- that amplification is the optimiser's, not the data-parallel step's (HipAdam itself: test_gpu_optim.py).
+        with torch.no_grad():
+            for p, o in zip(opt.flat_grads.params, opt.flat_grads.offsets):
+                g = flat[o:o + p.numel()].view_as(p)
+                p.add_(g / (g.abs().max() + 1e-30), alpha=-1e-3 * float(p.abs().max()))
     torch.cuda.synchronize()
     if rank == 0:
         torch.save(dict(grads=first_grads, state={k: v.detach().cpu() for k, v in m.state_dict().items()}), out)

@@ -123,6 +123,9 @@ template <class L, int NCS_> struct BwdDataPolicy {
   }
 };
 
+// does the per-channel input-transform table fit the unused, 16-byte aligned tail of the channel planes?
+template <class PL> constexpr bool igemm_tf_in_pad() { return PL::PS % 4 == 0 && (PL::HP * PL::HP + 3) / 4 * 4 + 4 <= PL::PS; }
+
 // All k-steps (tap x 4*KB source channels) of NG pixel tiles x NCJ channel tiles of one wavefront.
 template <class CG, int NG, int TG, int NCJ, int KC, int WROW, int PS>
 __device__ __forceinline__ void igemm_tile_mma(const float* __restrict__ s_img, const float* __restrict__ sw, const int (&abase)[TG],
@@ -170,7 +173,7 @@ extern __shared__ __attribute__((aligned(16))) float igemm_smem[];
 // NCJ: channel tiles per job.  PAIR: process the px = 0 / px = 1 classes of a row parity together and store float2
 // (stride-2 layers with an even output width: without it every 64-byte line of y is written twice, half each time --
 // measured 401 MB of HBM writes for a 205 MB output).
-template <class PL, int IPB, int TG, int NCJ, bool PAIR, int NTHR>
+template <class PL, int IPB, int TG, int NCJ, bool PAIR, int NTHR, bool DB = false>
 __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y, int B,
                                                       const float* __restrict__ in_bn) {
@@ -187,23 +190,32 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
   constexpr int SRC = KC * SH * SH;                  // floats per source image
   static_assert(SRC % 4 == 0, "float4 source fetch");
   constexpr int NLD = (IPB * SRC / 4 + NTHR - 1) / NTHR;   // float4 fetches per thread per group
-  float* s_img = igemm_smem;                         // [IPB][KC][PS] zero padded planes
-  float* s_w = igemm_smem + IPB * IMG;               // [cls][tap][KC][WROW]
+  constexpr int NBUF = DB ? 2 : 1;
+  float* s_img = igemm_smem;                         // [NBUF][IPB][KC][PS] zero padded planes
+  float* s_w = igemm_smem + NBUF * IPB * IMG;        // [cls][tap][KC][WROW]
   // in_bn ([KC][4] = mean, invstd, gamma, beta per source channel): the source is the raw output of the previous
   // convolution and the BatchNorm + ReLU that follows it is applied while the images are scattered to LDS, so the
   // normalised activation never goes through HBM (the zero padding is written once and stays zero)
-  float4* s_tf = reinterpret_cast<float4*>(s_w + PL::WSLAB);
+  // The table lives in the unused tail of image 0's channel planes when there is room (plane c holds HP * HP floats of its PS;
+  // entry c sits 16-byte aligned behind them, where no operand fetch reaches) -- the footprint is then planes + slabs exactly,
+  // which is what lets two 256-thread workgroups of the decnn.7 forward share a CU (2 x 80 KB) -- otherwise behind the slabs.
+  constexpr int TFO = (HP * HP + 3) / 4 * 4;
+  constexpr bool TF_PAD = igemm_tf_in_pad<PL>();
+  float4* s_tf_tail = reinterpret_cast<float4*>(s_w + PL::WSLAB);
+  auto tf_slot = [&](int ch) -> float4* { return TF_PAD ? reinterpret_cast<float4*>(s_img + ch * PS + TFO) : s_tf_tail + ch; };
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
   const int ngroups = (B + IPB - 1) / IPB;
   const float4* x4 = reinterpret_cast<const float4*>(x);
-  if (in_bn)
-    for (int e = tid; e < KC; e += NTHR) s_tf[e] = reinterpret_cast<const float4*>(in_bn)[e];
   // wavefront w runs on SIMD w & 3: order the wavefronts SIMD-major so that each SIMD owns a contiguous cost range
   const int jw = (wave & 3) * (NW / 4) + (wave >> 2);
 
   PROBE_T(pt_all);
-  for (int e = tid; e < IPB * IMG / 4; e += NTHR) reinterpret_cast<float4*>(s_img)[e] = float4{0.f, 0.f, 0.f, 0.f};
+  for (int e = tid; e < NBUF * IPB * IMG / 4; e += NTHR) reinterpret_cast<float4*>(s_img)[e] = float4{0.f, 0.f, 0.f, 0.f};
+  if (in_bn) {
+    if (TF_PAD) __syncthreads();                     // the zero fill above covers the slots
+    for (int e = tid; e < KC; e += NTHR) *tf_slot(e) = reinterpret_cast<const float4*>(in_bn)[e];
+  }
 
   // NC / NCS passes over the output channels.  When the grid divides evenly the passes are spread over the workgroups
   // (each stages ONE slab and walks every image group with its share of the grid); otherwise every workgroup loops.
@@ -241,33 +253,24 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
         if (f < nf4) pre[i] = src[f];
       }
     };
-    if (gfirst < ngroups) prefetch(gfirst);
-    for (int grp = gfirst; grp < ngroups; grp += gstride) {
-      const int b0 = grp * IPB;
-      const int nimg = min(IPB, B - b0);
-      PROBE_T(pt_b1);
-      __syncthreads();                               // previous group's MFMAs have read s_img; zero fill / slabs staged
-      PROBE_ADD(1, pt_b1);
-      PROBE_T(pt_sc);
-      {
-        const int nf4 = nimg * (SRC / 4);
+    // the prefetched source group -> zero-padded planes (BatchNorm + ReLU on the way when in_bn)
+    auto scatter = [&](float* __restrict__ img, int nimg) {
+      const int nf4 = nimg * (SRC / 4);
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-          const int f = tid + NTHR * i;
-          if (f < nf4) {
-            const float v[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+      for (int i = 0; i < NLD; ++i) {
+        const int f = tid + NTHR * i;
+        if (f < nf4) {
+          const float v[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int e = 4 * f + k, pl = e / (SH * SH), q = e % (SH * SH);
-              s_img[pl * PS + (q / SH + PADL) * HP + q % SH + PADL] = in_bn ? bn_relu(v[k], s_tf[pl % KC]) : v[k];
-            }
+          for (int k = 0; k < 4; ++k) {
+            const int e = 4 * f + k, pl = e / (SH * SH), q = e % (SH * SH);
+            img[pl * PS + (q / SH + PADL) * HP + q % SH + PADL] = in_bn ? bn_relu(v[k], *tf_slot(pl % KC)) : v[k];
           }
         }
       }
-      __syncthreads();
-      PROBE_ADD(2, pt_sc);
-      if (grp + gstride < ngroups) prefetch(grp + gstride);
-
+    };
+    // all (class, pixel tile, channel-tile column) jobs of this wavefront for the group staged in `img`
+    auto jobs = [&](const float* __restrict__ img, int b0, int nimg) {
       // cost (k-steps) of all jobs of the group, and this wavefront's share [lo, hi) of it
       int wtot = 0;
       // class groups: a class on its own, or (PAIR) the two column-parity classes of one row parity, whose pixels
@@ -324,10 +327,10 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
           auto run = [&](auto gtag, const float* sw, const int (&ab)[TG], f32x4 (&ac)[TG][NCJ]) {
             using GG = typename decltype(gtag)::type;
             switch (ng) {                            // wave-uniform
-              case 1: igemm_tile_mma<GG, 1, TG, NCJ, KC, WROW, PS>(s_img, sw, ab, lk, lr, ac); break;
-              case 2: if constexpr (TG >= 2) igemm_tile_mma<GG, 2, TG, NCJ, KC, WROW, PS>(s_img, sw, ab, lk, lr, ac); break;
-              case 3: if constexpr (TG >= 3) igemm_tile_mma<GG, 3, TG, NCJ, KC, WROW, PS>(s_img, sw, ab, lk, lr, ac); break;
-              default: if constexpr (TG >= 4) igemm_tile_mma<GG, 4, TG, NCJ, KC, WROW, PS>(s_img, sw, ab, lk, lr, ac); break;
+              case 1: igemm_tile_mma<GG, 1, TG, NCJ, KC, WROW, PS>(img, sw, ab, lk, lr, ac); break;
+              case 2: if constexpr (TG >= 2) igemm_tile_mma<GG, 2, TG, NCJ, KC, WROW, PS>(img, sw, ab, lk, lr, ac); break;
+              case 3: if constexpr (TG >= 3) igemm_tile_mma<GG, 3, TG, NCJ, KC, WROW, PS>(img, sw, ab, lk, lr, ac); break;
+              default: if constexpr (TG >= 4) igemm_tile_mma<GG, 4, TG, NCJ, KC, WROW, PS>(img, sw, ab, lk, lr, ac); break;
             }
           };
           run(std::common_type<G>{}, swc + jc * NCJ * 16, abase, acc);
@@ -356,6 +359,51 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
           PROBE_ADD(4, pt_st);
         }
       });
+    };
+    if constexpr (!DB) {
+      if (gfirst < ngroups) prefetch(gfirst);
+      for (int grp = gfirst; grp < ngroups; grp += gstride) {
+        const int b0 = grp * IPB;
+        const int nimg = min(IPB, B - b0);
+        PROBE_T(pt_b1);
+        __syncthreads();                             // previous group's MFMAs have read s_img; zero fill / slabs staged
+        PROBE_ADD(1, pt_b1);
+        PROBE_T(pt_sc);
+        scatter(s_img, nimg);
+        __syncthreads();
+        PROBE_ADD(2, pt_sc);
+        if (grp + gstride < ngroups) prefetch(grp + gstride);
+        jobs(s_img, b0, nimg);
+      }
+    } else {
+      // Double-buffered planes, ONE barrier per group: while a group is multiplied out of one buffer the next one is
+      // scattered into the other.  The two wavefronts of a SIMD (w and w + NW/2) take the scatter at opposite ends of
+      // the group -- one before its jobs, one after -- so that on every SIMD one wavefront's scatter / global stores run
+      // under the other's MFMAs instead of all eight scattering, multiplying and storing in lockstep.
+      const bool early = wave < NW / 2;
+      int cur = 0;
+      if (gfirst < ngroups) prefetch(gfirst);
+      __syncthreads();                               // zero fill, slabs, table
+      if (gfirst < ngroups) scatter(s_img, min(IPB, B - gfirst * IPB));
+      if (gfirst + gstride < ngroups) prefetch(gfirst + gstride);
+      __syncthreads();
+      for (int grp = gfirst; grp < ngroups; grp += gstride) {
+        const int b0 = grp * IPB, nxt = grp + gstride;
+        const int nimg = min(IPB, B - b0);
+        float* bc = s_img + cur * (IPB * IMG);
+        float* bn = s_img + (cur ^ 1) * (IPB * IMG);
+        if (early && nxt < ngroups) {
+          scatter(bn, min(IPB, B - nxt * IPB));
+          if (nxt + gstride < ngroups) prefetch(nxt + gstride);
+        }
+        jobs(bc, b0, nimg);
+        if (!early && nxt < ngroups) {
+          scatter(bn, min(IPB, B - nxt * IPB));
+          if (nxt + gstride < ngroups) prefetch(nxt + gstride);
+        }
+        __syncthreads();                             // next buffer complete; this one free for the group after next
+        cur ^= 1;
+      }
     }
   }
   PROBE_ADD(5, pt_all);
@@ -596,8 +644,8 @@ __global__ __launch_bounds__(1024) void k_sum_splits4(const float* __restrict__ 
   }
 }
 
-template <class PL, int IPB> constexpr size_t igemm_lds_bytes() {   // planes + weight slabs + the optional input-transform table
-  return sizeof(float) * ((size_t)IPB * PL::KC * PL::PS + (size_t)PL::WSLAB + (size_t)4 * PL::KC);
+template <class PL, int IPB, bool DB = false> constexpr size_t igemm_lds_bytes() {   // planes + weight slabs (+ the input-transform table when it does not fit the plane tails)
+  return sizeof(float) * ((size_t)(DB ? 2 : 1) * IPB * PL::KC * PL::PS + (size_t)PL::WSLAB + (igemm_tf_in_pad<PL>() ? 0 : (size_t)4 * PL::KC));
 }
 
 }  // namespace gp

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstdint>
 #include "gp_launch.hpp"
+#include <type_traits>
 #include "conv_mfma.hpp"
 #include "conv_dec10_mfma.hpp"
 

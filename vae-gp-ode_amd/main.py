@@ -60,6 +60,7 @@ EXT_FLAGS = [
     ('hip_graph', eval, False, 'replay each training step as one captured HIP graph, GP chains on a side stream, GP noise drawn '
                                'on the device (INTEGRATION.md); the reference draws GP noise from host numpy generators'),
     ('device_noise', eval, False, 'draw the GP noise on the device (seeded identically on every rank) without --hip_graph'),
+    ('gp_side_stream', eval, False, 'GP cache build / cache backward on a side stream next to the encoder, without --hip_graph'),
     ('sync_bn', eval, True, 'data parallel: BatchNorm normalises with the statistics of the GLOBAL minibatch (all ranks), as the '
                             'single-process reference does (vae.py:55,58,113,116,119)'),
 ]
@@ -255,6 +256,9 @@ def main(argv=None):
     elif args.device_noise:
         from .model.core.noise import DeviceNoise
         model.flow.odefunc.diffeq.noise_source = DeviceNoise(args.seed + 1)
+    if args.gp_side_stream and not args.hip_graph:
+        from . import ops
+        ops.set_overlap(True)
 
     # gloo's collectives are host code: a step that holds them (cross-rank BatchNorm) cannot be stream-captured
     capture_ok = not (bn_sync is not None and dist.get_backend() != 'nccl')
