@@ -68,8 +68,8 @@ def main():
         # its sign -- that amplification is the optimiser's, not the data-parallel step's (HipAdam itself: test_gpu_optim.py).
         with torch.no_grad():
             for p, o in zip(opt.flat_grads.params, opt.flat_grads.offsets):
-                g = flat[o:o + p.numel()].view_as(p)
-                p.add_(g / (g.abs().max() + 1e-30), alpha=-1e-3 * float(p.abs().max()))
+                gr = flat[o:o + p.numel()].view_as(p)
+                p.add_(gr / (gr.abs().max() + 1e-30), alpha=-1e-3 * float(p.abs().max()))
     torch.cuda.synchronize()
     if rank == 0:
         torch.save(dict(grads=first_grads, state={k: v.detach().cpu() for k, v in m.state_dict().items()}), out)

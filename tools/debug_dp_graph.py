@@ -20,8 +20,8 @@ def run(tmp, tag, world, extra, port):
 
 tmp = tempfile.mkdtemp()
 runs = {}
-for tag, world, extra, port in (('e2', 2, ['--device_noise', 'True'], 29571), ('e2o', 2, ['--device_noise', 'True', '--gp_side_stream', 'True'], 29573),
-                                ('g2', 2, ['--hip_graph', 'True'], 29572)):
+for tag, world, extra, port in (('e2', 2, ['--device_noise', 'True'], 29571), ('g2a', 2, ['--hip_graph', 'True'], 29572),
+                                ('g2b', 2, ['--hip_graph', 'True'], 29574), ('g2c', 2, ['--hip_graph', 'True'], 29575)):
     runs[tag] = run(tmp, tag, world, extra, port)
 n = min(len(v) for v in runs.values())
 print('iter   ' + '   '.join('%12s' % k for k in runs))

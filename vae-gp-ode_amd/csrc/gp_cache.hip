@@ -240,7 +240,7 @@ __global__ void k_Kzz_df(int D, int M, int np, const float* __restrict__ Z, cons
 // gfx950 needs wait states between a VALU SGPR write and a VALU read of that SGPR; hipcc does not see
 // inside asm, so every group pads itself: in a full group the later v_readlane are the padding, short
 // tail groups end in an explicit s_nop.
-template <int J, int C> __device__ __forceinline__ void chol_cols(float (&row)[NB], float nsc) {
+template <int J, int C> __device__ __forceinline__ void chol_cols_group(float (&row)[NB], float nsc) {
   if constexpr (C < NB) {
     constexpr int G = (NB - C) < 4 ? (NB - C) : 4;
     float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
@@ -263,27 +263,48 @@ template <int J, int C> __device__ __forceinline__ void chol_cols(float (&row)[N
     if constexpr (G > 1) row[C + 1] = fmaf(nsc, l1, row[C + 1]);
     if constexpr (G > 2) row[C + 2] = fmaf(nsc, l2, row[C + 2]);
     if constexpr (G > 3) row[C + 3] = fmaf(nsc, l3, row[C + 3]);
+  }
+}
+
+template <int J, int C> __device__ __forceinline__ void chol_cols(float (&row)[NB], float nsc) {
+  if constexpr (C < NB) {
+    chol_cols_group<J, C>(row, nsc);
     chol_cols<J, C + 4>(row, nsc);
   }
 }
 
-template <int J> __device__ __forceinline__ void chol_pivots(float (&row)[NB], int lane, bool& bad) {
+// 1 / sqrt(piv) to full fp32 accuracy (v_rsq + one Newton step)
+__device__ __forceinline__ float chol_rsqrt(float piv) {
+  float inv = __builtin_amdgcn_rsqf(piv);
+  return inv * (1.5f - 0.5f * piv * inv * inv);
+}
+
+// Pivot J.  Its scalar chain (broadcast of the diagonal, v_rsq, Newton step: ~8 dependent instructions, 60-80 cycles for a
+// lone wavefront) was computed by pivot J-1 right after J-1's update of column J -- i.e. under J-1's remaining column updates,
+// which do not depend on it -- and arrives as (piv, inv).  Same operations on the same values in the same order per element as
+// the straight loop: results are bit-identical.
+template <int J> __device__ __forceinline__ void chol_pivots(float (&row)[NB], int lane, bool& bad, float piv, float inv) {
   if constexpr (J < NB) {
-    const float piv = GP_BCAST(row[J], J);
-    bad |= !(piv > 0.f);
-    float inv = __builtin_amdgcn_rsqf(piv);
-    inv = inv * (1.5f - 0.5f * piv * inv * inv);  // one Newton step: full fp32 accuracy
     const float sc = row[J] * inv;
     row[J] = (lane == J) ? piv * inv : sc;
-    chol_cols<J, J + 1>(row, -row[J]);
-    chol_pivots<J + 1>(row, lane, bad);
+    const float nsc = -row[J];
+    float piv_n = 1.f, inv_n = 1.f;
+    if constexpr (J + 1 < NB) {
+      chol_cols_group<J, J + 1>(row, nsc);           // columns J+1 .. J+4: column J+1 is final for pivot J+1
+      piv_n = GP_BCAST(row[J + 1], J + 1);
+      bad |= !(piv_n > 0.f);
+      inv_n = chol_rsqrt(piv_n);
+      chol_cols<J, J + 5>(row, nsc);                 // the other columns, independent of the chain above
+    }
+    chol_pivots<J + 1>(row, lane, bad, piv_n, inv_n);
   }
 }
 
 // returns true when a pivot was not positive (matrix not positive definite)
 __device__ __forceinline__ bool chol32_panel_wave(float (&row)[NB], int lane) {
-  bool bad = false;
-  chol_pivots<0>(row, lane, bad);
+  const float piv = GP_BCAST(row[0], 0);
+  bool bad = !(piv > 0.f);
+  chol_pivots<0>(row, lane, bad, piv, chol_rsqrt(piv));
   return bad;
 }
 
@@ -564,6 +585,13 @@ __global__ __launch_bounds__(256) void k_solve_back(const float* __restrict__ Aa
 //   solve     block back-substitution in LDS (the wave-0 triangular solve of k_solve_back)
 //   publish   factor tiles to Lmat / Dfac (the backward's L^-1 and the optional Lu read them), nu to ws / output / pack
 // ---------------------------------------------------------------------------------------------
+// phase timing (tools/draw_probe.py builds the library with -DDRAW_PROBE; compiled out otherwise)
+#ifdef DRAW_PROBE
+#define DPROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const long long t_ = clock64(); dprobe[i] += t_ - dlast; dlast = t_; } } while (0)
+#else
+#define DPROBE(i)
+#endif
+
 template <int KERNEL>
 __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, int np, int nblk, const float* __restrict__ Z,
                                                    const float* __restrict__ ell, const float* __restrict__ var,
@@ -578,39 +606,57 @@ __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, 
   float* sx = sv + np;                               // [NB]
   float* sZ = sx + NB;                               // [M][Di]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int e = tid; e < M * Di; e += 512) sZ[e] = Z[e];
-  __syncthreads();
-  // ---- fill -----------------------------------------------------------------------------------
-  for (int e = tid; e < np * np; e += 512) {
-    const int r = e / np, c = e - r * np;
-    if ((r >> 5) < (c >> 5)) continue;               // tiles above the diagonal are never read
-    float v;
-    if (r < n && c < n) {
-      if (KERNEL == 0) {
-        float q = 0.f;
-        for (int i = 0; i < Di; ++i) {
-          const float t = (sZ[r * Di + i] - sZ[c * Di + i]) / ell[b * Di + i];
-          q = fmaf(t, t, q);
-        }
-        v = var[b] * expf(-0.5f * q) + (r == c ? kJitter : 0.f);
-      } else {
-        const int D = Do, nn = r / D, a = r % D, mm = c / D, bb = c % D;
-        float r2 = 0.f;
-        for (int i = 0; i < D; ++i) { const float t = sZ[mm * D + i] - sZ[nn * D + i]; r2 = fmaf(t, t, r2); }
-        const float l = ell[a * D + bb];
-        const float il2 = 1.f / (l * l);
-        const float da = sZ[mm * D + a] - sZ[nn * D + a], db = sZ[mm * D + bb] - sZ[nn * D + bb];
-        const float term = da * db * il2 + ((a == bb) ? ((float)(D - 1) - r2 * il2) : 0.f);
-        v = var[bb] * expf(-0.5f * r2 * il2) * term * il2 + (r == c ? kJitter : 0.f);
-      }
-    } else if (r == n) {
-      v = c < n ? (KERNEL == 0 ? u_prior[c * Do + b] : u_prior[c]) : (c == n ? 1e30f : 0.f);
-    } else {
-      v = (r == c) ? 1.f : 0.f;
-    }
-    sA[r * LD + c] = v;
+#ifdef DRAW_PROBE
+  long long dprobe[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = clock64();
+#endif
+  // Z transposed ([i][m], row stride M | 1: the per-lane column reads below are conflict-free) and the per-system constants
+  const int ZS = M | 1;
+  for (int e = tid; e < M * Di; e += 512) sZ[(e % Di) * ZS + e / Di] = Z[e];
+  float* sC = sZ + (size_t)Di * ZS;                  // RBF: 1 / ell[b][i]; DF: 1 / ell[a][bb]^2 then var[bb]
+  if (KERNEL == 0) {
+    for (int e = tid; e < Di; e += 512) sC[e] = 1.f / ell[b * Di + e];
+  } else {
+    for (int e = tid; e < Do * Do; e += 512) { const float l = ell[e]; sC[e] = 1.f / (l * l); }
+    for (int e = tid; e < Do; e += 512) sC[Do * Do + e] = var[e];
   }
   __syncthreads();
+  // ---- fill: wavefront w takes rows w, w + 8, ...; its lanes the columns lane, lane + 64, ... of the tiles at or below the
+  // row's diagonal tile.  The row's inducing point is wave-uniform (LDS broadcast), the column's is read once per chunk.
+  {
+    const float vb = KERNEL == 0 ? var[b] : 0.f;
+    for (int r = wave; r < np; r += 8) {
+      const int cend = ((r >> 5) + 1) * NB;          // first column right of the diagonal tile
+      const int nn = KERNEL == 0 ? r : r / Do, a = KERNEL == 0 ? 0 : r - nn * Do;
+      for (int c = lane; c < cend; c += 64) {
+        float v;
+        if (r < n && c < n) {
+          if (KERNEL == 0) {
+            float q = 0.f;
+            for (int i = 0; i < Di; ++i) {
+              const float t = (sZ[i * ZS + r] - sZ[i * ZS + c]) * sC[i];
+              q = fmaf(t, t, q);
+            }
+            v = vb * expf(-0.5f * q) + (r == c ? kJitter : 0.f);
+          } else {
+            const int D = Do, mm = c / D, bb = c - mm * D;
+            float r2 = 0.f;
+            for (int i = 0; i < D; ++i) { const float t = sZ[i * ZS + mm] - sZ[i * ZS + nn]; r2 = fmaf(t, t, r2); }
+            const float il2 = sC[a * D + bb];
+            const float da = sZ[a * ZS + mm] - sZ[a * ZS + nn], db = sZ[bb * ZS + mm] - sZ[bb * ZS + nn];
+            const float term = da * db * il2 + ((a == bb) ? ((float)(D - 1) - r2 * il2) : 0.f);
+            v = sC[D * D + bb] * expf(-0.5f * r2 * il2) * term * il2 + (r == c ? kJitter : 0.f);
+          }
+        } else if (r == n) {
+          v = c < n ? (KERNEL == 0 ? u_prior[c * Do + b] : u_prior[c]) : (c == n ? 1e30f : 0.f);
+        } else {
+          v = (r == c) ? 1.f : 0.f;
+        }
+        sA[r * LD + c] = v;
+      }
+    }
+  }
+  __syncthreads();
+  DPROBE(0);
   // ---- factor ---------------------------------------------------------------------------------
   const int lr = lane & 15, lk = lane >> 4;
   for (int k = 0; k < nblk; ++k) {
@@ -643,6 +689,7 @@ __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, 
       }
     }
     __syncthreads();
+    DPROBE(1);
     // trailing update: tiles (i, j), k < j <= i < nblk, as 16 x 16 quadrants; job = (tile, quadrant)
     const int T = below * (below + 1) / 2;
     for (int job = wave; job < 4 * T; job += 8) {
@@ -664,6 +711,7 @@ __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, 
       }
     }
     __syncthreads();
+    DPROBE(2);
   }
   // ---- nu = L^-T (u - y), y = row n of the factor ------------------------------------------------
   for (int j = tid; j < np; j += 512)
@@ -699,13 +747,17 @@ __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, 
     }
     __syncthreads();
   }
+  DPROBE(3);
   // ---- publish --------------------------------------------------------------------------------
   float* Lm = Lall + (size_t)b * batch_stride;
   float* Dfac = Dfac_all + (size_t)b * dfac_stride;
-  for (int e = tid; e < np * np; e += 512) {
-    const int r = e / np, c = e - r * np, tr = r >> 5, tc = c >> 5;
-    if (tr > tc) Lm[(size_t)r * np + c] = sA[r * LD + c];
-    else if (tr == tc) Dfac[(size_t)tr * NB * NB + (r & 31) * NB + (c & 31)] = sA[r * LD + c];
+  for (int r = wave; r < np; r += 8) {               // a wavefront writes runs of 64 consecutive floats of one row
+    const int tr = r >> 5, cend = (tr + 1) * NB;
+    for (int c = lane; c < cend; c += 64) {
+      const float v = sA[r * LD + c];
+      if ((c >> 5) < tr) Lm[(size_t)r * np + c] = v;
+      else Dfac[(size_t)tr * NB * NB + (r & 31) * NB + (c & 31)] = v;
+    }
   }
   for (int j = tid; j < n; j += 512) {
     const float v = sv[j];
@@ -718,10 +770,19 @@ __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, 
     const int field = Di + d;
     pack_ind[(((size_t)(m >> 6) * RQ2 + (field >> 2)) * 64 + (m & 63)) * 4 + (field & 3)] = coef;
   }
+#ifdef DRAW_PROBE
+  __syncthreads();
+  DPROBE(4);
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    printf("k_draw_lds cycles: fill %lld  factor+solve-panel %lld  trailing %lld  back-subst %lld  publish %lld\n", dprobe[0], dprobe[1],
+           dprobe[2], dprobe[3], dprobe[4]);
+#endif
 }
 
 // LDS bytes of k_draw_lds; it takes systems up to np = 192 (GPODE_DRAW_CHAIN=1 keeps the launch chain for every size: A/B switch)
-static inline size_t draw_lds_bytes(int np, int M, int Di) { return sizeof(float) * ((size_t)np * (np + 2) + np + NB + (size_t)M * Di); }
+static inline size_t draw_lds_bytes(int np, int M, int Di) {   // sA, sv, sx, Z transposed, constants (<= Di * Di + Di)
+  return sizeof(float) * ((size_t)np * (np + 2) + np + NB + (size_t)Di * (M | 1) + (size_t)Di * Di + Di);
+}
 static inline bool draw_in_lds(int np, int M, int Di) {
   static const bool off = [] { const char* e = getenv("GPODE_DRAW_CHAIN"); return e && e[0] == '1'; }();
   return !off && np <= 192 && draw_lds_bytes(np, M, Di) <= 160 * 1024;

@@ -44,10 +44,15 @@ class HipAdam:
         self.total = tot
         tab = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)
         self._p, self._m, self._v = tab(self.params), tab(self.exp_avg), tab(self.exp_avg_sq)
-        # gradient pointer table: refreshed through a pinned staging buffer (an async copy, legal inside graph capture)
-        self._g = torch.zeros(len(self.params), dtype=torch.int64, device=dev)
-        self._g_host = torch.zeros(len(self.params), dtype=torch.int64).pin_memory()
-        self._gptrs = None
+        # gradient pointer tables: one small device tensor per distinct set of gradient addresses, uploaded ONCE (the first time
+        # the set is seen) and kept.  Graph replays hand over the same tensors every time and the eager allocator cycles through
+        # a few sets, so the steady state uploads nothing.  (A single table refreshed through one pinned staging buffer is a race:
+        # the host may overwrite the staging buffer for step i+1 before the device has run step i's asynchronous copy.)
+        self._tables = {}
+        self._g = None
+        # pinned sources for tables uploaded INSIDE a graph capture (allocating pinned memory is not a capturable call): one per
+        # captured graph that holds the update
+        self._pinned = [torch.zeros(len(self.params), dtype=torch.int64).pin_memory() for _ in range(8)]
         self._offs = torch.tensor(offs, dtype=torch.int64, device=dev)
         if self.gather:                              # the update reads the (all-reduced) bucket: a static table of pointers into it
             base = self.flat_grads.flat.data_ptr()
@@ -75,10 +80,25 @@ class HipAdam:
             elif not g.is_contiguous() or g.dtype != torch.float32:
                 raise _lib.GpodeError('HipAdam: gradients must be contiguous float32')
             cur.append(g.data_ptr())
-        if cur != self._gptrs:  # a gradient tensor was replaced: refresh the table
-            self._g_host.copy_(torch.tensor(cur, dtype=torch.int64))
-            self._g.copy_(self._g_host, non_blocking=True)
-            self._gptrs = cur
+        key = tuple(cur)
+        tab = self._tables.get(key)
+        if tab is None:
+            if len(self._tables) >= 256:             # an allocator that never repeats itself: do not grow without bound
+                self._tables.clear()
+            if torch.cuda.is_current_stream_capturing():
+                # inside a capture the upload must be a node of the graph: pinned source kept alive with the table
+                if not self._pinned:
+                    raise _lib.GpodeError('HipAdam: more than 8 captured graphs hold the update; create the optimiser with more staging buffers')
+                host = self._pinned.pop()
+                host.copy_(torch.tensor(cur, dtype=torch.int64))
+                tab = torch.empty(len(cur), dtype=torch.int64, device=self._p.device)
+                tab.copy_(host, non_blocking=True)
+                self._tables[key] = (tab, host)
+            else:
+                tab = torch.tensor(cur, dtype=torch.int64, device=self._p.device)   # synchronous upload, once per set
+                self._tables[key] = (tab, None)
+            tab = self._tables[key]
+        self._g = tab[0]
 
     def gather_grads(self):
         """bucketed='gather': fill the flat bucket from the gradients autograd produced (one launch)."""
