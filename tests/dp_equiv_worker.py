@@ -63,13 +63,13 @@ def main():
         if first_grads is None:
             first_grads = {k: flat[o:o + p.numel()].view_as(p).detach().cpu().clone()
                            for (k, p), o in zip([(k, p) for k, p in m.named_parameters() if p.requires_grad], opt.flat_grads.offsets)}
-        # A per-tensor normalised gradient step instead of Adam: Adam divides every entry by its own magnitude, so an entry whose
-        # gradient is round-off noise (the zero-initialised off-diagonals of Us_sqrt, 1e-9 of the largest) moves by +-lr whatever
-        # its sign -- that amplification is the optimiser's, not the data-parallel step's (HipAdam itself: test_gpu_optim.py).
+        # A plain gradient step (one global scale) instead of Adam: Adam divides every entry by its own magnitude, so an entry whose
+        # gradient is round-off noise (the zero-initialised off-diagonals of Us_sqrt, the biases in front of a BatchNorm) moves by
+        # +-lr whatever its sign -- that amplification is the optimiser's, not the data-parallel step's (HipAdam: test_gpu_optim.py).
         with torch.no_grad():
+            scale = 1e-3 / float(flat.abs().max())
             for p, o in zip(opt.flat_grads.params, opt.flat_grads.offsets):
-                gr = flat[o:o + p.numel()].view_as(p)
-                p.add_(gr / (gr.abs().max() + 1e-30), alpha=-1e-3 * float(p.abs().max()))
+                p.add_(flat[o:o + p.numel()].view_as(p), alpha=-scale * float(p.abs().max()))
     torch.cuda.synchronize()
     if rank == 0:
         torch.save(dict(grads=first_grads, state={k: v.detach().cpu() for k, v in m.state_dict().items()}), out)

@@ -15,6 +15,7 @@
 // barriers), inverts it, and applies the inverse to its block.  The right-hand side f_prior(Z) is
 // appended as row n of the matrix, so the forward substitution L^-1 f_prior(Z) falls out of the
 // panel solves for free (row n of the factor); only the transposed solve runs as its own kernel.
+#include <type_traits>
 #include "gp_eval.hpp"
 #include "gp_launch.hpp"
 #include "wave_reduce.hpp"
@@ -622,29 +623,70 @@ __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, 
   __syncthreads();
   // ---- fill: wavefront w takes rows w, w + 8, ...; its lanes the columns lane, lane + 64, ... of the tiles at or below the
   // row's diagonal tile.  The row's inducing point is wave-uniform (LDS broadcast), the column's is read once per chunk.
-  {
+  // The coordinate loop is unrolled for the compiled latent widths (a runtime trip count serialises one LDS round trip per
+  // coordinate: 19 of the kernel's first 55 us).
+  auto fill = [&](auto dtag) {
+    constexpr int DC = decltype(dtag)::value;        // compile-time Di, or 0: runtime
+    constexpr int DA = DC > 0 ? DC : 1;
+    const int DIr = DC > 0 ? DC : Di;
     const float vb = KERNEL == 0 ? var[b] : 0.f;
+    // the lane's columns are the same for every row: their inducing points (and, RBF, the inverse lengthscales) stay in
+    // registers when the width is a compile-time constant; only the row's point is fetched per row (LDS broadcast)
+    float zc[3][DA], ie[DA], vq[3];
+    int mq[3], bq[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int c = lane + 64 * q;
+      mq[q] = KERNEL == 0 ? c : c / Do;
+      bq[q] = KERNEL == 0 ? 0 : c - mq[q] * Do;
+      const bool ok = c < n;
+      if (!ok) { mq[q] = 0; bq[q] = 0; }
+      vq[q] = KERNEL == 0 ? vb : sC[Do * Do + bq[q]];
+      if (DC > 0) {
+#pragma unroll
+        for (int i = 0; i < DA; ++i) zc[q][i] = sZ[i * ZS + mq[q]];
+      }
+    }
+    if (DC > 0 && KERNEL == 0) {
+#pragma unroll
+      for (int i = 0; i < DA; ++i) ie[i] = sC[i];
+    }
     for (int r = wave; r < np; r += 8) {
       const int cend = ((r >> 5) + 1) * NB;          // first column right of the diagonal tile
-      const int nn = KERNEL == 0 ? r : r / Do, a = KERNEL == 0 ? 0 : r - nn * Do;
-      for (int c = lane; c < cend; c += 64) {
+      const int nn = KERNEL == 0 ? (r < n ? r : 0) : (r < n ? r / Do : 0), a = KERNEL == 0 ? 0 : (r < n ? r - nn * Do : 0);
+      float zr[DA];
+      if (DC > 0) {
+#pragma unroll
+        for (int i = 0; i < DA; ++i) zr[i] = sZ[i * ZS + nn];
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int c = lane + 64 * q;
+        if (c >= cend) continue;
         float v;
         if (r < n && c < n) {
           if (KERNEL == 0) {
-            float q = 0.f;
-            for (int i = 0; i < Di; ++i) {
-              const float t = (sZ[i * ZS + r] - sZ[i * ZS + c]) * sC[i];
-              q = fmaf(t, t, q);
+            float qq = 0.f;
+            if (DC > 0) {
+#pragma unroll
+              for (int i = 0; i < DA; ++i) { const float t = (zr[i] - zc[q][i]) * ie[i]; qq = fmaf(t, t, qq); }
+            } else {
+              for (int i = 0; i < DIr; ++i) { const float t = (sZ[i * ZS + r] - sZ[i * ZS + c]) * sC[i]; qq = fmaf(t, t, qq); }
             }
-            v = vb * expf(-0.5f * q) + (r == c ? kJitter : 0.f);
+            v = vb * expf(-0.5f * qq) + (r == c ? kJitter : 0.f);
           } else {
-            const int D = Do, mm = c / D, bb = c - mm * D;
+            const int D = DIr, mm = mq[q], bb = bq[q];
             float r2 = 0.f;
-            for (int i = 0; i < D; ++i) { const float t = sZ[i * ZS + mm] - sZ[i * ZS + nn]; r2 = fmaf(t, t, r2); }
+            if (DC > 0) {
+#pragma unroll
+              for (int i = 0; i < DA; ++i) { const float t = zc[q][i] - zr[i]; r2 = fmaf(t, t, r2); }
+            } else {
+              for (int i = 0; i < D; ++i) { const float t = sZ[i * ZS + mm] - sZ[i * ZS + nn]; r2 = fmaf(t, t, r2); }
+            }
             const float il2 = sC[a * D + bb];
             const float da = sZ[a * ZS + mm] - sZ[a * ZS + nn], db = sZ[bb * ZS + mm] - sZ[bb * ZS + nn];
             const float term = da * db * il2 + ((a == bb) ? ((float)(D - 1) - r2 * il2) : 0.f);
-            v = sC[D * D + bb] * expf(-0.5f * r2 * il2) * term * il2 + (r == c ? kJitter : 0.f);
+            v = vq[q] * expf(-0.5f * r2 * il2) * term * il2 + (r == c ? kJitter : 0.f);
           }
         } else if (r == n) {
           v = c < n ? (KERNEL == 0 ? u_prior[c * Do + b] : u_prior[c]) : (c == n ? 1e30f : 0.f);
@@ -654,6 +696,16 @@ __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, 
         sA[r * LD + c] = v;
       }
     }
+  };
+  switch (Di) {
+    case 2: fill(std::integral_constant<int, 2>{}); break;
+    case 3: fill(std::integral_constant<int, 3>{}); break;
+    case 4: fill(std::integral_constant<int, 4>{}); break;
+    case 6: fill(std::integral_constant<int, 6>{}); break;
+    case 8: fill(std::integral_constant<int, 8>{}); break;
+    case 12: fill(std::integral_constant<int, 12>{}); break;
+    case 16: fill(std::integral_constant<int, 16>{}); break;
+    default: fill(std::integral_constant<int, 0>{}); break;
   }
   __syncthreads();
   DPROBE(0);
@@ -713,40 +765,54 @@ __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, 
     __syncthreads();
     DPROBE(2);
   }
-  // ---- nu = L^-T (u - y), y = row n of the factor ------------------------------------------------
-  for (int j = tid; j < np; j += 512)
-    sv[j] = j < n ? (KERNEL == 0 ? u[(size_t)j * Do + b] : u[j]) - sA[n * LD + j] : 0.f;
-  __syncthreads();
-  for (int k = cdiv(n, NB) - 1; k >= 0; --k) {
-    const int c0 = k * NB;
-    if (tid < 64) {
-      const int c = lane & 31;
-      float Lc[NB];
+  // ---- nu = L^-T (u - y), y = row n of the factor: block back-substitution by wavefront 0 alone -- the residual lives in its
+  // registers (lane l holds entries l, l + 64, l + 128), the 32 solved unknowns of a block travel as wave-uniform values
+  // (v_readlane), so the 2 x nblk workgroup barriers of a shared-residual formulation disappear from the chain
+  if (wave == 0) {
+    float res[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int j = lane + 64 * q;
+      res[q] = j < n ? (KERNEL == 0 ? u[(size_t)j * Do + b] : u[j]) - sA[n * LD + j] : 0.f;
+    }
+    for (int k = cdiv(n, NB) - 1; k >= 0; --k) {
+      const int c0 = k * NB, q0 = c0 >> 6, l0 = c0 & 63;     // the block sits in chunk q0, lanes l0 .. l0 + 31
+      const int c = (lane - l0) & 31;                        // column within the block (meaningful in the block's lanes)
+      const bool mine = lane >= l0 && lane < l0 + NB;
+      float Lc[NB];                                          // column c of L_kk
 #pragma unroll
       for (int r = 0; r < NB; ++r) Lc[r] = sA[(c0 + r) * LD + c0 + c];
-      float res = sv[c0 + c];
       float dg = 1.f;
 #pragma unroll
-      for (int r = 0; r < NB; ++r) dg = (r == c) ? Lc[r] : dg;   // static register indices only
+      for (int r = 0; r < NB; ++r) dg = (r == c) ? Lc[r] : dg;
       const float myinv = 1.f / dg;
+      float rb = q0 == 0 ? res[0] : (q0 == 1 ? res[1] : res[2]);
+      float xs[NB];
 #pragma unroll
       for (int r = NB - 1; r >= 0; --r) {
-        const float t = res * myinv;                 // in lane r: x_r = res_r / L_rr (one broadcast per row instead of two)
-        float xr = GP_BCAST(t, r);
-        xr = (c0 + r < n) ? xr : 0.f;                // rows past n are padding (row n is the rhs row): x = 0
-        res = (c == r) ? xr : fmaf(-Lc[r], xr, res);
+        const float t = rb * myinv;                          // in the lane of row r: x_r = res_r / L_rr
+        float xr = GP_BCAST(t, l0 + r);
+        xr = (c0 + r < n) ? xr : 0.f;                        // rows past n are padding (row n is the rhs row): x = 0
+        xs[r] = xr;
+        rb = (c == r) ? xr : fmaf(-Lc[r], xr, rb);           // lanes c < r consume L[r][c]; lanes c > r hold x already
       }
-      if (lane < NB) { sx[lane] = res; sv[c0 + lane] = res; }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int j = lane + 64 * q;
+        float v = res[q];
+        if (q == q0 && mine) v = rb;                         // the solved block
+        if (j < c0) {                                        // columns left of the block: subtract its contribution
+#pragma unroll
+          for (int r = 0; r < NB; ++r) v = fmaf(-sA[(c0 + r) * LD + j], xs[r], v);
+        }
+        res[q] = v;
+      }
     }
-    __syncthreads();
-    for (int c = tid; c < c0; c += 512) {
-      float acc = sv[c];
-#pragma unroll 8
-      for (int r = 0; r < NB; ++r) acc = fmaf(-sA[(c0 + r) * LD + c], sx[r], acc);
-      sv[c] = acc;
-    }
-    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (lane + 64 * q < np) sv[lane + 64 * q] = res[q];
   }
+  __syncthreads();
   DPROBE(3);
   // ---- publish --------------------------------------------------------------------------------
   float* Lm = Lall + (size_t)b * batch_stride;

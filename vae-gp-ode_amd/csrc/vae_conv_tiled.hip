@@ -391,12 +391,12 @@ static bool use_mfma() {
 // matrix-core path (conv_mfma.hpp): persistent grid of one 512-thread workgroup per CU
 // NTHR = 256 with a footprint <= 80 KB: TWO independent 4-wavefront workgroups per CU, whose scatter / store phases interleave
 // with each other's MFMA phases instead of idling the matrix pipe in lockstep
-template <class PL, int IPB, int TG, int NCJ, bool PAIR = false, int NTHR = 512>
+template <class PL, int IPB, int TG, int NCJ, bool PAIR = false, int NTHR = 512, bool DB = false>
 static int launch_igemm(const float* x, const float* w, const float* bias, float* y, int B, hipStream_t st, const char* what,
                         const float* in_bn = nullptr) {
-  constexpr size_t lds = igemm_lds_bytes<PL, IPB>();
+  constexpr size_t lds = igemm_lds_bytes<PL, IPB, DB>();
   static_assert(lds <= (NTHR == 512 ? 160 : 80) * 1024, "LDS budget");
-  auto km = k_conv_igemm<PL, IPB, TG, NCJ, PAIR, NTHR>;
+  auto km = k_conv_igemm<PL, IPB, TG, NCJ, PAIR, NTHR, DB>;
   if (set_max_lds((const void*)km, lds)) return 1;
   const int ngroups = (B + IPB - 1) / IPB;
   const int cap = num_cus() * (512 / NTHR);
@@ -413,6 +413,12 @@ static int launch_T1(const float* x, const float* w, const float* bias, float* y
     constexpr int TG = COS >= 64 ? 1 : (COS >= 32 ? 2 : 4);
     // column-parity classes pair up when both cover the same pixel grid: stride 2, (HO + P) even
     constexpr bool PAIR = L::S == 2 && (L::HO % 2 == 0) && (L::P % 2 == 1);
+    if constexpr (std::is_same<L, Dec7>::value) {
+      // decnn.7: ONE image per group in double-buffered planes (2 x 38 KB + 50 KB of slabs): one barrier per group, and the two
+      // wavefronts of a SIMD scatter at opposite ends of it (GPODE_DEC7_FWD_SB=1: single-buffered, two images per group -- A/B)
+      static const bool sb = [] { const char* e = getenv("GPODE_DEC7_FWD_SB"); return e && e[0] == '1'; }();
+      if (!sb) return launch_igemm<FwdPolicy<L, COS>, 1, TG, COS / 16, PAIR, 512, true>(x, w, bias, y, B, st, "convT_fwd_mfma", in_bn);
+    }
     return launch_igemm<FwdPolicy<L, COS>, IPBM, TG, COS / 16, PAIR>(x, w, bias, y, B, st, "convT_fwd_mfma", in_bn);
   }
   if (in_bn) return set_error("convT forward with a fused BatchNorm input needs the matrix-core path (16-byte aligned input, GPODE_CONV_VALU unset)");
