@@ -414,10 +414,12 @@ static int launch_T1(const float* x, const float* w, const float* bias, float* y
     // column-parity classes pair up when both cover the same pixel grid: stride 2, (HO + P) even
     constexpr bool PAIR = L::S == 2 && (L::HO % 2 == 0) && (L::P % 2 == 1);
     if constexpr (std::is_same<L, Dec7>::value) {
-      // decnn.7: ONE image per group in double-buffered planes (2 x 38 KB + 50 KB of slabs): one barrier per group, and the two
-      // wavefronts of a SIMD scatter at opposite ends of it (GPODE_DEC7_FWD_SB=1: single-buffered, two images per group -- A/B)
-      static const bool sb = [] { const char* e = getenv("GPODE_DEC7_FWD_SB"); return e && e[0] == '1'; }();
-      if (!sb) return launch_igemm<FwdPolicy<L, COS>, 1, TG, COS / 16, PAIR, 512, true>(x, w, bias, y, B, st, "convT_fwd_mfma", in_bn);
+      // GPODE_DEC7_FWD_DB=1 (A/B only): ONE image per group in double-buffered planes (2 x 38 KB + 50 KB of slabs), one barrier
+      // per group, the two wavefronts of a SIMD scattering at opposite ends of it.  Measured SLOWER than the default below
+      // (4096 images: 0.244 vs 0.229 ms): a single image per group quantises to 13 tiles for 12.25 and the scatter was 2 % of
+      // the kernel to begin with -- the idle matrix-pipe cycles are not in the phases the second buffer overlaps.
+      static const bool db = [] { const char* e = getenv("GPODE_DEC7_FWD_DB"); return e && e[0] == '1'; }();
+      if (db) return launch_igemm<FwdPolicy<L, COS>, 1, TG, COS / 16, PAIR, 512, true>(x, w, bias, y, B, st, "convT_fwd_mfma", in_bn);
     }
     return launch_igemm<FwdPolicy<L, COS>, IPBM, TG, COS / 16, PAIR>(x, w, bias, y, B, st, "convT_fwd_mfma", in_bn);
   }
