@@ -16,6 +16,7 @@
 //     gp_cache_bwd.hip chains back to the raw parameters.
 #include "gp_eval.hpp"
 #include "gp_team.hpp"
+#include "gp_wide.hpp"
 #include "gp_launch.hpp"
 
 namespace gp {
@@ -554,6 +555,8 @@ __global__ __launch_bounds__(1024) void reduce_slab_kernel(const float* __restri
 // host side
 // ---------------------------------------------------------------------------------------------
 static inline int team_grid_b(int N) { return N < 2048 ? N : 2048; }
+// wavefronts per trajectory of the wide team (gp_wide.hpp) for an output width, 0: none
+template <int DO> constexpr int wide_ts_b() { return (DO == 6 || DO == 3) ? 12 : (DO == 4 ? 8 : (DO == 8 ? 16 : 0)); }
 
 // register-resident team when the quarter pack fits (S <= 256, M <= 128, D <= 8), streamed team otherwise
 template <int DI, int DO> static bool rbf_team_ok(int M, int S) {
@@ -568,6 +571,14 @@ template <int D> static bool df_team_ok(int M, int S) {
 template <int DI, int DO, int ORDER, int METHOD>
 static int launch_bwd_rbf(const float* pack, int M, int S, const float* xstage, const float* gzt, const float* ts, int N, int T,
                           float* gz0, float* astage, hipStream_t st) {
+  if constexpr (wide_ts_b<DO>() > 0 && DI <= 8) {   // few trajectories: 12 wavefronts each (gp_wide.hpp)
+    constexpr int TS = wide_ts_b<DO>();
+    if (wide_team_enabled() && N <= kWideMaxRows && RbfWideTeam<DI, DO, TS>::fits(M, S)) {
+      hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfWideTeam<DI, DO, TS>, DI, DO, ORDER, METHOD>), N, 64 * TS, 0, st,
+                         pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+      return check_launch("rollout_bwd_rbf_wide");
+    }
+  }
   if constexpr (DO <= 8) {
     if (rbf_team_ok<DI, DO>(M, S)) {
       hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO, ORDER, METHOD>), team_grid_b(N), 256, 0, st,
@@ -583,6 +594,14 @@ static int launch_bwd_rbf(const float* pack, int M, int S, const float* xstage, 
 template <int D, int METHOD>
 static int launch_bwd_df(const float* pack, int M, int S, const float* xstage, const float* gzt, const float* ts, int N, int T,
                          float* gz0, float* astage, hipStream_t st) {
+  if constexpr (wide_ts_b<D>() > 0) {
+    constexpr int TS = wide_ts_b<D>();
+    if (wide_team_enabled() && N <= kWideMaxRows && DfWideTeam<D, TS>::fits(M, S)) {
+      hipLaunchKernelGGL((rollout_bwd_team_kernel<DfWideTeam<D, TS>, D, D, 1, METHOD>), N, 64 * TS, 0, st,
+                         pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+      return check_launch("rollout_bwd_df_wide");
+    }
+  }
   if constexpr (D <= 8) {
     if (df_team_ok<D>(M, S)) {
       hipLaunchKernelGGL((rollout_bwd_team_kernel<DfTeamEval<D, 1>, D, D, 1, METHOD>), team_grid_b(N), 256, 0, st,

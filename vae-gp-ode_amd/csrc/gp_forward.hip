@@ -12,6 +12,7 @@
 //   DF  "stream" : pack larger than LDS (cfg5): records are re-read from L2.
 #include "gp_eval.hpp"
 #include "gp_team.hpp"
+#include "gp_wide.hpp"
 #include "gp_launch.hpp"
 
 namespace gp {
@@ -365,6 +366,10 @@ static inline void grid_for(int N, int& grid, int& block) {
   if (grid < 1) grid = 1;
 }
 
+
+// wavefronts per trajectory of the wide team (gp_wide.hpp) for an output width, 0: none
+template <int DO> constexpr int wide_ts() { return (DO == 6 || DO == 3) ? 12 : (DO == 4 ? 8 : (DO == 8 ? 16 : 0)); }
+
 static const int kTeamMaxRows = 2048;  // below this, 4 waves per trajectory beat 1 (all 1024 SIMDs busy sooner)
 static inline int team_grid(int N) { return N < 2048 ? N : 2048; }
 
@@ -431,6 +436,13 @@ template <int DI, int DO, int ORDER, int METHOD>
 static int launch_rollout_rbf(const float* pack, int M, int S, const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st) {
   int grid, block;
   grid_for(N, grid, block);
+  if constexpr (wide_ts<DO>() > 0 && DI <= 8) {
+    constexpr int TS = wide_ts<DO>();
+    if (wide_team_enabled() && N <= kWideMaxRows && RbfWideTeam<DI, DO, TS>::fits(M, S)) {
+      hipLaunchKernelGGL((rollout_team_kernel<RbfWideTeam<DI, DO, TS>, DI, DO, ORDER, METHOD>), N, 64 * TS, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
+      return check_launch("rollout_rbf_wide");
+    }
+  }
   if (N <= kTeamMaxRows && DO <= 16) {
     if (RbfTeamEval<DI, DO, 1>::fits(M, S)) {
       hipLaunchKernelGGL((rollout_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO, ORDER, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
@@ -464,6 +476,13 @@ static int launch_rollout_df(const float* pack, int M, int S, const float* z0, c
   const size_t f4 = L::rff_f4(S) + L::ind_f4(M);
   int grid, block;
   grid_for(N, grid, block);
+  if constexpr (wide_ts<D>() > 0) {
+    constexpr int TS = wide_ts<D>();
+    if (wide_team_enabled() && N <= kWideMaxRows && DfWideTeam<D, TS>::fits(M, S)) {
+      hipLaunchKernelGGL((rollout_team_kernel<DfWideTeam<D, TS>, D, D, 1, METHOD>), N, 64 * TS, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
+      return check_launch("rollout_df_wide");
+    }
+  }
   if constexpr (D <= 8) {
     if (N <= kTeamMaxRows && DfTeamEval<D, 1>::fits(M, S)) {
       hipLaunchKernelGGL((rollout_team_kernel<DfTeamEval<D, 1>, D, D, 1, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
