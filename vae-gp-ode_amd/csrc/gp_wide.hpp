@@ -262,11 +262,16 @@ template <int D, int TS> struct DfWideTeam {
   }
 };
 
-// the wide team serves few trajectories (<= 2 per CU), where the chain's latency is everything
+// Measured (MI355X, rk4, T = 16; rollout launch, us): the wide team LOSES to the 4-wavefront team at every BASELINE shape --
+//   configs[0] RBF batch 32: 53 vs 48   configs[3] RBF batch 256: 74 vs 67   configs[1] DF batch 256: 105 vs 94   configs[2]: 72 vs 58
+// An evaluation's arithmetic does shrink (~850 -> ~280 issue cycles per wavefront), but it was never the long pole: the chain
+// reduce -> LDS slot -> s_barrier -> LDS read -> cross-lane sum -> v_readlane is ~1500 cycles of pure latency per evaluation either
+// way, and twelve wavefronts reach the barrier with more skew than four.  So it stays an A/B switch (GPODE_TEAM_WIDE=1) and the
+// parity tests cover it (tests/test_gpu_forward.py::test_wide_team_matches); the default is the 4-wavefront team.
 static constexpr int kWideMaxRows = 512;
 static inline bool wide_team_enabled() {
-  static const bool off = [] { const char* e = getenv("GPODE_TEAM4"); return e && e[0] == '1'; }();   // A/B: the 4-wavefront team everywhere
-  return !off;
+  static const bool on = [] { const char* e = getenv("GPODE_TEAM_WIDE"); return e && e[0] == '1'; }();
+  return on;
 }
 
 }  // namespace gp
