@@ -245,3 +245,37 @@ def test_build_conditional_many_queries_and_errors():
     assert (var > 0).all()
     with pytest.raises(NotImplementedError):
         SVGP_Layer(6, 6, 16, 32, kernel='DF').cuda().build_conditional(x[:4].cuda())
+
+
+def test_wide_team_matches():
+    """GPODE_TEAM_WIDE=1 (12 wavefronts per trajectory, csrc/gp_wide.hpp -- an A/B variant, slower than the default 4-wavefront
+    team at every BASELINE shape): rollout and reverse sweep agree with the default team to fp32 summation-order noise."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import load_golden, sub
+from test_gpu_forward import build
+from vae_gp_ode_amd import ops
+out = {}
+for name, kernel, order in (('gp_rbf1_cfg1', 'RBF', 1), ('gp_df1_cfg2', 'DF', 1), ('gp_rbf2_cfg3', 'RBF', 2), ('gp_df1_tiny_q4', 'DF', 1)):
+    g = load_golden(name)
+    c = build(g, kernel, want_Lu=False)
+    zt, xs = ops.rollout(c, g['z0'].cuda(), g['ts'].cuda(), order, 'rk4', save_stages=True)
+    gz0, ast = ops.rollout_bwd(c, xs, torch.ones_like(zt), g['ts'].cuda(), order, 'rk4')
+    out[name] = (zt.cpu(), gz0.cpu(), ast.cpu())
+torch.save(out, sys.argv[1])
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (('team4', {}), ('wide', {'GPODE_TEAM_WIDE': '1'})):
+        fn = os.path.join(tempfile.mkdtemp(), tag + '.pt')
+        r = subprocess.run([sys.executable, '-c', code, fn], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[tag] = torch.load(fn)
+    for name in res['team4']:
+        for a, b, what in zip(res['wide'][name], res['team4'][name], ('zt', 'gz0', 'astage')):
+            e = relerr(a, b)
+            assert e < (2e-5 if what == 'zt' else 2e-4), (name, what, e)
