@@ -307,3 +307,40 @@ def test_streamed_backward_matches_fp64_oracle(kernel, Di, Do, order, M, S, meth
     for k in got:
         tol = 1e-3 + 3 * relerr(g32[k], g64[k])
         assert relerr(got[k], g64[k]) < tol, (k, relerr(got[k], g64[k]), tol)
+
+
+@pytest.mark.parametrize('M,Dd', [(1056, 3), (600, 2)])
+def test_hyperparameter_gradients_on_a_rank_deficient_kuu(M, Dd):
+    """Many inducing points in a low-dimensional latent: K_uu + jitter I is numerically rank deficient (what training drives the
+    model towards).  The cache backward takes the solve-based route (block substitution with the factor, csrc/gp_cache_bwd.hip
+    k_trsm_slab) -- the autograd of kernels.py:163-171 -- instead of products with an explicit L^-1, which at M = 1056, D = 3
+    left d/d lengthscale 12 % from fp64 where torch's own fp32 solves are at 1 % (round 1, tools/ab_bigfactor.py).
+    Every GP gradient must now be within 2x of the fp32 oracle's distance to the fp64 oracle (floor 2e-4)."""
+    kernel, Di, Do, order, S, method, N, T_ = 'RBF', Dd, Dd, 1, 64, 'euler', 5, 4
+    p, nz, z0, ts, gw = synthetic_gp(kernel, Di, Do, M, S, N, T_, seed=1000 + M + S + Di)
+    from vae_gp_ode_amd.model.core.flow import Flow
+    from vae_gp_ode_amd.model.core.svpy import SVGP_Layer
+    gp = SVGP_Layer(Di, Do, M, S, kernel=kernel).cuda()
+    with torch.no_grad():
+        gp.kern.unconstrained_lengthscales.copy_(p['raw_ell']); gp.kern.unconstrained_variance.copy_(p['raw_var'])
+        gp.inducing_loc.optvar.copy_(p['Z']); gp.Um.optvar.copy_(p['Um']); gp.Us_sqrt.optvar.copy_(p['Us'])
+    flow = Flow(gp, order=order, solver=method).cuda()
+    gp.set_noise({k: v.cuda() for k, v in nz.items()})
+    zg = z0.cuda().requires_grad_(True)
+    zt = flow(zg, ts.cuda())
+    (zt * gw.cuda()).sum().backward()
+    got = {'raw_ell': gp.kern.unconstrained_lengthscales.grad, 'raw_var': gp.kern.unconstrained_variance.grad,
+           'Z': gp.inducing_loc.optvar.grad, 'Um': gp.Um.optvar.grad, 'Us': gp.Us_sqrt.optvar.grad, 'z0': zg.grad}
+
+    def oracle(dtype):
+        q = {k: v.to(dtype).clone().requires_grad_(True) for k, v in p.items()}
+        c = O.build_cache(q, O.to_dtype(nz, dtype), kernel)
+        z = z0.to(dtype).clone().requires_grad_(True)
+        out = O.flow_forward(z, ts.to(dtype), c, order, method)
+        (out * gw.to(dtype)).sum().backward()
+        return dict({k: v.grad for k, v in q.items()}, z0=z.grad)
+    g64, g32 = oracle(torch.float64), oracle(torch.float32)
+    rep = {k: (relerr(got[k], g64[k]), relerr(g32[k], g64[k])) for k in got}
+    print('M=%d D=%d  hip / fp32-oracle distance to fp64:' % (M, Dd), {k: '%.1e/%.1e' % v for k, v in rep.items()})
+    for k, (e_hip, e_ref) in rep.items():
+        assert e_hip < max(2 * e_ref, 2e-4), (k, e_hip, e_ref)

@@ -486,6 +486,179 @@ __global__ __launch_bounds__(256, 2) void k_linv_dc_mfma(int step, int sb, int n
 
 
 // ---------------------------------------------------------------------------------------------
+// Solve-based route (np <= kTrsmMaxNp): what torch's autograd does behind cholesky / triangular_solve (kernels.py:163-171,
+// :384-386) -- triangular SOLVES with the factor, not products with an explicit L^-1.  The explicit inverse (k_linv_dc above)
+// is built from products of inverted sub-blocks and loses accuracy with cond(L): on a numerically rank-deficient K_uu (1056
+// inducing points in a 3-D latent) d/d ell came out 12 % from fp64 where torch's fp32 solves stay at 1 %
+// (tools/ab_bigfactor.py).  Here only the 32 x 32 DIAGONAL blocks are inverted (k_trinv_diag; their condition is that of a
+// block, not of the factor) and everything else is block substitution:
+//     q = L^-1 g_nu            (forward)        MODE 0, one slab per system (column 0)
+//     [X | a] = L^-T [Phi | q] (backward)       MODE 1, slabs of 32 columns of Phi = tril_half(-r q^T + q v^T) + one slab for q
+//     S^T = L^-T X^T           (backward)       MODE 2, slabs of 32 rows of X  (S = X L^-1)
+// A triangular solve is sequential along the rows but independent per right-hand-side column, so ONE workgroup owns a slab of
+// 32 columns for the whole substitution: the slab (np x 32) lives in LDS, there is no inter-workgroup synchronisation, and
+// the n^2/2 x 32 multiply-adds per slab run on the matrix cores (v_mfma_f32_16x16x4_f32; the factor's tiles stream from L2
+// straight into MFMA operands, each element used once per slab).  Per block step: Y_k = Dinv_k(^T) R_k, then
+// R_j -= L_(k,j)^T Y_k for the blocks still to be solved (tiles dealt round-robin to the 4 wavefronts).
+// ---------------------------------------------------------------------------------------------
+constexpr int TSL = 33;                              // slab row stride in LDS (floats)
+static constexpr int kTrsmMaxNp = 1216;              // np * TSL floats must fit 160 KB
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_trsm_slab(int n, int np, int nbn, const float* __restrict__ Lall, size_t batch_stride,
+                                                    const float* __restrict__ Dinv_all, size_t dinv_stride,
+                                                    float* __restrict__ vec_all, const float* __restrict__ Xin_all,
+                                                    float* __restrict__ Out_all) {
+  extern __shared__ __attribute__((aligned(16))) float sY[];        // [32 nbn][TSL]
+  constexpr bool TRANS = MODE != 0;
+  const int slab = blockIdx.x, b = blockIdx.y, nb = gridDim.y;
+  const float* Lm = Lall + (size_t)b * batch_stride;
+  const float* Dinv = Dinv_all + (size_t)b * dinv_stride;
+  const float* vg = vec_all + (size_t)(0 * nb + b) * np;
+  const float* vq = vec_all + (size_t)(1 * nb + b) * np;
+  const float* vr = vec_all + (size_t)(3 * nb + b) * np;
+  const float* vv = vec_all + (size_t)(4 * nb + b) * np;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lk = lane >> 4;
+  const int nrow = nbn * NB, c0 = slab * NB;
+  // ---- right-hand sides -------------------------------------------------------------------
+  for (int e = tid; e < nrow * NB; e += 256) {
+    float v = 0.f;
+    if (MODE == 0) {
+      const int i = e >> 5, c = e & 31;
+      if (c == 0 && i < n) v = vg[i];
+      sY[i * TSL + c] = v;
+    } else if (MODE == 1) {
+      const int i = e >> 5, c = e & 31, gj = c0 + c;
+      if (slab == nbn) { if (c == 0 && i < n) v = vq[i]; }
+      else if (i < n && gj < n) {
+        const float ph = -vr[i] * vq[gj] + vq[i] * vv[gj];
+        v = i > gj ? ph : (i == gj ? 0.5f * ph : 0.f);
+      }
+      sY[i * TSL + c] = v;
+    } else {                                         // B[i][c] = X[c0 + c][i]: walk X's rows (i contiguous)
+      const int c = e / nrow, i = e - c * nrow, gj = c0 + c;
+      if (i < n && gj < n) v = Xin_all[(size_t)b * batch_stride + (size_t)gj * np + i];
+      sY[i * TSL + c] = v;
+    }
+  }
+  __syncthreads();
+  // ---- block substitution ------------------------------------------------------------------
+  const int mb = wave >> 1, nbk = wave & 1;          // this wavefront's 16 x 16 block of the diagonal step
+  for (int step = 0; step < nbn; ++step) {
+    const int kb = TRANS ? nbn - 1 - step : step;
+    const float* Dk = Dinv + (size_t)kb * NB * NB;
+    float* Rk = sY + (size_t)kb * NB * TSL;
+    // Y_k = Dinv_k^T R_k (TRANS) or Dinv_k R_k: one 16 x 16 block per wavefront
+    gf32x4 acc = gf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NB / 4; ++ks) {
+      const int k = 4 * ks + lk;
+      const float a = TRANS ? Dk[k * NB + mb * 16 + lr] : Dk[(mb * 16 + lr) * NB + k];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Rk[k * TSL + nbk * 16 + lr], acc, 0, 0, 0);
+    }
+    __syncthreads();                                 // every wavefront has read R_k
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Rk[(mb * 16 + 4 * lk + r) * TSL + nbk * 16 + lr] = acc[r];
+    __syncthreads();
+    // R_j -= A_j Y_k for the blocks still to be solved: TRANS: j < kb, A_j = L[kb][j]^T; else j > kb, A_j = L[j][kb]
+    const int ntile = TRANS ? kb : nbn - 1 - kb;
+    if (ntile > 0) {
+      float bf[2][NB / 4];                           // Y_k as B operand, shared by all tiles of the step
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks) bf[q][ks] = Rk[(4 * ks + lk) * TSL + q * 16 + lr];
+      auto loadA = [&](int t, float (&af)[2][NB / 4]) {
+        const int j = TRANS ? t : kb + 1 + t;
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+          for (int ks = 0; ks < NB / 4; ++ks) {
+            const int k = 4 * ks + lk, m = m2 * 16 + lr;
+            const int row = TRANS ? kb * NB + k : j * NB + m, col = TRANS ? j * NB + m : kb * NB + k;
+            af[m2][ks] = (row < n && col < n) ? Lm[(size_t)row * np + col] : 0.f;   // rows / columns >= n: not part of the factor
+          }
+      };
+      float afA[2][NB / 4], afB[2][NB / 4];
+      int t = wave;
+      if (t < ntile) loadA(t, afA);
+      auto tile = [&](int tcur, const float (&af)[2][NB / 4]) {
+        const int j = TRANS ? tcur : kb + 1 + tcur;
+        float* Rj = sY + (size_t)j * NB * TSL;
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            gf32x4 c = gf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NB / 4; ++ks) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m2][ks], bf[q][ks], c, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* dst = Rj + (m2 * 16 + 4 * lk + r) * TSL + q * 16 + lr;
+              *dst = *dst - c[r];
+            }
+          }
+      };
+      while (t < ntile) {                            // the next tile's operands travel while this one is multiplied
+        if (t + 4 < ntile) loadA(t + 4, afB);
+        tile(t, afA);
+        t += 4;
+        if (t >= ntile) break;
+        if (t + 4 < ntile) loadA(t + 4, afA);
+        tile(t, afB);
+        t += 4;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- results -------------------------------------------------------------------------------
+  if (MODE == 0) {
+    for (int i = tid; i < np; i += 256) vec_all[(size_t)(1 * nb + b) * np + i] = i < n ? sY[i * TSL] : 0.f;
+  } else if (MODE == 1) {
+    if (slab == nbn) {
+      for (int i = tid; i < np; i += 256) vec_all[(size_t)(2 * nb + b) * np + i] = i < n ? sY[i * TSL] : 0.f;
+    } else {
+      float* X = Out_all + (size_t)b * batch_stride;
+      for (int e = tid; e < nrow * NB; e += 256) {
+        const int i = e >> 5, c = e & 31;
+        X[(size_t)i * np + c0 + c] = sY[i * TSL + c];
+      }
+    }
+  } else {
+    float* Sm = Out_all + (size_t)b * batch_stride;  // S[c0 + c][i] = Y[i][c]
+    for (int e = tid; e < nrow * NB; e += 256) {
+      const int c = e / nrow, i = e - c * nrow;
+      Sm[(size_t)(c0 + c) * np + i] = sY[i * TSL + c];
+    }
+  }
+}
+
+// r = u - v, v = row n of the factor (the forward-solved rhs); g_u = q -> g_Um; g_p = -a -> gp_rows  (what k_vec_a does after
+// its product with the explicit inverse); one thread per element
+__global__ void k_vec_rv(int kernel, int Do, int n, int np, const float* __restrict__ Lall, size_t batch_stride,
+                         const float* __restrict__ Dfac_all, size_t dfac_stride, const float* __restrict__ u,
+                         float* __restrict__ vec_all, int with_a, float* __restrict__ g_Um, float* __restrict__ gp_rows) {
+  const int b = blockIdx.y, nb = gridDim.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= np) return;
+  const float* Lm = Lall + (size_t)b * batch_stride;
+  const float* Dfac = Dfac_all + (size_t)b * dfac_stride;
+  const int u_stride = kernel == 0 ? Do : 1, u_b = kernel == 0 ? b : 0;
+  if (!with_a) {
+    float y = 0.f, rr = 0.f;
+    if (j < n) {
+      const int kl = n / NB, cl = kl * NB;
+      y = (j < cl) ? Lm[(size_t)n * np + j] : Dfac[(size_t)kl * NB * NB + (n - cl) * NB + (j - cl)];
+      rr = u[(size_t)j * u_stride + u_b] - y;
+    }
+    vec_all[(size_t)(3 * nb + b) * np + j] = rr;
+    vec_all[(size_t)(4 * nb + b) * np + j] = y;
+  } else if (j < n) {
+    g_Um[(size_t)j * u_stride + u_b] = vec_all[(size_t)(1 * nb + b) * np + j];
+    gp_rows[(size_t)j * u_stride + u_b] = -vec_all[(size_t)(2 * nb + b) * np + j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // kernel-matrix backward.  G = (S + S^T)/2 multiplies BOTH triangles of K(Z) (torch's cholesky_backward).
 // ---------------------------------------------------------------------------------------------
 // RBF: grid (ceil(M/64), Do), block 64: thread = row point n.
@@ -774,6 +947,13 @@ __global__ __launch_bounds__(256) void k_chain_df(int M, int S, const float* __r
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
+// solve-based route for every factor whose 32-column slab fits LDS (GPODE_BWD_EXPLICIT_INVERSE=1: the explicit L^-1 route for
+// every size, for A/B and tools/ab_bigfactor.py)
+static inline bool use_trsm(int np) {
+  static const bool off = [] { const char* e = getenv("GPODE_BWD_EXPLICIT_INVERSE"); return e && e[0] == '1'; }();
+  return !off && np <= kTrsmMaxNp;
+}
+
 int cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, size_t* bws_floats) {
   size_t pf = 0;
   if (cache_sizes(kernel, Di, Do, M, S, &pf, nullptr)) return 1;
@@ -793,6 +973,7 @@ int cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, const float* ws,
   const float* Dfac = ws + w.Dfac;
   const size_t bstride = (size_t)w.np * w.np, dstride = (size_t)w.nblk * NB * NB, dinv_stride = (size_t)b.nbn * NB * NB;
   hipLaunchKernelGGL(k_trinv_diag, dim3(b.nbn, b.batch), 64, 0, st, Dfac, dstride, b.n, bws + b.Dinv, dinv_stride);
+  if (use_trsm(b.np)) return check_launch("cache bwd: diagonal-block inverses");   // the solve-based route needs nothing else
   hipLaunchKernelGGL(k_linv_init, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, b.np, bws + b.Dinv, dinv_stride, bws + b.Linv, bstride);
   for (int sb = 1; sb < b.nbn; sb *= 2) {            // T lives in the X buffer (written by k_gemm_phiX only afterwards)
     const int npairs = cdiv(b.nbn, 2 * sb);
@@ -827,9 +1008,25 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
 
   hipLaunchKernelGGL(k_gnu, dim3(cdiv(b.np, 128), b.batch), 128, 0, st, kernel, Di, Do, M, b.n, b.np, gpack_ind, ws + w.var, vec);
   if (!prepared && cache_bwd_prepare(kernel, Di, Do, M, S, ws, bws, st)) return 1;
-  hipLaunchKernelGGL(k_vec_q, dim3(cdiv(b.np, 4), b.batch), 256, 0, st, b.n, b.np, bws + b.Linv, bstride, vec);
-  hipLaunchKernelGGL(k_vec_a, dim3(cdiv(b.np, 4), b.batch), 256, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, bws + b.Linv,
-                     ws + w.u, vec, g_Um, bws + b.gp_rows);
+  const bool solves = use_trsm(b.np);
+  const size_t trsm_lds = sizeof(float) * (size_t)b.nbn * NB * TSL;
+  if (solves) {
+    // triangular solves with the factor (torch's route); L^-1 is never formed
+    if (set_max_lds((const void*)k_trsm_slab<0>, trsm_lds) || set_max_lds((const void*)k_trsm_slab<1>, trsm_lds) ||
+        set_max_lds((const void*)k_trsm_slab<2>, trsm_lds)) return 1;
+    hipLaunchKernelGGL(k_vec_rv, dim3(cdiv(b.np, 128), b.batch), 128, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, ws + w.u, vec,
+                       0, g_Um, bws + b.gp_rows);
+    hipLaunchKernelGGL(k_trsm_slab<0>, dim3(1, b.batch), 256, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, bws + b.Dinv, dinv_stride, vec,
+                       (const float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(k_trsm_slab<1>, dim3(b.nbn + 1, b.batch), 256, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, bws + b.Dinv, dinv_stride,
+                       vec, (const float*)nullptr, bws + b.X);
+    hipLaunchKernelGGL(k_vec_rv, dim3(cdiv(b.np, 128), b.batch), 128, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, ws + w.u, vec,
+                       1, g_Um, bws + b.gp_rows);
+  } else {
+    hipLaunchKernelGGL(k_vec_q, dim3(cdiv(b.np, 4), b.batch), 256, 0, st, b.n, b.np, bws + b.Linv, bstride, vec);
+    hipLaunchKernelGGL(k_vec_a, dim3(cdiv(b.np, 4), b.batch), 256, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, bws + b.Linv,
+                       ws + w.u, vec, g_Um, bws + b.gp_rows);
+  }
   if (check_launch("cache bwd: solves")) return 1;
   {
     const size_t P = (size_t)M * (M + 1) / 2 * Do;
@@ -839,7 +1036,10 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
   if (rhs_vjp(kernel, Di, Do, M, S, pack, Z, bws + b.gp_rows, M, bws + b.vjpZ, 1, st)) return 1;
   if (param_grad(kernel, Di, Do, M, S, pack, Z, bws + b.gp_rows, M, bws + b.slab, b.nchunkZ, gpack, 1, 1, st)) return 1;
   // g_K = sym(L^-T Phi L^-1)
-  if (big_factor(b.np)) {            // big factor: both products on the matrix cores
+  if (solves) {                      // X = L^-T Phi is there already; S^T = L^-T X^T (the consumer symmetrises S)
+    hipLaunchKernelGGL(k_trsm_slab<2>, dim3(b.nbn, b.batch), 256, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, bws + b.Dinv, dinv_stride, vec,
+                       bws + b.X, bws + b.S);
+  } else if (big_factor(b.np)) {     // big factor: both products on the matrix cores
     const int klim = b.nbn * NB, nt = cdiv(klim, GT);
     const dim3 grid(nt, nt, b.batch);                // column tile on the slow axis: the longest k ranges start first
     hipLaunchKernelGGL(k_gemm_mfma<1>, grid, 256, 0, st, bws + b.Linv, bws + b.Linv, bstride, b.np, klim, vec, bws + b.X);
