@@ -501,8 +501,9 @@ __global__ __launch_bounds__(256, 2) void k_linv_dc_mfma(int step, int sb, int n
 // straight into MFMA operands, each element used once per slab).  Per block step: Y_k = Dinv_k(^T) R_k, then
 // R_j -= L_(k,j)^T Y_k for the blocks still to be solved (tiles dealt round-robin to the 4 wavefronts).
 // ---------------------------------------------------------------------------------------------
-constexpr int TSL = 33;                              // slab row stride in LDS (floats)
-static constexpr int kTrsmMaxNp = 1216;              // np * TSL floats must fit 160 KB
+constexpr int TSW = 16;                              // right-hand-side columns per slab (one MFMA tile column)
+constexpr int TSL = TSW + 1;                         // slab row stride in LDS (floats)
+static constexpr int kTrsmMaxNp = 1216;              // beyond: the explicit-inverse matrix-core route (BASELINE configs[4])
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_trsm_slab(int n, int np, int nbn, const float* __restrict__ Lall, size_t batch_stride,
@@ -519,17 +520,17 @@ __global__ __launch_bounds__(256) void k_trsm_slab(int n, int np, int nbn, const
   const float* vr = vec_all + (size_t)(3 * nb + b) * np;
   const float* vv = vec_all + (size_t)(4 * nb + b) * np;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lk = lane >> 4;
-  const int nrow = nbn * NB, c0 = slab * NB;
+  const int nrow = nbn * NB, c0 = slab * TSW, nslab = (nrow + TSW - 1) / TSW;   // MODE 1: slab nslab carries q
   // ---- right-hand sides -------------------------------------------------------------------
-  for (int e = tid; e < nrow * NB; e += 256) {
+  for (int e = tid; e < nrow * TSW; e += 256) {
     float v = 0.f;
     if (MODE == 0) {
-      const int i = e >> 5, c = e & 31;
+      const int i = e / TSW, c = e % TSW;
       if (c == 0 && i < n) v = vg[i];
       sY[i * TSL + c] = v;
     } else if (MODE == 1) {
-      const int i = e >> 5, c = e & 31, gj = c0 + c;
-      if (slab == nbn) { if (c == 0 && i < n) v = vq[i]; }
+      const int i = e / TSW, c = e % TSW, gj = c0 + c;
+      if (slab == nslab) { if (c == 0 && i < n) v = vq[i]; }
       else if (i < n && gj < n) {
         const float ph = -vr[i] * vq[gj] + vq[i] * vv[gj];
         v = i > gj ? ph : (i == gj ? 0.5f * ph : 0.f);
@@ -541,92 +542,109 @@ __global__ __launch_bounds__(256) void k_trsm_slab(int n, int np, int nbn, const
       sY[i * TSL + c] = v;
     }
   }
-  __syncthreads();
   // ---- block substitution ------------------------------------------------------------------
-  const int mb = wave >> 1, nbk = wave & 1;          // this wavefront's 16 x 16 block of the diagonal step
-  for (int step = 0; step < nbn; ++step) {
-    const int kb = TRANS ? nbn - 1 - step : step;
+  // diagonal step: wavefronts 0 / 1 own rows 0..15 / 16..31 of Y_k (two k-halves each, summed: two independent MFMA chains)
+  auto loadD = [&](int kb, float (&df)[NB / 4]) {    // A operand of Dinv_k^T (TRANS) / Dinv_k for row block mb = wave & 1
     const float* Dk = Dinv + (size_t)kb * NB * NB;
-    float* Rk = sY + (size_t)kb * NB * TSL;
-    // Y_k = Dinv_k^T R_k (TRANS) or Dinv_k R_k: one 16 x 16 block per wavefront
-    gf32x4 acc = gf32x4{0.f, 0.f, 0.f, 0.f};
+    const int m = (wave & 1) * 16 + lr;
 #pragma unroll
     for (int ks = 0; ks < NB / 4; ++ks) {
       const int k = 4 * ks + lk;
-      const float a = TRANS ? Dk[k * NB + mb * 16 + lr] : Dk[(mb * 16 + lr) * NB + k];
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Rk[k * TSL + nbk * 16 + lr], acc, 0, 0, 0);
+      df[ks] = TRANS ? Dk[k * NB + m] : Dk[m * NB + k];
     }
-    __syncthreads();                                 // every wavefront has read R_k
+  };
+  auto loadA = [&](int kb, int t, float (&af)[2][NB / 4]) {   // tile t of the step: TRANS: L[kb][j]^T, j = t; else L[j][kb], j = kb + 1 + t
+    const int j = TRANS ? t : kb + 1 + t;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Rk[(mb * 16 + 4 * lk + r) * TSL + nbk * 16 + lr] = acc[r];
+    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+      for (int ks = 0; ks < NB / 4; ++ks) {
+        const int k = 4 * ks + lk, m = m2 * 16 + lr;
+        const int row = TRANS ? kb * NB + k : j * NB + m, col = TRANS ? j * NB + m : kb * NB + k;
+        af[m2][ks] = (row < n && col < n) ? Lm[(size_t)row * np + col] : 0.f;   // rows / columns >= n: not part of the factor
+      }
+  };
+  float dfn[NB / 4], afA[2][NB / 4], afB[2][NB / 4];
+  {
+    const int kb0 = TRANS ? nbn - 1 : 0;
+    if (wave < 2) loadD(kb0, dfn);
+    if (wave < (TRANS ? kb0 : nbn - 1 - kb0)) loadA(kb0, wave, afA);
+  }
+  __syncthreads();
+  for (int step = 0; step < nbn; ++step) {
+    const int kb = TRANS ? nbn - 1 - step : step;
+    float* Rk = sY + (size_t)kb * NB * TSL;
+    gf32x4 acc0 = gf32x4{0.f, 0.f, 0.f, 0.f}, acc1 = gf32x4{0.f, 0.f, 0.f, 0.f};
+    if (wave < 2) {
+#pragma unroll
+      for (int ks = 0; ks < NB / 8; ++ks) {          // k = 0..15 and 16..31 as two chains
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dfn[ks], Rk[(4 * ks + lk) * TSL + lr], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dfn[NB / 8 + ks], Rk[(4 * (NB / 8 + ks) + lk) * TSL + lr], acc1, 0, 0, 0);
+      }
+    }
+    __syncthreads();                                 // R_k has been read
+    if (wave < 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Rk[((wave & 1) * 16 + 4 * lk + r) * TSL + lr] = acc0[r] + acc1[r];
+    }
+    // the next step's diagonal-block operand travels under this step's update
+    const int kbn = TRANS ? kb - 1 : kb + 1;
+    if (wave < 2 && step + 1 < nbn) loadD(kbn, dfn);
     __syncthreads();
     // R_j -= A_j Y_k for the blocks still to be solved: TRANS: j < kb, A_j = L[kb][j]^T; else j > kb, A_j = L[j][kb]
     const int ntile = TRANS ? kb : nbn - 1 - kb;
     if (ntile > 0) {
-      float bf[2][NB / 4];                           // Y_k as B operand, shared by all tiles of the step
+      float bf[NB / 4];                              // Y_k as B operand, shared by all tiles of the step
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int ks = 0; ks < NB / 4; ++ks) bf[q][ks] = Rk[(4 * ks + lk) * TSL + q * 16 + lr];
-      auto loadA = [&](int t, float (&af)[2][NB / 4]) {
-        const int j = TRANS ? t : kb + 1 + t;
-#pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-          for (int ks = 0; ks < NB / 4; ++ks) {
-            const int k = 4 * ks + lk, m = m2 * 16 + lr;
-            const int row = TRANS ? kb * NB + k : j * NB + m, col = TRANS ? j * NB + m : kb * NB + k;
-            af[m2][ks] = (row < n && col < n) ? Lm[(size_t)row * np + col] : 0.f;   // rows / columns >= n: not part of the factor
-          }
-      };
-      float afA[2][NB / 4], afB[2][NB / 4];
-      int t = wave;
-      if (t < ntile) loadA(t, afA);
+      for (int ks = 0; ks < NB / 4; ++ks) bf[ks] = Rk[(4 * ks + lk) * TSL + lr];
       auto tile = [&](int tcur, const float (&af)[2][NB / 4]) {
         const int j = TRANS ? tcur : kb + 1 + tcur;
         float* Rj = sY + (size_t)j * NB * TSL;
+        gf32x4 c0v = gf32x4{0.f, 0.f, 0.f, 0.f}, c1v = gf32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2)
+        for (int ks = 0; ks < NB / 4; ++ks) {        // the two row halves interleaved: independent accumulators back to back
+          c0v = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][ks], bf[ks], c0v, 0, 0, 0);
+          c1v = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][ks], bf[ks], c1v, 0, 0, 0);
+        }
 #pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            gf32x4 c = gf32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < NB / 4; ++ks) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m2][ks], bf[q][ks], c, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float* dst = Rj + (m2 * 16 + 4 * lk + r) * TSL + q * 16 + lr;
-              *dst = *dst - c[r];
-            }
-          }
+        for (int r = 0; r < 4; ++r) {
+          float* d0 = Rj + (4 * lk + r) * TSL + lr;
+          float* d1 = Rj + (16 + 4 * lk + r) * TSL + lr;
+          *d0 = *d0 - c0v[r];
+          *d1 = *d1 - c1v[r];
+        }
       };
+      int t = wave;
       while (t < ntile) {                            // the next tile's operands travel while this one is multiplied
-        if (t + 4 < ntile) loadA(t + 4, afB);
+        if (t + 4 < ntile) loadA(kb, t + 4, afB);
         tile(t, afA);
         t += 4;
         if (t >= ntile) break;
-        if (t + 4 < ntile) loadA(t + 4, afA);
+        if (t + 4 < ntile) loadA(kb, t + 4, afA);
         tile(t, afB);
         t += 4;
       }
     }
+    // first tile of the next step (its factor tile does not depend on this step's result)
+    if (step + 1 < nbn && wave < (TRANS ? kbn : nbn - 1 - kbn)) loadA(kbn, wave, afA);
     __syncthreads();
   }
   // ---- results -------------------------------------------------------------------------------
   if (MODE == 0) {
     for (int i = tid; i < np; i += 256) vec_all[(size_t)(1 * nb + b) * np + i] = i < n ? sY[i * TSL] : 0.f;
   } else if (MODE == 1) {
-    if (slab == nbn) {
+    if (slab == nslab) {
       for (int i = tid; i < np; i += 256) vec_all[(size_t)(2 * nb + b) * np + i] = i < n ? sY[i * TSL] : 0.f;
     } else {
       float* X = Out_all + (size_t)b * batch_stride;
-      for (int e = tid; e < nrow * NB; e += 256) {
-        const int i = e >> 5, c = e & 31;
+      for (int e = tid; e < nrow * TSW; e += 256) {
+        const int i = e / TSW, c = e % TSW;
         X[(size_t)i * np + c0 + c] = sY[i * TSL + c];
       }
     }
   } else {
     float* Sm = Out_all + (size_t)b * batch_stride;  // S[c0 + c][i] = Y[i][c]
-    for (int e = tid; e < nrow * NB; e += 256) {
+    for (int e = tid; e < nrow * TSW; e += 256) {
       const int c = e / nrow, i = e - c * nrow;
       Sm[(size_t)(c0 + c) * np + i] = sY[i * TSL + c];
     }
@@ -1010,6 +1028,7 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
   if (!prepared && cache_bwd_prepare(kernel, Di, Do, M, S, ws, bws, st)) return 1;
   const bool solves = use_trsm(b.np);
   const size_t trsm_lds = sizeof(float) * (size_t)b.nbn * NB * TSL;
+  const int nslab = (b.nbn * NB + TSW - 1) / TSW;
   if (solves) {
     // triangular solves with the factor (torch's route); L^-1 is never formed
     if (set_max_lds((const void*)k_trsm_slab<0>, trsm_lds) || set_max_lds((const void*)k_trsm_slab<1>, trsm_lds) ||
@@ -1018,7 +1037,7 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
                        0, g_Um, bws + b.gp_rows);
     hipLaunchKernelGGL(k_trsm_slab<0>, dim3(1, b.batch), 256, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, bws + b.Dinv, dinv_stride, vec,
                        (const float*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL(k_trsm_slab<1>, dim3(b.nbn + 1, b.batch), 256, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, bws + b.Dinv, dinv_stride,
+    hipLaunchKernelGGL(k_trsm_slab<1>, dim3(nslab + 1, b.batch), 256, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, bws + b.Dinv, dinv_stride,
                        vec, (const float*)nullptr, bws + b.X);
     hipLaunchKernelGGL(k_vec_rv, dim3(cdiv(b.np, 128), b.batch), 128, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, ws + w.u, vec,
                        1, g_Um, bws + b.gp_rows);
@@ -1037,7 +1056,7 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
   if (param_grad(kernel, Di, Do, M, S, pack, Z, bws + b.gp_rows, M, bws + b.slab, b.nchunkZ, gpack, 1, 1, st)) return 1;
   // g_K = sym(L^-T Phi L^-1)
   if (solves) {                      // X = L^-T Phi is there already; S^T = L^-T X^T (the consumer symmetrises S)
-    hipLaunchKernelGGL(k_trsm_slab<2>, dim3(b.nbn, b.batch), 256, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, bws + b.Dinv, dinv_stride, vec,
+    hipLaunchKernelGGL(k_trsm_slab<2>, dim3(nslab, b.batch), 256, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, bws + b.Dinv, dinv_stride, vec,
                        bws + b.X, bws + b.S);
   } else if (big_factor(b.np)) {     // big factor: both products on the matrix cores
     const int klim = b.nbn * NB, nt = cdiv(klim, GT);
