@@ -505,15 +505,20 @@ constexpr int TSW = 16;                              // right-hand-side columns 
 constexpr int TSL = TSW + 1;                         // slab row stride in LDS (floats)
 static constexpr int kTrsmMaxNp = 1216;              // beyond: the explicit-inverse matrix-core route (BASELINE configs[4])
 
+constexpr int TNW = 8;                               // wavefronts per slab workgroup
+
 template <int MODE>
-__global__ __launch_bounds__(256) void k_trsm_slab(int n, int np, int nbn, const float* __restrict__ Lall, size_t batch_stride,
-                                                    const float* __restrict__ Dinv_all, size_t dinv_stride,
-                                                    float* __restrict__ vec_all, const float* __restrict__ Xin_all,
-                                                    float* __restrict__ Out_all) {
-  extern __shared__ __attribute__((aligned(16))) float sY[];        // [32 nbn][TSL]
+__global__ __launch_bounds__(64 * TNW) void k_trsm_slab(int n, int np, int nbn, const float* __restrict__ Lall, size_t batch_stride,
+                                                         const float* __restrict__ Dfac_all, size_t dfac_stride,
+                                                         const float* __restrict__ Dinv_all, size_t dinv_stride,
+                                                         float* __restrict__ vec_all, const float* __restrict__ Xin_all,
+                                                         float* __restrict__ Out_all) {
+  extern __shared__ __attribute__((aligned(16))) float sY[];        // [32 nbn][TSL] slab, then two [32][TSL] scratch tiles
   constexpr bool TRANS = MODE != 0;
+  constexpr int NT = 64 * TNW;
   const int slab = blockIdx.x, b = blockIdx.y, nb = gridDim.y;
   const float* Lm = Lall + (size_t)b * batch_stride;
+  const float* Dfac = Dfac_all + (size_t)b * dfac_stride;
   const float* Dinv = Dinv_all + (size_t)b * dinv_stride;
   const float* vg = vec_all + (size_t)(0 * nb + b) * np;
   const float* vq = vec_all + (size_t)(1 * nb + b) * np;
@@ -521,8 +526,10 @@ __global__ __launch_bounds__(256) void k_trsm_slab(int n, int np, int nbn, const
   const float* vv = vec_all + (size_t)(4 * nb + b) * np;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lk = lane >> 4;
   const int nrow = nbn * NB, c0 = slab * TSW, nslab = (nrow + TSW - 1) / TSW;   // MODE 1: slab nslab carries q
+  float* sT0 = sY + (size_t)nrow * TSL;              // first solution y0 of the diagonal step
+  float* sT1 = sT0 + NB * TSL;                       // its residual
   // ---- right-hand sides -------------------------------------------------------------------
-  for (int e = tid; e < nrow * TSW; e += 256) {
+  for (int e = tid; e < nrow * TSW; e += NT) {
     float v = 0.f;
     if (MODE == 0) {
       const int i = e / TSW, c = e % TSW;
@@ -543,14 +550,20 @@ __global__ __launch_bounds__(256) void k_trsm_slab(int n, int np, int nbn, const
     }
   }
   // ---- block substitution ------------------------------------------------------------------
-  // diagonal step: wavefronts 0 / 1 own rows 0..15 / 16..31 of Y_k (two k-halves each, summed: two independent MFMA chains)
-  auto loadD = [&](int kb, float (&df)[NB / 4]) {    // A operand of Dinv_k^T (TRANS) / Dinv_k for row block mb = wave & 1
+  // Diagonal step, wavefronts 0 / 1 (rows 0..15 / 16..31 of the block): y0 = Dinv^(T) r, then ONE refinement with the block of the
+  // factor itself, y = y0 + Dinv^(T) (r - L_kk^(T) y0).  Dinv alone carries an error of eps * cond(L_kk) -- on a rank-deficient
+  // K_uu the pivots of a block range from 1 down to sqrt(jitter) -- the refined solution is as good as a substitution with L_kk.
+  auto loadD = [&](int kb, float (&df)[NB / 4], float (&lf)[NB / 4]) {   // A operands for row block mb = wave & 1
     const float* Dk = Dinv + (size_t)kb * NB * NB;
+    const float* Lk = Dfac + (size_t)kb * NB * NB;
     const int m = (wave & 1) * 16 + lr;
 #pragma unroll
     for (int ks = 0; ks < NB / 4; ++ks) {
       const int k = 4 * ks + lk;
       df[ks] = TRANS ? Dk[k * NB + m] : Dk[m * NB + k];
+      const int rr = TRANS ? k : m, cc = TRANS ? m : k;                  // element (rr, cc) of L_kk (lower triangle)
+      const bool in = kb * NB + rr < n && kb * NB + cc < n;
+      lf[ks] = in ? (cc <= rr ? Lk[rr * NB + cc] : 0.f) : (rr == cc ? 1.f : 0.f);   // rows / columns >= n: identity, as k_trinv_diag
     }
   };
   auto loadA = [&](int kb, int t, float (&af)[2][NB / 4]) {   // tile t of the step: TRANS: L[kb][j]^T, j = t; else L[j][kb], j = kb + 1 + t
@@ -564,32 +577,48 @@ __global__ __launch_bounds__(256) void k_trsm_slab(int n, int np, int nbn, const
         af[m2][ks] = (row < n && col < n) ? Lm[(size_t)row * np + col] : 0.f;   // rows / columns >= n: not part of the factor
       }
   };
-  float dfn[NB / 4], afA[2][NB / 4], afB[2][NB / 4];
+  // 32 x 16 product of this wavefront's 16 rows: A operand af (8 k-steps), B rows from an LDS tile; two chains over k
+  auto mm = [&](const float (&af)[NB / 4], const float* __restrict__ Bt) {
+    gf32x4 a0 = gf32x4{0.f, 0.f, 0.f, 0.f}, a1 = gf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NB / 8; ++ks) {
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks], Bt[(4 * ks + lk) * TSL + lr], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[NB / 8 + ks], Bt[(4 * (NB / 8 + ks) + lk) * TSL + lr], a1, 0, 0, 0);
+    }
+    return a0 + a1;
+  };
+  float dfn[NB / 4], lfn[NB / 4], afA[2][NB / 4], afB[2][NB / 4];
   {
     const int kb0 = TRANS ? nbn - 1 : 0;
-    if (wave < 2) loadD(kb0, dfn);
+    if (wave < 2) loadD(kb0, dfn, lfn);
     if (wave < (TRANS ? kb0 : nbn - 1 - kb0)) loadA(kb0, wave, afA);
   }
   __syncthreads();
   for (int step = 0; step < nbn; ++step) {
     const int kb = TRANS ? nbn - 1 - step : step;
     float* Rk = sY + (size_t)kb * NB * TSL;
-    gf32x4 acc0 = gf32x4{0.f, 0.f, 0.f, 0.f}, acc1 = gf32x4{0.f, 0.f, 0.f, 0.f};
+    const int r0 = (wave & 1) * 16 + 4 * lk;         // this lane's accumulator rows r0 .. r0 + 3, column lr
+    gf32x4 y0;
     if (wave < 2) {
+      y0 = mm(dfn, Rk);
 #pragma unroll
-      for (int ks = 0; ks < NB / 8; ++ks) {          // k = 0..15 and 16..31 as two chains
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dfn[ks], Rk[(4 * ks + lk) * TSL + lr], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dfn[NB / 8 + ks], Rk[(4 * (NB / 8 + ks) + lk) * TSL + lr], acc1, 0, 0, 0);
-      }
+      for (int r = 0; r < 4; ++r) sT0[(r0 + r) * TSL + lr] = y0[r];
     }
-    __syncthreads();                                 // R_k has been read
+    __syncthreads();
     if (wave < 2) {
+      const gf32x4 p = mm(lfn, sT0);                 // L_kk^(T) y0
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Rk[((wave & 1) * 16 + 4 * lk + r) * TSL + lr] = acc0[r] + acc1[r];
+      for (int r = 0; r < 4; ++r) sT1[(r0 + r) * TSL + lr] = Rk[(r0 + r) * TSL + lr] - p[r];
     }
-    // the next step's diagonal-block operand travels under this step's update
+    __syncthreads();                                 // residual complete; R_k no longer needed
+    if (wave < 2) {
+      const gf32x4 d = mm(dfn, sT1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Rk[(r0 + r) * TSL + lr] = y0[r] + d[r];
+    }
+    // the next step's diagonal-block operands travel under this step's update
     const int kbn = TRANS ? kb - 1 : kb + 1;
-    if (wave < 2 && step + 1 < nbn) loadD(kbn, dfn);
+    if (wave < 2 && step + 1 < nbn) loadD(kbn, dfn, lfn);
     __syncthreads();
     // R_j -= A_j Y_k for the blocks still to be solved: TRANS: j < kb, A_j = L[kb][j]^T; else j > kb, A_j = L[j][kb]
     const int ntile = TRANS ? kb : nbn - 1 - kb;
@@ -616,13 +645,13 @@ __global__ __launch_bounds__(256) void k_trsm_slab(int n, int np, int nbn, const
       };
       int t = wave;
       while (t < ntile) {                            // the next tile's operands travel while this one is multiplied
-        if (t + 4 < ntile) loadA(kb, t + 4, afB);
+        if (t + TNW < ntile) loadA(kb, t + TNW, afB);
         tile(t, afA);
-        t += 4;
+        t += TNW;
         if (t >= ntile) break;
-        if (t + 4 < ntile) loadA(kb, t + 4, afA);
+        if (t + TNW < ntile) loadA(kb, t + TNW, afA);
         tile(t, afB);
-        t += 4;
+        t += TNW;
       }
     }
     // first tile of the next step (its factor tile does not depend on this step's result)
@@ -631,20 +660,20 @@ __global__ __launch_bounds__(256) void k_trsm_slab(int n, int np, int nbn, const
   }
   // ---- results -------------------------------------------------------------------------------
   if (MODE == 0) {
-    for (int i = tid; i < np; i += 256) vec_all[(size_t)(1 * nb + b) * np + i] = i < n ? sY[i * TSL] : 0.f;
+    for (int i = tid; i < np; i += NT) vec_all[(size_t)(1 * nb + b) * np + i] = i < n ? sY[i * TSL] : 0.f;
   } else if (MODE == 1) {
     if (slab == nslab) {
-      for (int i = tid; i < np; i += 256) vec_all[(size_t)(2 * nb + b) * np + i] = i < n ? sY[i * TSL] : 0.f;
+      for (int i = tid; i < np; i += NT) vec_all[(size_t)(2 * nb + b) * np + i] = i < n ? sY[i * TSL] : 0.f;
     } else {
       float* X = Out_all + (size_t)b * batch_stride;
-      for (int e = tid; e < nrow * TSW; e += 256) {
+      for (int e = tid; e < nrow * TSW; e += NT) {
         const int i = e / TSW, c = e % TSW;
         X[(size_t)i * np + c0 + c] = sY[i * TSL + c];
       }
     }
   } else {
     float* Sm = Out_all + (size_t)b * batch_stride;  // S[c0 + c][i] = Y[i][c]
-    for (int e = tid; e < nrow * TSW; e += 256) {
+    for (int e = tid; e < nrow * TSW; e += NT) {
       const int c = e / nrow, i = e - c * nrow;
       Sm[(size_t)(c0 + c) * np + i] = sY[i * TSL + c];
     }
@@ -1027,7 +1056,7 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
   hipLaunchKernelGGL(k_gnu, dim3(cdiv(b.np, 128), b.batch), 128, 0, st, kernel, Di, Do, M, b.n, b.np, gpack_ind, ws + w.var, vec);
   if (!prepared && cache_bwd_prepare(kernel, Di, Do, M, S, ws, bws, st)) return 1;
   const bool solves = use_trsm(b.np);
-  const size_t trsm_lds = sizeof(float) * (size_t)b.nbn * NB * TSL;
+  const size_t trsm_lds = sizeof(float) * (size_t)(b.nbn + 2) * NB * TSL;
   const int nslab = (b.nbn * NB + TSW - 1) / TSW;
   if (solves) {
     // triangular solves with the factor (torch's route); L^-1 is never formed
@@ -1035,9 +1064,9 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
         set_max_lds((const void*)k_trsm_slab<2>, trsm_lds)) return 1;
     hipLaunchKernelGGL(k_vec_rv, dim3(cdiv(b.np, 128), b.batch), 128, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, ws + w.u, vec,
                        0, g_Um, bws + b.gp_rows);
-    hipLaunchKernelGGL(k_trsm_slab<0>, dim3(1, b.batch), 256, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, bws + b.Dinv, dinv_stride, vec,
+    hipLaunchKernelGGL(k_trsm_slab<0>, dim3(1, b.batch), 64 * TNW, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, Dfac, dstride, bws + b.Dinv, dinv_stride, vec,
                        (const float*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL(k_trsm_slab<1>, dim3(nslab + 1, b.batch), 256, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, bws + b.Dinv, dinv_stride,
+    hipLaunchKernelGGL(k_trsm_slab<1>, dim3(nslab + 1, b.batch), 64 * TNW, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, Dfac, dstride, bws + b.Dinv, dinv_stride,
                        vec, (const float*)nullptr, bws + b.X);
     hipLaunchKernelGGL(k_vec_rv, dim3(cdiv(b.np, 128), b.batch), 128, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, ws + w.u, vec,
                        1, g_Um, bws + b.gp_rows);
@@ -1056,7 +1085,7 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
   if (param_grad(kernel, Di, Do, M, S, pack, Z, bws + b.gp_rows, M, bws + b.slab, b.nchunkZ, gpack, 1, 1, st)) return 1;
   // g_K = sym(L^-T Phi L^-1)
   if (solves) {                      // X = L^-T Phi is there already; S^T = L^-T X^T (the consumer symmetrises S)
-    hipLaunchKernelGGL(k_trsm_slab<2>, dim3(nslab, b.batch), 256, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, bws + b.Dinv, dinv_stride, vec,
+    hipLaunchKernelGGL(k_trsm_slab<2>, dim3(nslab, b.batch), 64 * TNW, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, Dfac, dstride, bws + b.Dinv, dinv_stride, vec,
                        bws + b.X, bws + b.S);
   } else if (big_factor(b.np)) {     // big factor: both products on the matrix cores
     const int klim = b.nbn * NB, nt = cdiv(klim, GT);
