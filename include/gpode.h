@@ -104,6 +104,13 @@ int gpode_cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, const floa
  * definite -- torch.linalg.cholesky raises there, kernels.py:163/:384).  Copies one int to the host and
  * synchronises `stream`. */
 int gpode_cache_info(const float* ws, int* host_info, void* stream);
+/* Conditioning estimate of the draw's factor(s): host_min_max[0] / [1] = the smallest / largest diagonal entry of L
+ * (K_uu + jitter I = L L^T, kernels.py:163 / :384); their ratio squared bounds cond(K_uu) from below.  Synchronises `stream`. */
+int gpode_cache_pivots(const float* ws, float* host_min_max, void* stream);
+/* Route of gpode_cache_build_bwd through the factor (the autograd of kernels.py:163-171 / :384-386): 0 auto (triangular solves up
+ * to 192 rows, an explicit triangular inverse beyond), 1 always triangular solves (up to 1216 rows; slower, and as accurate as
+ * torch's fp32 solves on a numerically rank-deficient K_uu, where the explicit inverse is not), 2 never.  Process-wide. */
+int gpode_set_backward_solves(int mode);
 
 /* kern.K(X, X2) (kernels.py:98-110 / :289-303), no jitter.  X (N,Di), X2 (M2,Di).
  * RBF: out (Do,N,M2).  DF: out (N*D, M2*D), row (n,a), col (m,b). */

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def run(tmp, tag, world, extra, port):
     env = dict(os.environ, GPODE_DIST_BACKEND='gloo', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
     base = ['-m', 'vae_gp_ode_amd.main', '--task', 'synthetic', '--Ndata', '10', '--Ntest', '4', '--batch', '4', '--T', '6', '--solver', 'rk4',
-            '--num_inducing', '16', '--num_features', '32', '--lr', '1e-3', '--log_freq', '1', '--Nepoch', '4', '--save', 'results/' + tag,
+            '--num_inducing', '16', '--num_features', '32', '--lr', '1e-3', '--log_freq', '1', '--Nepoch', '6', '--save', 'results/' + tag,
             '--sync_bn', 'False'] + extra
     if world == 1:
         cmd = [sys.executable] + base
@@ -20,8 +20,8 @@ def run(tmp, tag, world, extra, port):
 
 tmp = tempfile.mkdtemp()
 runs = {}
-for tag, world, extra, port in (('e2', 2, ['--device_noise', 'True'], 29571), ('g2a', 2, ['--hip_graph', 'True'], 29572),
-                                ('g2b', 2, ['--hip_graph', 'True'], 29574), ('g2c', 2, ['--hip_graph', 'True'], 29575)):
+for tag, world, extra, port in (('e2', 2, ['--device_noise', 'True'], 29571), ('e2o', 2, ['--device_noise', 'True', '--gp_side_stream', 'True'], 29573),
+                                ('g2a', 2, ['--hip_graph', 'True'], 29572), ('g2b', 2, ['--hip_graph', 'True'], 29574)):
     runs[tag] = run(tmp, tag, world, extra, port)
 n = min(len(v) for v in runs.values())
 print('iter   ' + '   '.join('%12s' % k for k in runs))

@@ -25,6 +25,8 @@ SIGNATURES = {
     'gpode_cache_build_bwd': (_i, [_i] * 5 + [_c_float_p] * 13 + [_i, ctypes.c_void_p]),
     'gpode_cache_bwd_prepare': (_i, [_i] * 5 + [_c_float_p] * 2 + [ctypes.c_void_p]),
     'gpode_cache_info': (_i, [_c_float_p, ctypes.POINTER(_i), ctypes.c_void_p]),
+    'gpode_cache_pivots': (_i, [_c_float_p, ctypes.POINTER(ctypes.c_float), ctypes.c_void_p]),
+    'gpode_set_backward_solves': (_i, [_i]),
     'gpode_kernel_matrix': (_i, [_i, _i, _i, _c_float_p, _c_float_p, _c_float_p, _i, _c_float_p, _i, _c_float_p, ctypes.c_void_p]),
     'gpode_conditional_ws': (_i, [_i, _i, _i, _i, _sz_p]),
     'gpode_conditional': (_i, [_i, _i, _i, _i] + [_c_float_p] * 5 + [_i, _c_float_p, _i] + [_c_float_p] * 3 + [ctypes.c_void_p]),

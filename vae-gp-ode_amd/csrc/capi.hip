@@ -41,6 +41,20 @@ int gpode_cache_info(const float* ws, int* host_info, void* stream) {
   return 0;
 }
 
+int gpode_cache_pivots(const float* ws, float* host_min_max, void* stream) {
+  // smallest and largest diagonal entry of the Cholesky factor(s) of this draw; synchronises `stream`
+  hipError_t e = hipMemcpyAsync(host_min_max, ws + 1, 2 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) return gp::set_error("gpode_cache_pivots: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int gpode_set_backward_solves(int mode) {
+  if (mode < 0 || mode > 2) return gp::set_error("gpode_set_backward_solves: mode %d (0 auto, 1 always, 2 never)", mode);
+  gp::set_backward_solves(mode);
+  return 0;
+}
+
 int gpode_rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack,
                   const float* x, int N, float* f, int mode, void* stream) {
   if (N < 0 || mode < 0 || mode > 2) return gp::set_error("gpode_rhs_fwd: N=%d mode=%d", N, mode);

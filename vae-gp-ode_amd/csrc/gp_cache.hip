@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
   }
   blk -= a.nb_ind;
   if (blk < a.nb_hyp) {
-    if (threadIdx.x < 4) a.info[threadIdx.x] = 0;
+    // status word, then the smallest / largest diagonal entry of the factor (float bit patterns; positive floats order like
+    // unsigned integers, so atomicMin / atomicMax on the bits work)
+    if (threadIdx.x < 4) a.info[threadIdx.x] = threadIdx.x == 1 ? 0x7f800000 : 0;
     for (int e = tid; e < Do * Di; e += 256) {
       float l = sEll[e];
       a.ell_ws[e] = l;
@@ -311,7 +313,7 @@ __device__ __forceinline__ bool chol32_panel_wave(float (&row)[NB], int lane) {
 
 __global__ __launch_bounds__(256) void k_chol_rl(float* __restrict__ Aall, float* __restrict__ Lall, int np,
                                                   size_t batch_stride, float* __restrict__ Dfac_all, size_t dfac_stride,
-                                                  int k, int* __restrict__ info, int nblk, int jlim) {
+                                                  int k, int* __restrict__ info, int nblk, int jlim, int nreal) {
   __shared__ float sD[NB][NB + 1], sI[NB][NB + 1], sJ[NB][NB + 1];     // loaded tiles A_kk, A_ik, A_jk
   __shared__ float lD[NB][NB + 1], lI[NB][NB + 1], lJ[NB][NB + 1];     // factored: L_kk, L_ik, L_jk
   float* A = Aall + (size_t)blockIdx.y * batch_stride;
@@ -366,8 +368,13 @@ __global__ __launch_bounds__(256) void k_chol_rl(float* __restrict__ Aall, float
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = ty + 8 * q;
-      if (i == k) Dfac[r * NB + tx] = lD[r][tx];
-      else Lm[(size_t)(i * NB + r) * np + c0 + tx] = lI[r][tx];
+      if (i == k) {
+        Dfac[r * NB + tx] = lD[r][tx];
+        if (r == tx && c0 + r < nreal) {             // diagonal of the factor proper (not the rhs row / identity padding)
+          atomicMin(reinterpret_cast<unsigned*>(info) + 1, __float_as_uint(lD[r][tx]));
+          atomicMax(reinterpret_cast<unsigned*>(info) + 2, __float_as_uint(lD[r][tx]));
+        }
+      } else Lm[(size_t)(i * NB + r) * np + c0 + tx] = lI[r][tx];
     }
   } else {
     // trailing tile: A_ij -= L_ik L_jk^T   (j == i: L_jk is L_ik)
@@ -765,6 +772,11 @@ __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, 
     __syncthreads();
     DPROBE(2);
   }
+  for (int j = tid; j < n; j += 512) {               // diagonal range of the factor (conditioning estimate, gpode_cache_pivots)
+    const float dj = sA[j * LD + j];
+    atomicMin(reinterpret_cast<unsigned*>(info) + 1, __float_as_uint(dj));
+    atomicMax(reinterpret_cast<unsigned*>(info) + 2, __float_as_uint(dj));
+  }
   // ---- nu = L^-T (u - y), y = row n of the factor: block back-substitution by wavefront 0 alone -- the residual lives in its
   // registers (lane l holds entries l, l + 64, l + 128), the 32 solved unknowns of a block travel as wave-uniform values
   // (v_readlane), so the 2 x nblk workgroup barriers of a shared-residual formulation disappear from the chain
@@ -961,7 +973,7 @@ int cache_sizes(int kernel, int Di, int Do, int M, int S, size_t* pack_floats, s
 }
 
 // Blocked Cholesky of `batch` np x np systems (A is consumed; L goes to Lmat below the diagonal tiles and to Dfac on them).
-static void cholesky_blocked(float* A, float* Lmat, float* Dfac, int np, int nblk, int batch, int* info, hipStream_t st) {
+static void cholesky_blocked(float* A, float* Lmat, float* Dfac, int np, int nblk, int batch, int* info, hipStream_t st, int nreal) {
   struct { int np, nblk, batch; } w{np, nblk, batch};
   const size_t bstride = (size_t)np * np, dstride = (size_t)nblk * NB * NB;
   constexpr int PB = ST / NB;                          // 32-blocks per 128-wide panel
@@ -974,7 +986,7 @@ static void cholesky_blocked(float* A, float* Lmat, float* Dfac, int np, int nbl
       for (int k = K * PB; k < jlim; ++k) {
         int tiles = 0;
         for (int j = k; j < jlim; ++j) tiles += w.nblk - j;
-        hipLaunchKernelGGL(k_chol_rl, dim3(tiles, w.batch), 256, 0, st, A, Lmat, w.np, bstride, Dfac, dstride, k, info, w.nblk, jlim);
+        hipLaunchKernelGGL(k_chol_rl, dim3(tiles, w.batch), 256, 0, st, A, Lmat, w.np, bstride, Dfac, dstride, k, info, w.nblk, jlim, nreal);
       }
       const int Tt = w.nblk / PB - (K + 1);
       if (Tt > 0)
@@ -983,7 +995,7 @@ static void cholesky_blocked(float* A, float* Lmat, float* Dfac, int np, int nbl
   } else {
     for (int k = 0; k < w.nblk; ++k) {
       const int T = w.nblk - k;
-      hipLaunchKernelGGL(k_chol_rl, dim3(T * (T + 1) / 2, w.batch), 256, 0, st, A, Lmat, w.np, bstride, Dfac, dstride, k, info, w.nblk, w.nblk);
+      hipLaunchKernelGGL(k_chol_rl, dim3(T * (T + 1) / 2, w.batch), 256, 0, st, A, Lmat, w.np, bstride, Dfac, dstride, k, info, w.nblk, w.nblk, nreal);
     }
   }
 }
@@ -1048,7 +1060,7 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
     hipLaunchKernelGGL(k_Kzz_rbf, dim3(cdiv(w.np, 128), w.np, Do), 128, 0, st, Di, Do, M, w.np, Z, ws + w.ell, ws + w.var, up, A);
   else
     hipLaunchKernelGGL(k_Kzz_df, dim3(cdiv(w.np, 128), w.np, 1), 128, 0, st, Do, M, w.np, Z, ws + w.ell, ws + w.var, up, A);
-  cholesky_blocked(A, Lmat, Dfac, w.np, w.nblk, w.batch, info, st);
+  cholesky_blocked(A, Lmat, Dfac, w.np, w.nblk, w.batch, info, st, w.n);
   if (check_launch("cholesky")) return 1;
 
   // nu = L^-T (u - L^-1 u_prior), written to ws, to the optional output and into the pack
@@ -1225,7 +1237,7 @@ int conditional(int Di, int Do, int M, int N, const float* raw_ell, const float*
   int* info = reinterpret_cast<int*>(ws + c.info);
   const size_t bstride = (size_t)c.np * c.np, dstride = (size_t)c.nblk * NB * NB;
   hipLaunchKernelGGL(k_cond_fill, dim3(cdiv(c.np, 128), c.np, Do), 128, 0, st, Di, Do, M, N, c.np, raw_ell, raw_var, Z, x, ws + c.A, info);
-  cholesky_blocked(ws + c.A, ws + c.Lmat, ws + c.Dfac, c.np, c.nblk, Do, info, st);
+  cholesky_blocked(ws + c.A, ws + c.Lmat, ws + c.Dfac, c.np, c.nblk, Do, info, st, M);
   if (check_launch("conditional: cholesky")) return 1;
   const size_t lds = sizeof(float) * M;
   if (set_max_lds((const void*)k_cond_rows, lds)) return 1;

@@ -994,11 +994,22 @@ __global__ __launch_bounds__(256) void k_chain_df(int M, int S, const float* __r
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
-// solve-based route for every factor whose 32-column slab fits LDS (GPODE_BWD_EXPLICIT_INVERSE=1: the explicit L^-1 route for
-// every size, for A/B and tools/ab_bigfactor.py)
+// Which factors take the solve-based route: mode 0 "auto" (default): the LDS-resident sizes np <= 192 (BASELINE configs[0], [2],
+// [3]: six 128-row systems, where the solves cost nothing measurable); mode 1 "always": every factor whose slab fits LDS
+// (np <= 1216); mode 2 "never".  Past 192 rows the explicit inverse is faster (BASELINE configs[1], 608 rows: 3.25 vs 3.41 ms per
+// training step) and as accurate while the factor is well conditioned; the training loop switches to "always" when the pivots of
+// the factor approach the jitter floor (gpode_cache_pivots; main.py --backward_solves adaptive).
+static int g_solves_mode = [] {
+  const char* e = getenv("GPODE_BWD_SOLVES");
+  if (e && e[0] == '1') return 1;
+  const char* f = getenv("GPODE_BWD_EXPLICIT_INVERSE");
+  return (f && f[0] == '1') ? 2 : 0;
+}();
+void set_backward_solves(int mode) { g_solves_mode = mode; }
+int get_backward_solves() { return g_solves_mode; }
 static inline bool use_trsm(int np) {
-  static const bool off = [] { const char* e = getenv("GPODE_BWD_EXPLICIT_INVERSE"); return e && e[0] == '1'; }();
-  return !off && np <= kTrsmMaxNp;
+  if (g_solves_mode == 2) return false;
+  return g_solves_mode == 1 ? np <= kTrsmMaxNp : np <= 192;
 }
 
 int cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, size_t* bws_floats) {

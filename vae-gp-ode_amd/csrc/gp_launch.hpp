@@ -79,6 +79,8 @@ int conditional(int Di, int Do, int M, int N, const float* raw_ell, const float*
 int svgp_kl_fwd(int M, int Do, const float* Um, const float* Us, float* kl, hipStream_t st);
 int svgp_kl_bwd(int M, int Do, const float* Um, const float* Us, const float* g, float* dUm, float* dUs, hipStream_t st);
 
+void set_backward_solves(int mode);
+int get_backward_solves();
 int cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, size_t* bws_floats);
 int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_ell, const float* raw_var, const float* Z,
                     const float* eps_u, const float* pack, const float* ws, float* gpack, float* bws,

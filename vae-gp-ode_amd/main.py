@@ -60,11 +60,15 @@ EXT_FLAGS = [
     ('hip_graph', eval, False, 'replay each training step as one captured HIP graph, GP chains on a side stream, GP noise drawn '
                                'on the device (INTEGRATION.md); the reference draws GP noise from host numpy generators'),
     ('device_noise', eval, False, 'draw the GP noise on the device (seeded identically on every rank) without --hip_graph'),
+    ('backward_solves', str, 'adaptive', 'GP cache backward through the Cholesky factor: auto (triangular solves up to 192 rows, explicit '
+                                         'triangular inverse beyond: fastest), always (solves up to 1216 rows: torch-grade accuracy on a '
+                                         'rank-deficient K_uu), never, adaptive (auto, switched to always for the next epoch once the '
+                                         "factor's pivots span more than 200x, i.e. approach the jitter floor)"),
     ('gp_side_stream', eval, False, 'GP cache build / cache backward on a side stream next to the encoder, without --hip_graph'),
     ('sync_bn', eval, True, 'data parallel: BatchNorm normalises with the statistics of the GLOBAL minibatch (all ranks), as the '
                             'single-process reference does (vae.py:55,58,113,116,119)'),
 ]
-CHOICES = {'kernel': KERNELS, 'solver': SOLVERS}  # default 'euler' is accepted only as a default, as in the reference
+CHOICES = {'kernel': KERNELS, 'solver': SOLVERS, 'backward_solves': ['auto', 'always', 'never', 'adaptive']}  # default 'euler' is accepted only as a default, as in the reference
 
 
 def make_parser():
@@ -292,6 +296,9 @@ def main(argv=None):
         buf.copy_(minibatch, non_blocking=True)
         return g()
 
+    from . import ops as gp_ops
+    solves_mode = 'auto' if args.backward_solves == 'adaptive' else args.backward_solves
+    gp_ops.set_backward_solves(solves_mode)
     logger.info('********** Started Training **********')
     begin = time.time()
     for ep in range(args.Nepoch):
@@ -348,6 +355,14 @@ def main(argv=None):
                 break
         if bn_sync is not None:
             vae_ops.set_bn_sync(bn_sync)
+        if args.backward_solves == 'adaptive':       # once per epoch (the evaluation above has synchronised anyway)
+            lo, hi = model.flow.odefunc.diffeq.cache.pivot_range()
+            want = 'always' if not (lo > 0) or hi / lo >= 200.0 else 'auto'
+            if want != solves_mode:
+                solves_mode = want
+                gp_ops.set_backward_solves(want)
+                graphs.clear()                       # a captured step has its route baked in
+                logger.info('Cholesky pivots span {:.1f}x: cache backward route -> {}'.format(hi / lo if lo > 0 else float('inf'), want))
         logger.info('Epoch:{:4d}/{:4d}| tr_elbo:{:8.2f}({:8.2f}) | test_mse:{:5.3f}\n'.format(
             ep, args.Nepoch, meters['elbo'].val, meters['elbo'].avg, test_mse.item()))
     logger.info('********** Optimization completed **********')

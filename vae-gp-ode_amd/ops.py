@@ -117,6 +117,23 @@ class GPCache:
             raise _lib.GpodeError('linalg.cholesky: K_uu + jitter*I is not positive-definite')
 
 
+    def pivot_range(self):
+        """(min, max) diagonal entry of the draw's Cholesky factor(s): (max / min)^2 bounds cond(K_uu + jitter I) from below.
+        Synchronises the stream."""
+        mm = (ctypes.c_float * 2)()
+        _lib.call('gpode_cache_pivots', _ptr(self.ws), mm, _stream())
+        return float(mm[0]), float(mm[1])
+
+
+BACKWARD_SOLVES = {'auto': 0, 'always': 1, 'never': 2}
+
+
+def set_backward_solves(mode):
+    """How the cache backward goes through the factor: 'auto' (triangular solves up to 192 rows, explicit inverse beyond -- the
+    fastest on a well-conditioned K_uu), 'always' (solves up to 1216 rows: torch-grade accuracy on a rank-deficient K_uu), 'never'."""
+    _lib.call('gpode_set_backward_solves', BACKWARD_SOLVES[mode])
+
+
 def cache_build(kernel, raw_ell, raw_var, Z, Um, Us_packed, eps_u, rff_w, rff_eps, rff_u, want_Lu=False):
     """SVGP_Layer.build_cache (svpy.py:103-121) on the GPU."""
     Do, Di = raw_ell.shape
