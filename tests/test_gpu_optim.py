@@ -229,9 +229,11 @@ def test_main_trains_data_parallel_on_two_ranks(tmp_path, graph):
     assert len(ck) == 1 and all(torch.isfinite(v).all() for v in torch.load(ck[0]).values() if v.is_floating_point())
 
 
-def _run_dp(tmp_path, tag, port, extra, nepoch=4):
+def _run_dp(tmp_path, tag, port, extra, nepoch=6):
+    """-> per-iteration elbo values of a 2-rank run of main.py on synthetic sequences (10 sequences in batches of 4: ragged)."""
     import glob
     import os
+    import re
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -242,28 +244,26 @@ def _run_dp(tmp_path, tag, port, extra, nepoch=4):
            '--log_freq', '1', '--Nepoch', str(nepoch), '--save', 'results/' + tag] + extra
     r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    ck = glob.glob(str(tmp_path / 'results' / (tag + '_*') / 'odegpvae_mnist.pth'))
-    assert len(ck) == 1
-    return torch.load(ck[0], map_location='cpu')
+    log = glob.glob(str(tmp_path / 'results' / (tag + '_*') / 'logs'))
+    assert len(log) == 1
+    return [float(m.group(1)) for m in re.finditer(r'elbo\s+(-?[\d.]+)\(', open(log[0]).read())]
 
 
 def test_graph_replayed_data_parallel_run_equals_the_eager_one(tmp_path):
-    """Two ranks, four epochs over 10 sequences in batches of 4 (ragged last batch; L switches from 1 to 5 after epoch 2): every
+    """Two ranks, six epochs over 10 sequences in batches of 4 (ragged last batch; L switches from 1 to 5 after epoch 3): every
     graph key is captured once and REVISITED in later epochs.  The gradient gather / all-reduce / Adam run between the replays
     and read ``p.grad``: a replay must leave ``p.grad`` bound to the tensors that replay wrote (each captured graph has its own),
     and the step that doubles as a capture warm-up must hand over the gradients it really computed.  Same device-side noise on
-    both runs, so the parameters after the last epoch must agree."""
+    both runs, so the LOSS SEQUENCES must agree: a step taken with stale or never-computed gradients shows in every later
+    loss (round 1: the first graph step applied uninitialised memory).  Parameters are not compared entry by entry -- Adam moves
+    an entry whose gradient is round-off noise by +-lr whatever its sign, which turns a last-bit difference into 1e-3."""
     # per-rank BatchNorm statistics: the cross-rank exchange runs over gloo here (host code), which cannot be stream-captured
     a = _run_dp(tmp_path, 'eager', 29551, ['--device_noise', 'True', '--sync_bn', 'False'])
     b = _run_dp(tmp_path, 'graph', 29552, ['--hip_graph', 'True', '--sync_bn', 'False'])
-    worst = 0.0
-    for k, v in a.items():
-        if not v.is_floating_point() or k.endswith('_num_evals'):
-            continue
-        err = relerr(b[k], v)
-        worst = max(worst, err)
-        assert err < 1e-5, (k, err)
-    print('graph-replayed vs eager data-parallel run, worst relative parameter difference: %.2e' % worst)
+    assert len(a) == len(b) == 18
+    worst = max(abs(x - y) / max(abs(x), 1.0) for x, y in zip(a, b))
+    print('graph-replayed vs eager data-parallel run, worst relative loss difference over 18 steps: %.1e' % worst)
+    assert worst < 2e-5, (a, b)
 
 
 def test_nan_guard_reloads_the_last_checkpoint(tmp_path, monkeypatch, caplog):

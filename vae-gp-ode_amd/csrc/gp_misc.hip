@@ -51,25 +51,29 @@ int kernel_matrix(int kernel, int Di, int Do, const float* raw_ell, const float*
 
 // ---------------------------------------------------------------------------------------------
 // KL(q(u)||N(0,I)) = 0.5 sum_d [ -sum_m log L_mm^2 + sum_m Um[m,d]^2 + ||L_d||_F^2 - M ]
-// One workgroup per output dim; block reduction; one atomic per workgroup.  kl must be zeroed first.
+// ONE workgroup of 1024 threads walks every output dimension and reduces in a fixed order: no float atomics (the sum of per-
+// dimension atomics made kl_u differ in its last bits from run to run), no memset node in front of it.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_svgp_kl(int M, int Do, const float* __restrict__ Um, const float* __restrict__ Us,
-                                                 float* __restrict__ kl) {
-  __shared__ float red[4];
-  const int d = blockIdx.x;
+__global__ __launch_bounds__(1024) void k_svgp_kl(int M, int Do, const float* __restrict__ Um, const float* __restrict__ Us,
+                                                  float* __restrict__ kl) {
+  __shared__ float red[16];
   const size_t P = (size_t)M * (M + 1) / 2;
-  const float* row = Us + (size_t)d * P;
   float acc = 0.f;
-  for (size_t e = threadIdx.x; e < P; e += blockDim.x) acc = fmaf(row[e], row[e], acc);
-  for (int m = threadIdx.x; m < M; m += blockDim.x) {
-    float l = row[(size_t)m * (m + 1) / 2 + m];
-    float u = Um[m * Do + d];
+  for (size_t e = threadIdx.x; e < P * Do; e += blockDim.x) acc = fmaf(Us[e], Us[e], acc);
+  for (int e = threadIdx.x; e < M * Do; e += blockDim.x) {
+    const int m = e / Do, d = e % Do;
+    const float l = Us[(size_t)d * P + (size_t)m * (m + 1) / 2 + m];
+    const float u = Um[e];
     acc += u * u - logf(l * l);
   }
   acc = wave_allreduce_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(kl, 0.5f * (red[0] + red[1] + red[2] + red[3] - (float)M));
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    *kl = 0.5f * (t - (float)M * (float)Do);
+  }
 }
 
 // dUm = g Um ; dUs = g Us off the diagonal, g (Us - 1/Us) on it.   g = *gptr (device scalar)
@@ -92,9 +96,7 @@ __global__ void k_svgp_kl_bwd(int M, int Do, const float* __restrict__ Um, const
 }
 
 int svgp_kl_fwd(int M, int Do, const float* Um, const float* Us, float* kl, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(kl, 0, sizeof(float), st);
-  if (e != hipSuccess) return set_error("memset: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(k_svgp_kl, Do, 256, 0, st, M, Do, Um, Us, kl);
+  hipLaunchKernelGGL(k_svgp_kl, 1, 1024, 0, st, M, Do, Um, Us, kl);
   return check_launch("svgp_kl");
 }
 
