@@ -359,3 +359,57 @@ def test_hyperparameter_gradients_on_a_rank_deficient_kuu(M, Dd):
     print('M=%d D=%d  hip / fp32-oracle distance to fp64:' % (M, Dd), {k: '%.1e/%.1e' % v for k, v in rep.items()})
     for k, (e_hip, e_ref) in rep.items():
         assert e_hip < max((8 if k == 'raw_var' else 3) * e_ref, 2e-4), (k, e_hip, e_ref)
+
+
+@pytest.mark.parametrize('Di,Do,order,method', [(5, 5, 1, 'rk4'), (10, 10, 1, 'euler'), (10, 5, 2, 'rk4'), (7, 7, 1, 'midpoint')])
+def test_rbf_widths_outside_the_compiled_list(Di, Do, order, method):
+    """--latent_dim / --D_in / --D_out are free integers in the reference (main.py:45,77,79).  An RBF layer whose widths are not
+    compiled (5, 7, 10 ...) is evaluated at the next compiled width on zero-padded operands (ops.WidthPad), which is the same
+    arithmetic term for term: trajectories, f(x), the cached attributes' shapes and every gradient against the fp64 oracle at
+    the TRUE widths, with the tolerances of the compiled widths."""
+    from vae_gp_ode_amd import _lib
+    from vae_gp_ode_amd.model.core.flow import Flow
+    from vae_gp_ode_amd.model.core.svpy import SVGP_Layer
+    assert not _lib.load().gpode_supported(0, Di, Do)
+    M, S, N, T_ = 40, 96, 6, 5
+    p, nz, z0, ts, gw = synthetic_gp('RBF', Di, Do, M, S, N, T_, seed=31 * Di + Do)
+    gp = SVGP_Layer(Di, Do, M, S, kernel='RBF').cuda()
+    with torch.no_grad():
+        gp.kern.unconstrained_lengthscales.copy_(p['raw_ell']); gp.kern.unconstrained_variance.copy_(p['raw_var'])
+        gp.inducing_loc.optvar.copy_(p['Z']); gp.Um.optvar.copy_(p['Um']); gp.Us_sqrt.optvar.copy_(p['Us'])
+    flow = Flow(gp, order=order, solver=method).cuda()
+    gp.set_noise({k: v.cuda() for k, v in nz.items()})
+    zg = z0.cuda().requires_grad_(True)
+    zt = flow(zg, ts.cuda())
+    assert tuple(zt.shape) == (N, T_, Di)
+    (zt * gw.cuda()).sum().backward()
+    k = gp.kern
+    assert tuple(k.rff_omega.shape) == (Di, S, Do) and tuple(k.nu.shape) == (Do, M, 1) and tuple(k.rff_phase.shape) == (1, S, Do)
+    p64 = {kk: v.double().clone().requires_grad_(True) for kk, v in p.items()}
+    c64 = O.build_cache(p64, O.to_dtype(nz, torch.float64), 'RBF')
+    z64 = z0.double().clone().requires_grad_(True)
+    zt64 = O.flow_forward(z64, ts.double(), c64, order, method)
+    (zt64 * gw.double()).sum().backward()
+    p32 = {kk: v.clone().requires_grad_(True) for kk, v in p.items()}
+    z32 = z0.clone().requires_grad_(True)
+    zt32 = O.flow_forward(z32, ts, O.build_cache(p32, nz, 'RBF'), order, method)
+    (zt32 * gw).sum().backward()
+    assert relerr(zt, zt64) < 2e-4 + 3 * relerr(zt32, zt64)
+    x = z0.cuda()
+    assert relerr(gp(x), O.gp_forward(z0.double(), c64)) < 2e-4 + 3 * relerr(O.gp_forward(z0, O.build_cache(p, nz, 'RBF')), O.gp_forward(z0.double(), c64))
+    assert relerr(k.nu, c64['nu']) < 2e-4 + 3 * relerr(O.build_cache(p, nz, 'RBF')['nu'], c64['nu'])
+    got = {'raw_ell': k.unconstrained_lengthscales.grad, 'raw_var': k.unconstrained_variance.grad, 'Z': gp.inducing_loc.optvar.grad,
+           'Um': gp.Um.optvar.grad, 'Us': gp.Us_sqrt.optvar.grad}
+    for kk in got:
+        assert tuple(got[kk].shape) == tuple(p[kk].shape)
+        tol = 1e-3 + 3 * relerr(p32[kk].grad, p64[kk].grad)
+        assert relerr(got[kk], p64[kk].grad) < tol, (kk, relerr(got[kk], p64[kk].grad), tol)
+    assert relerr(zg.grad, z64.grad) < 5e-4 + 3 * relerr(z32.grad, z64.grad)
+
+
+def test_df_width_outside_the_compiled_list_is_refused_loudly():
+    from vae_gp_ode_amd import _lib
+    from vae_gp_ode_amd.model.core.svpy import SVGP_Layer
+    gp = SVGP_Layer(5, 5, 8, 16, kernel='DF').cuda()
+    with pytest.raises(_lib.GpodeError, match='divergence-free kernel is compiled for D in'):
+        gp.build_cache()

@@ -54,7 +54,13 @@ class RBF(nn.Module):
     def _set_cache(self, cache, noise):
         self._cache = cache
         self.rff_weights = noise['rff_w']
-        if self.dimwise or self.kernel_id != 'RBF':
+        if cache.Do != self.D_out or cache.Di != self.D_in:      # evaluated zero-padded (ops.WidthPad): expose the unpadded slices
+            pad = ops.width_pad(self.kernel_id, self.D_in, self.D_out)
+            idx = pad.index(cache.omega.device)
+            self.rff_weights = noise['rff_w'][:, :self.D_out]
+            self.rff_omega = cache.omega.index_select(0, idx)[..., :self.D_out]
+            self.rff_phase, self.nu = cache.phase[..., :self.D_out], cache.nu[:self.D_out]
+        elif self.dimwise or self.kernel_id != 'RBF':
             self.rff_omega, self.rff_phase, self.nu = cache.omega, cache.phase, cache.nu
         else:   # attribute layouts of the reference's non-dimwise branch (kernels.py:118-132,164-172)
             self.rff_omega, self.rff_phase = cache.omega[..., 0], cache.phase[..., 0]
@@ -67,11 +73,18 @@ class RBF(nn.Module):
 
     def rff_forward(self, x, S=None):
         """Prior sample f_prior(x) from the cached Fourier features (kernels.py:140-153 / :319-351)."""
-        return ops.rhs(self._need_cache(), x, mode=1)
+        return self._rhs(x, 1)
 
     def f_update(self, x, x2=None):
         """Pathwise update K(x,Z) nu with the cached nu (kernels.py:174-181 / :390-393)."""
-        return ops.rhs(self._need_cache(), x, mode=2)
+        return self._rhs(x, 2)
+
+    def _rhs(self, x, mode):
+        c = self._need_cache()
+        if c.Di != self.D_in or c.Do != self.D_out:
+            pad = ops.width_pad(self.kernel_id, self.D_in, self.D_out)
+            return ops.rhs(c, pad.state(x).contiguous(), mode=mode)[:, :self.D_out]
+        return ops.rhs(c, x, mode=mode)
 
     def forward(self, X, X2=None):
         return self.K(X, X2)

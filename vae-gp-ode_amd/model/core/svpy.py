@@ -45,6 +45,14 @@ class SVGP_Layer(torch.nn.Module):
         self.noise_source = NumpyNoise()
         self._next_noise = []
         self.cache = None
+        self._width_pad = False                      # resolved on first use (the library is loaded lazily)
+
+    @property
+    def width_pad(self):
+        """ops.WidthPad when (D_in, D_out) is not a compiled width (RBF: evaluated zero-padded at the next compiled one)."""
+        if self._width_pad is False:
+            self._width_pad = ops.width_pad(self.kernel_n, self.D_in, self.D_out)
+        return self._width_pad
 
     def us_packed(self):
         """The inducing scale in the packed lower-triangular layout (D_out, M(M+1)/2) the kernels consume.  q_diag=False:
@@ -87,8 +95,11 @@ class SVGP_Layer(torch.nn.Module):
             nz = dict(nz, rff_eps=nz['rff_eps'].unsqueeze(-1).expand(-1, -1, self.D_out).contiguous(),
                       rff_u=nz['rff_u'].unsqueeze(-1).expand(-1, -1, self.D_out).contiguous())
         raw_ell, raw_var = self.kern.raw_dimwise()
-        return nz, (raw_ell.detach(), raw_var.detach(), self.inducing_loc.optvar.detach(), self.Um.optvar.detach(),
-                    self.us_packed().detach())
+        params = (raw_ell.detach(), raw_var.detach(), self.inducing_loc.optvar.detach(), self.Um.optvar.detach(), self.us_packed().detach())
+        pad = self.width_pad
+        if pad is not None:
+            nz, params = pad.noise(nz), tuple(t.contiguous() for t in pad.params(*params))
+        return nz, params
 
     def _launch_cache_build(self, nz, params, want_Lu=False):
         self.cache = ops.cache_build(self.kernel_n, *params, nz['eps_u'], nz['rff_w'], nz['rff_eps'], nz['rff_u'], want_Lu=want_Lu)
@@ -126,6 +137,9 @@ class SVGP_Layer(torch.nn.Module):
         """f(x) = f_prior(x) + K(x,Z) nu for the cached draw (svpy.py:123-142)."""
         if self.cache is None:
             raise RuntimeError('call build_cache() first')
+        pad = self.width_pad
+        if pad is not None:
+            return ops.rhs(self.cache, pad.state(x).contiguous(), mode=0)[:, :self.D_out]
         return ops.rhs(self.cache, x, mode=0)
 
     def build_conditional(self, x, full_cov=False):

@@ -251,6 +251,92 @@ def kernel_matrix(kernel, raw_ell, raw_var, X, X2=None):
     return out
 
 
+# ---------------------------------------------------------------------------------------------
+# Latent widths outside the compiled specialisations (experiments/main.py:45,77,79 take any integers): the RBF vector field is
+# evaluated at the next compiled width on ZERO-PADDED operands, which reproduces the unpadded arithmetic term for term --
+#   extra input dimensions: state, inducing locations and frequency noise 0 there, so every difference and phase gains + 0 * 0;
+#   extra output dimensions: rff weights, inducing mean and eps_u 0 there, so f_prior(Z), u, nu and f are exactly 0 and the padded
+#   state components stay 0 along the whole trajectory (their own K_uu systems are factored and discarded).
+# The padding is a differentiable scatter / slice in torch on (M, D)-sized tensors; the kernels are the compiled ones.
+# The divergence-free kernel is NOT padded: its matrix-valued kernel carries the width itself (the (D - 1) of kernels.py:296 and the
+# normalisation of B(omega), kernels.py:327-336), so it runs at its compiled widths D in {2, 3, 4, 6, 8, 16} only.
+# ---------------------------------------------------------------------------------------------
+_RBF_COMPILED = None
+
+
+def _rbf_compiled():
+    global _RBF_COMPILED
+    if _RBF_COMPILED is None:
+        lib = _lib.load()
+        _RBF_COMPILED = [(di, do) for do in range(1, 17) for di in range(1, 17) if lib.gpode_supported(0, di, do)]
+    return _RBF_COMPILED
+
+
+class WidthPad:
+    """Embedding of an RBF layer of widths (Di, Do) into the compiled widths (Dip, Dop)."""
+
+    def __init__(self, Di, Do):
+        self.Di, self.Do = Di, Do
+        second_order = Di == 2 * Do                  # state [s, v] of ODEfunc.second_order (flow.py:33-38)
+        cands = [(a, b) for a, b in _rbf_compiled() if b >= Do and (a == 2 * b if second_order else (a >= Di and (a == b) == (Di == Do)))]
+        if not cands:
+            raise _lib.GpodeError('no compiled RBF width can hold D_in=%d, D_out=%d (largest: 16 x 16)' % (Di, Do))
+        self.Dip, self.Dop = min(cands, key=lambda c: (c[0] * c[1], c[0]))
+        # position of input dimension i in the padded input: order 2 keeps [s | v] as two halves of the padded state
+        self.in_index = list(range(Do)) + [self.Dop + j for j in range(Do)] if second_order else list(range(Di))
+        self._idx = {}
+
+    def index(self, device):
+        key = str(device)
+        if key not in self._idx:
+            self._idx[key] = torch.tensor(self.in_index, dtype=torch.long, device=device)
+        return self._idx[key]
+
+    def pad_in(self, t, dim):
+        """zero-pad input-dimension axis ``dim`` of t from Di to Dip (scatter at in_index)."""
+        shape = list(t.shape)
+        shape[dim] = self.Dip
+        return torch.zeros(shape, dtype=t.dtype, device=t.device).index_copy(dim, self.index(t.device), t)
+
+    def pad_out(self, t, dim, value=0.0):
+        shape = list(t.shape)
+        shape[dim] = self.Dop - self.Do
+        if shape[dim] == 0:
+            return t
+        return torch.cat((t, torch.full(shape, value, dtype=t.dtype, device=t.device)), dim=dim)
+
+    def params(self, raw_ell, raw_var, Z, Um, Us):
+        one = 0.5413248546129181                     # invsoftplus(1.0): lengthscale / variance 1 in the padded slots
+        # padded input columns of the real rows: raw 0, i.e. lengthscale softplus(0) = 0.69 -- any positive value does, the differences are 0
+        ell = self.pad_out(self.pad_in(raw_ell, 1), 0, one)
+        M = Z.shape[0]
+        P = M * (M + 1) // 2
+        diag = torch.zeros(P, dtype=Us.dtype, device=Us.device)
+        diag[torch.tensor([n * (n + 1) // 2 + n for n in range(M)], device=Us.device)] = 1e-3
+        Usp = Us if self.Dop == self.Do else torch.cat((Us, diag.expand(self.Dop - self.Do, P)), dim=0)
+        return ell, self.pad_out(raw_var, 0, one), self.pad_in(Z, 1), self.pad_out(Um, 1), Usp
+
+    def noise(self, nz):
+        return dict(eps_u=self.pad_out(nz['eps_u'], 1), rff_w=self.pad_out(nz['rff_w'], 1),
+                    rff_eps=self.pad_out(self.pad_in(nz['rff_eps'], 0), 2), rff_u=self.pad_out(nz['rff_u'], 2))
+
+    def state(self, z):
+        return self.pad_in(z, z.dim() - 1)
+
+    def unstate(self, z):
+        return z.index_select(z.dim() - 1, self.index(z.device))
+
+
+def width_pad(kernel, Di, Do):
+    """None when (kernel, Di, Do) is compiled; a WidthPad for other RBF widths; an error for other DF widths."""
+    if _lib.load().gpode_supported(KERNEL_ID[kernel], Di, Do):
+        return None
+    if kernel != 'RBF':
+        raise _lib.GpodeError('the divergence-free kernel is compiled for D in {2, 3, 4, 6, 8, 16}; D = %d is not (its kernel carries '
+                              'the width itself, so it cannot be evaluated on zero-padded operands)' % Do)
+    return WidthPad(Di, Do)
+
+
 class _SvgpKL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Um, Us, M):
@@ -351,8 +437,14 @@ class _Flow(torch.autograd.Function):
 def flow(gp, z0, ts, order, method):
     k = gp.kern
     raw_ell, raw_var = k.raw_dimwise() if hasattr(k, 'raw_dimwise') else (k.unconstrained_lengthscales, k.unconstrained_variance)
-    return _Flow.apply(z0, ts, raw_ell, raw_var, gp.inducing_loc.optvar,
-                       gp.Um.optvar, gp.us_packed() if hasattr(gp, 'us_packed') else gp.Us_sqrt.optvar, gp, order, method)
+    params = (raw_ell, raw_var, gp.inducing_loc.optvar, gp.Um.optvar, gp.us_packed() if hasattr(gp, 'us_packed') else gp.Us_sqrt.optvar)
+    pad = getattr(gp, 'width_pad', None)
+    if pad is None:
+        return _Flow.apply(z0, ts, *params, gp, order, method)
+    # a width outside the compiled list: the compiled kernels on zero-padded operands (see WidthPad); autograd carries the
+    # gradients back through the scatter / slice
+    zt = _Flow.apply(pad.state(z0), ts, *pad.params(*params), gp, order, method)
+    return pad.unstate(zt)
 
 
 def cache_bwd_prepare(cache):
