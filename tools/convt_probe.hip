@@ -20,7 +20,7 @@ template <class L> void run(const char* name, int B) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(z, HIP_SYMBOL(g_probe), sizeof(z));
     if (rep == 2)
-      printf("%s B=%d cycles: wstage %llu barrier %llu scatter %llu mma %llu store %llu total %llu\n", name, B, z[0], z[1], z[2], z[3], z[4], z[5]);
+      printf("%s B=%d cycles: wstage+range %llu barrier %llu scatter %llu prefetch %llu mma %llu store %llu jobsetup %llu total %llu\n", name, B, z[0], z[1], z[2], z[7], z[3], z[4], z[6], z[5]);
   }
   hipFree(x); hipFree(w); hipFree(b); hipFree(y);
 }
@@ -37,7 +37,7 @@ template <class L> void runb(const char* name, int B) {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(z, HIP_SYMBOL(g_probe), sizeof(z));
     if (rep == 2)
-      printf("%s B=%d cycles: wstage %llu barrier %llu scatter %llu mma %llu store %llu total %llu\n", name, B, z[0], z[1], z[2], z[3], z[4], z[5]);
+      printf("%s B=%d cycles: wstage+range %llu barrier %llu scatter %llu prefetch %llu mma %llu store %llu jobsetup %llu total %llu\n", name, B, z[0], z[1], z[2], z[7], z[3], z[4], z[6], z[5]);
   }
   hipFree(gy); hipFree(w); hipFree(gx);
 }

@@ -261,16 +261,21 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
         const int f = tid + NTHR * i;
         if (f < nf4) {
           const float v[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+          // one division per float4, then carries: plane / row / column of the following three elements
+          int pl = (4 * f) / (SH * SH), q = (4 * f) % (SH * SH), row = q / SH, col = q % SH;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const int e = 4 * f + k, pl = e / (SH * SH), q = e % (SH * SH);
-            img[pl * PS + (q / SH + PADL) * HP + q % SH + PADL] = in_bn ? bn_relu(v[k], *tf_slot(pl % KC)) : v[k];
+            img[pl * PS + (row + PADL) * HP + col + PADL] = in_bn ? bn_relu(v[k], *tf_slot(pl % KC)) : v[k];
+            if (SH % 4 != 0 || k < 3) {              // SH % 4 == 0: the four elements share a row
+              if (++col == SH) { col = 0; if (++row == SH) { row = 0; ++pl; } }
+            }
           }
         }
       }
     };
     // all (class, pixel tile, channel-tile column) jobs of this wavefront for the group staged in `img`
     auto jobs = [&](const float* __restrict__ img, int b0, int nimg) {
+      PROBE_T(pt_rng);
       // cost (k-steps) of all jobs of the group, and this wavefront's share [lo, hi) of it
       int wtot = 0;
       // class groups: a class on its own, or (PAIR) the two column-parity classes of one row parity, whose pixels
@@ -284,6 +289,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
       });
       const int lo = (wtot * jw) / NW, hi = (wtot * (jw + 1)) / NW;
       int cbase = 0;
+      PROBE_ADD(0, pt_rng);
       static_for<NCG>([&](auto c) {
         constexpr int c0 = PAIR ? 2 * decltype(c)::value : decltype(c)::value;
         using G = typename PL::template C<c0>;                       // px = 0 class of a pair (odd output columns)
@@ -301,6 +307,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
         const int ub = min(njobs, nlo <= 0 ? 0 : (nlo + ntaps - 1) / ntaps), ue = min(njobs, nhi <= 0 ? 0 : (nhi + ntaps - 1) / ntaps);
         cbase += njobs * ntaps;
         for (int u0 = ub; u0 < ue; u0 += TG) {
+          PROBE_T(pt_su);
           const int ng = min(TG, ue - u0);
           const int t0 = u0 / NJ, jc = u0 % NJ;      // NJ > 1 implies TG == 1
           // B-operand base address of this lane's pixel in each tile (invalid rows alias pixel 0; masked at the store)
@@ -323,6 +330,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
           for (int cc = 0; cc < NCJ; ++cc)
 #pragma unroll
             for (int r = 0; r < 4; ++r) bv[cc][r] = bias ? bias[n0 + (jc * NCJ + cc) * 16 + 4 * lk + r] : 0.f;
+          PROBE_ADD(6, pt_su);
           PROBE_T(pt_mm);
           auto run = [&](auto gtag, const float* sw, const int (&ab)[TG], f32x4 (&ac)[TG][NCJ]) {
             using GG = typename decltype(gtag)::type;
@@ -372,7 +380,9 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
         scatter(s_img, nimg);
         __syncthreads();
         PROBE_ADD(2, pt_sc);
+        PROBE_T(pt_pf);
         if (grp + gstride < ngroups) prefetch(grp + gstride);
+        PROBE_ADD(7, pt_pf);
         jobs(s_img, b0, nimg);
       }
     } else {

@@ -522,7 +522,15 @@ int tiled_fwd(const float* x, const float* w, const float* bias, float* y, int B
   }
   if (bias) return -1;
   if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec7, 2, 8, 1, 16, 2, 1, 256>(x, w, y, B, st);
-  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec4, 3, 8, 2, 32, 1, 1>(x, w, y, B, st);
+  // decnn.4 d/d input: 36 output pixels per image; two images and two 16-channel halves per pass make 10 equal jobs for 8
+  // wavefronts (tools/convt_probe.hip: 28 % of wavefront 0's cycles in the group barrier).  Three images per group with 16
+  // channels per pass (7 jobs, one idle wavefront) was measured and is NOT faster (0.455 vs 0.444 ms for d/d input + d/d weight at
+  // 4096 images: twice the passes over the source images eat the gain); GPODE_DEC4_BWD_3IMG=1 selects it for A/B.
+  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) {
+    static const bool alt = [] { const char* e = getenv("GPODE_DEC4_BWD_3IMG"); return e && e[0] == '1'; }();
+    if (alt) return launch_T2<Dec4, 3, 8, 3, 16, 1, 1>(x, w, y, B, st);
+    return launch_T2<Dec4, 3, 8, 2, 32, 1, 1>(x, w, y, B, st);
+  }
   if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec1, 8, 32, 6, 32, 1, 1>(x, w, y, B, st);
 
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) {
