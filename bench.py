@@ -597,18 +597,19 @@ def dominant_kernel_roofline(w, dev, reps=20):
     traffic, tsrc = None, None
     try:
         here = os.path.dirname(os.path.abspath(__file__))
-        rec = json.load(open(os.path.join(here, 'profiles', 'r01f_roofline_traffic.json')))
+        rec = json.load(open(os.path.join(here, 'profiles', 'r02a_roofline_traffic.json')))
         if rec.get('images') == B:
-            traffic, tsrc = rec['hbm_bytes_per_launch'], 'profiles/r01f_roofline_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)'
+            traffic, tsrc = rec['hbm_bytes_per_launch'], 'profiles/r02a_roofline_traffic.json: replayed from the committed rocprofv3 --pmc passes of this build (FETCH_SIZE x2 + WRITE_SIZE, separate passes; counters cannot be read from inside this process)'
     except (OSError, ValueError, KeyError):
         pass
     mfma_busy = None
     try:
-        mfma_busy = json.load(open(os.path.join(here, 'profiles', 'r01j_roofline_sq.json'))).get('mfma_busy_frac')
+        mfma_busy = json.load(open(os.path.join(here, 'profiles', 'r02a_roofline_sq.json'))).get('mfma_busy_frac')
     except (OSError, ValueError, NameError):
         pass
     return {'bound': 'mfma', 'kernel': 'k_conv_igemm<FwdPolicy<decnn.7>> (decoder decnn.7 forward, v_mfma_f32_16x16x4_f32)',
             'mfma_busy_frac_pmc': mfma_busy,
+            'mfma_busy_frac_source': 'profiles/r02a_roofline_sq.json: replayed from the committed rocprofv3 --pmc SQ pass of this build',
             'achieved': ach, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_TFLOPS, 'traffic': traffic,
             'traffic_source': tsrc, 'algorithmic_bytes': B * (32 * 169 + 16 * 784) * 4 + 32 * 16 * 25 * 4, 'ms_per_launch': ms,
             'note': 'algorithmic flops = 2 x 2.163 MMAC/image x %d images; exact fp32 on the matrix cores, priced against the '
