@@ -48,7 +48,7 @@ static BwsLayout bws_layout(int kernel, int Di, int Do, int M, int S, size_t pac
   b.slab = take((size_t)b.nchunkZ * pack_floats);
   b.gZpart = take((size_t)(kernel == 0 ? Do : 1) * M * Di);
   b.kpart_stride = kernel == 0 ? (1 + Di) : (Do + Do * Do);
-  b.kpart = take((size_t)(kernel == 0 ? Do * cdiv(M, 64) : M) * b.kpart_stride);
+  b.kpart = take((size_t)(kernel == 0 ? Do * M : M) * b.kpart_stride);
   b.gom = take(kernel == 1 ? (size_t)S * Do * Do : 4);
   b.total = o;
   return b;
@@ -708,39 +708,53 @@ __global__ void k_vec_rv(int kernel, int Do, int n, int np, const float* __restr
 // ---------------------------------------------------------------------------------------------
 // kernel-matrix backward.  G = (S + S^T)/2 multiplies BOTH triangles of K(Z) (torch's cholesky_backward).
 // ---------------------------------------------------------------------------------------------
-// RBF: grid (ceil(M/64), Do), block 64: thread = row point n.
+// RBF: grid (M, Do), block 64: one wavefront per (row point n, output dimension d); lanes stride over the other point m.
+//   gZpart[d][n][i];  kpart[d][n]: [gvar | gell(Di)]  (k_chain_rbf sums them over n in a fixed order)
 __global__ __launch_bounds__(64) void k_Kbwd_rbf(int Di, int Do, int M, int np, const float* __restrict__ Z,
                                                   const float* __restrict__ ell, const float* __restrict__ var,
                                                   const float* __restrict__ S_all, float* __restrict__ gZpart,
                                                   float* __restrict__ kpart) {
-  const int d = blockIdx.y, lane = threadIdx.x, n = blockIdx.x * 64 + lane;
+  const int n = blockIdx.x, d = blockIdx.y, lane = threadIdx.x;
   const float* Sm = S_all + (size_t)d * np * np;
   float gz[16], gl[16], zn[16], il[16];
   float gv = 0.f;
-  const bool ok = n < M;
-  for (int i = 0; i < Di; ++i) { gz[i] = 0.f; gl[i] = 0.f; zn[i] = ok ? Z[n * Di + i] : 0.f; il[i] = 1.f / ell[d * Di + i]; }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    gz[i] = 0.f; gl[i] = 0.f;
+    zn[i] = i < Di ? Z[n * Di + i] : 0.f;
+    il[i] = i < Di ? 1.f / ell[d * Di + i] : 0.f;
+  }
   const float vd = var[d];
-  if (ok) {
-    for (int m = 0; m < M; ++m) {
-      float qd = 0.f, dl[16];
-      for (int i = 0; i < Di; ++i) { dl[i] = zn[i] - Z[m * Di + i]; const float t = dl[i] * il[i]; qd = fmaf(t, t, qd); }
-      const float K = vd * expf(-0.5f * qd);
-      const float G = 0.5f * (Sm[(size_t)n * np + m] + Sm[(size_t)m * np + n]);
-      const float GK = G * K;
-      gv = fmaf(G, K / vd, gv);
-      for (int i = 0; i < Di; ++i) {
-        gz[i] = fmaf(-2.f * GK, dl[i] * il[i] * il[i], gz[i]);
-        gl[i] = fmaf(GK, dl[i] * dl[i] * il[i] * il[i] * il[i], gl[i]);
+  for (int m = lane; m < M; m += 64) {
+    float qd = 0.f, dl[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      dl[i] = i < Di ? zn[i] - Z[m * Di + i] : 0.f;
+      const float t = dl[i] * il[i];
+      qd = fmaf(t, t, qd);
+    }
+    const float E = expf(-0.5f * qd);
+    const float G = 0.5f * (Sm[(size_t)n * np + m] + Sm[(size_t)m * np + n]);
+    const float GK = G * vd * E;
+    gv = fmaf(G, E, gv);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      gz[i] = fmaf(-2.f * GK, dl[i] * il[i] * il[i], gz[i]);
+      gl[i] = fmaf(GK, dl[i] * dl[i] * il[i] * il[i] * il[i], gl[i]);
+    }
+  }
+  float* kp = kpart + ((size_t)d * M + n) * (1 + Di);
+  gv = wave_allreduce_sum(gv);
+  if (lane == 0) kp[0] = gv;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (i < Di) {                                    // wave-uniform
+      const float sz = wave_allreduce_sum(gz[i]), sl = wave_allreduce_sum(gl[i]);
+      if (lane == 0) {
+        gZpart[((size_t)d * M + n) * Di + i] = sz;
+        kp[1 + i] = sl;
       }
     }
-    for (int i = 0; i < Di; ++i) gZpart[((size_t)d * M + n) * Di + i] = gz[i];
-  }
-  gv = wave_allreduce_sum(gv);
-  float* kp = kpart + (size_t)(d * gridDim.x + blockIdx.x) * (1 + Di);
-  if (lane == 0) kp[0] = gv;
-  for (int i = 0; i < Di; ++i) {
-    const float s = wave_allreduce_sum(gl[i]);
-    if (lane == 0) kp[1 + i] = s;
   }
 }
 
@@ -827,47 +841,69 @@ __device__ __forceinline__ float rec_field(const float* __restrict__ base, size_
   return base[((rec_f4_base + (size_t)(field >> 2)) * 64 + lane) * 4 + (field & 3)];
 }
 
-// RBF: one block.  g_ell[d,i], g_var[d] -> raw; g_Z.
+// RBF: one workgroup per output scalar (Do * Di lengthscales, Do variances), threads over the summation index, fixed-order
+// reduction; the remaining workgroups assemble g_Z.  g_ell[d,i], g_var[d] -> raw.
 __global__ __launch_bounds__(256) void k_chain_rbf(int Di, int Do, int M, int S, const float* __restrict__ pack,
                                                     const float* __restrict__ gpack, const float* __restrict__ raw_ell,
                                                     const float* __restrict__ raw_var, const float* __restrict__ nu,
                                                     const float* __restrict__ vjpZ, const float* __restrict__ gZpart,
-                                                    const float* __restrict__ kpart, int nbx,
+                                                    const float* __restrict__ kpart,
                                                     float* __restrict__ g_raw_ell, float* __restrict__ g_raw_var,
                                                     float* __restrict__ g_Z) {
   const int RQ = cdiv(Di + 2, 4), RQ2 = cdiv(Di + Do, 4), SJ = cdiv(S, 64), MJ = cdiv(M, 64);
   const size_t rff_f4 = (size_t)SJ * Do * RQ * 64, ind_f4 = (size_t)MJ * RQ2 * 64;
   const float* gind = gpack + 4 * rff_f4;
   const float* guni = gpack + 4 * (rff_f4 + ind_f4);
-  const int tid = threadIdx.x;
-  for (int e = tid; e < Do * Di; e += 256) {
-    const int d = e / Di, i = e % Di;
+  const int tid = threadIdx.x, blk = blockIdx.x;
+  __shared__ float red[4];
+  auto block_sum = [&](float v) {                    // every thread gets the total
+    v = wave_allreduce_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  if (blk < Do * Di) {
+    const int e = blk, d = e / Di, i = e % Di;
     const float l = softplus_l(raw_ell[e]);
     float g = 0.f;
-    for (int s = 0; s < S; ++s) {
+    for (int s = tid; s < S; s += 256) {
       const size_t base = (size_t)((s >> 6) * Do + d) * RQ;
       g = fmaf(rec_field(gpack, base, s & 63, i), -rec_field(pack, base, s & 63, i) / l, g);  // om = eps/(2 pi l)
     }
-    g = fmaf(guni[e], GP_LOG2E / (l * l * l), g);                                             // wl = -log2e/(2 l^2)
-    for (int bx = 0; bx < nbx; ++bx) g += kpart[(size_t)(d * nbx + bx) * (1 + Di) + 1 + i];
-    g_raw_ell[e] = g * sigmoid_raw(raw_ell[e]);
-  }
-  for (int d = tid; d < Do; d += 256) {
+    float k = 0.f;
+    for (int n = tid; n < M; n += 256) k += kpart[((size_t)d * M + n) * (1 + Di) + 1 + i];
+    g = block_sum(g);
+    k = block_sum(k);
+    if (tid == 0) {
+      g = fmaf(guni[e], GP_LOG2E / (l * l * l), g);                                           // wl = -log2e/(2 l^2)
+      g_raw_ell[e] = (g + k) * sigmoid_raw(raw_ell[e]);
+    }
+  } else if (blk < Do * Di + Do) {
+    const int d = blk - Do * Di;
     const float v = softplus_l(raw_var[d]);
     float g = 0.f;
-    for (int s = 0; s < S; ++s) {
+    for (int s = tid; s < S; s += 256) {
       const size_t base = (size_t)((s >> 6) * Do + d) * RQ;
       g = fmaf(rec_field(gpack, base, s & 63, Di + 1), rec_field(pack, base, s & 63, Di + 1) / (2.f * v), g);  // aw = sqrt(v/S) w
     }
-    for (int m = 0; m < M; ++m) g = fmaf(rec_field(gind, (size_t)(m >> 6) * RQ2, m & 63, Di + d), nu[(size_t)d * M + m], g);  // cc = v nu
-    for (int bx = 0; bx < nbx; ++bx) g += kpart[(size_t)(d * nbx + bx) * (1 + Di)];
-    g_raw_var[d] = g * sigmoid_raw(raw_var[d]);
-  }
-  for (int e = tid; e < M * Di; e += 256) {
-    const int m = e / Di, i = e % Di;
-    float g = rec_field(gind, (size_t)(m >> 6) * RQ2, m & 63, i) + vjpZ[e];
-    for (int d = 0; d < Do; ++d) g += gZpart[((size_t)d * M + m) * Di + i];
-    g_Z[e] = g;
+    float c = 0.f, k = 0.f;
+    for (int m = tid; m < M; m += 256) {
+      c = fmaf(rec_field(gind, (size_t)(m >> 6) * RQ2, m & 63, Di + d), nu[(size_t)d * M + m], c);             // cc = v nu
+      k += kpart[((size_t)d * M + m) * (1 + Di)];
+    }
+    g = block_sum(g);
+    c = block_sum(c);
+    k = block_sum(k);
+    if (tid == 0) g_raw_var[d] = ((g + c) + k) * sigmoid_raw(raw_var[d]);
+  } else {
+    const int e = (blk - Do * Di - Do) * 256 + tid;
+    if (e < M * Di) {
+      const int m = e / Di, i = e % Di;
+      float g = rec_field(gind, (size_t)(m >> 6) * RQ2, m & 63, i) + vjpZ[e];
+      for (int d = 0; d < Do; ++d) g += gZpart[((size_t)d * M + m) * Di + i];
+      g_Z[e] = g;
+    }
   }
 }
 
@@ -1109,11 +1145,10 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
   }
   if (check_launch("cache bwd: gK")) return 1;
   if (kernel == 0) {
-    const int nbx = cdiv(M, 64);
-    hipLaunchKernelGGL(k_Kbwd_rbf, dim3(nbx, Do), 64, 0, st, Di, Do, M, b.np, Z, ws + w.ell, ws + w.var, bws + b.S,
+    hipLaunchKernelGGL(k_Kbwd_rbf, dim3(M, Do), 64, 0, st, Di, Do, M, b.np, Z, ws + w.ell, ws + w.var, bws + b.S,
                        bws + b.gZpart, bws + b.kpart);
-    hipLaunchKernelGGL(k_chain_rbf, 1, 256, 0, st, Di, Do, M, S, pack, gpack, raw_ell, raw_var, ws + w.nu, bws + b.vjpZ,
-                       bws + b.gZpart, bws + b.kpart, nbx, g_raw_ell, g_raw_var, g_Z);
+    hipLaunchKernelGGL(k_chain_rbf, Do * Di + Do + cdiv(M * Di, 256), 256, 0, st, Di, Do, M, S, pack, gpack, raw_ell, raw_var, ws + w.nu,
+                       bws + b.vjpZ, bws + b.gZpart, bws + b.kpart, g_raw_ell, g_raw_var, g_Z);
     return check_launch("cache bwd: chain");
   }
 #define X(D_)                                                                                                              \
