@@ -199,6 +199,21 @@ int gpode_bn_bwd_apply(const float* x, const float* gy, const float* gamma, cons
                        const float* save_invstd, const float* sums_gathered, const float* weights, int nranks, float count_all,
                        float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW, int relu, float* scratch,
                        void* stream);
+/* The decoder's last stage backward, fused: decnn.10 = ConvTranspose2d(16 -> 1, 5, stride 1, padding 2) on 28 x 28 (vae.py:121) fed by
+ * ReLU(BatchNorm2d(16)) (vae.py:119-120).  The gradient w.r.t. the normalised activation (25 multiply-adds per element from one
+ * 3 KB plane of gy) is recomputed inside both BatchNorm backward passes instead of being written once and read twice:
+ *   gpode_dec10_bn_bwd_sums   this shard's {sum g, sum g xhat} (partials stay in scratch; sums[32] too unless NULL)
+ *   gpode_dec10_bn_bwd_apply  gc = d loss / d c (c = the BatchNorm's input, B x 16 x 28 x 28), ggamma, gbeta, and the channel sums of gc
+ *                             (gc_chansum, may be NULL).  sums_gathered == NULL: statistics of this rank alone; otherwise as
+ *                             gpode_bn_bwd_apply.  Must be given the scratch gpode_dec10_bn_bwd_sums just used.
+ * c: the BatchNorm input, gy: B x 1 x 28 x 28, w: decnn.10's weight [16][1][5][5]; scratch: gpode_dec10_bn_scratch_floats() floats.
+ * Replaces gpode_conv2d_fwd (as the d/d input of decnn.10) + gpode_bn_bwd / gpode_bn_bwd_sums + gpode_bn_bwd_apply for this stage. */
+int gpode_dec10_bn_scratch_floats(void);
+int gpode_dec10_bn_bwd_sums(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* save_mean,
+                            const float* save_invstd, float* sums, int B, float* scratch, void* stream);
+int gpode_dec10_bn_bwd_apply(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* save_mean,
+                             const float* save_invstd, const float* sums_gathered, const float* weights, int nranks, float count_all,
+                             float* gc, float* ggamma, float* gbeta, float* gc_chansum, int B, float* scratch, void* stream);
 /* nn.BatchNorm2d in EVALUATION mode (running statistics; main.py:157-163 puts the pre-trained VAE in eval()).
  * gy == NULL: out = y = relu?(affine(x)); gy != NULL: out = d/dx (frozen layer: no affine gradients). */
 int gpode_bn_eval(const float* x, const float* gy, const float* gamma, const float* beta, const float* running_mean,

@@ -170,3 +170,41 @@ def test_fused_batchnorm_relu_conv_transpose(B, geom):
     assert relerr(bn.weight.grad, ref.weight.grad) < 5 * TOL and relerr(bn.bias.grad, ref.bias.grad) < 5 * TOL
     assert relerr(bn.running_mean, ref.running_mean) < 1e-5 and relerr(bn.running_var, ref.running_var) < 1e-5
     assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B', [3, 130, 1100])
+def test_last_decoder_stage_fused_backward_matches_the_separate_kernels(B):
+    """gpode_dec10_bn_bwd_sums / _apply (decnn.10's input gradient recomputed inside both BatchNorm backward passes) against the
+    unfused route (gpode_conv2d_fwd + gpode_bn_bwd) on the same inputs, in both forms of the statistics: this rank alone, and
+    'gathered' sums with one rank of weight 1 (the data-parallel form; must give the same numbers)."""
+    import ctypes
+    from vae_gp_ode_amd import _lib, vae_ops as V
+    from vae_gp_ode_amd.ops import _ptr, _stream
+    g = torch.Generator().manual_seed(B)
+    c = (torch.randn(B, 16, 28, 28, generator=g) * 1.3 + 0.2).cuda()
+    gam, bet = (torch.rand(16, generator=g) + 0.5).cuda(), (torch.randn(16, generator=g) * 0.3).cuda()
+    w, gy = (torch.randn(16, 1, 5, 5, generator=g) * 0.05).cuda(), torch.randn(B, 1, 28, 28, generator=g).cuda()
+    mean = c.mean((0, 2, 3))
+    invstd = torch.rsqrt(c.var((0, 2, 3), unbiased=False) + 1e-5)
+    # separate kernels
+    ga = torch.empty_like(c)
+    _lib.call('gpode_conv2d_fwd', _ptr(gy), _ptr(w), _ptr(None), _ptr(ga), B, 1, 28, 28, 16, 5, 1, 2, 28, 28, _stream())
+    ref = [torch.empty_like(c)] + [torch.empty(16, device='cuda') for _ in range(3)]
+    _lib.call('gpode_bn_bwd', _ptr(c), _ptr(ga), _ptr(gam), _ptr(bet), _ptr(mean), _ptr(invstd), *[_ptr(t) for t in ref], B, 16, 784, 1,
+              _ptr(V._bn_scratch(B, 16, c)), _stream())
+    # fused, local statistics
+    out = V._dec10_bn_bwd(None, c, gy, w, gam, bet, mean, invstd)
+    for name, a, b in zip(('gc', 'ggamma', 'gbeta', 'chansum'), out, ref):
+        tol = 2e-4 if name == 'chansum' else 2e-5        # the channel sums of gc cancel to ~0: compare against the scale of gc
+        scale = ref[0].abs().max() * 784 * B if name == 'chansum' else b.abs().max()
+        assert float((a - b).abs().max() / scale) < tol, (name, float((a - b).abs().max()), float(scale))
+    # fused, gathered statistics of a single rank
+    class OneRank:
+        world = 1
+        def gather(self, sums): return sums.reshape(1, -1).clone()
+        def weights(self, device): return torch.ones(1, device=device)
+        def count_all(self, n): return float(n)
+    out1 = V._dec10_bn_bwd(OneRank(), c, gy, w, gam, bet, mean, invstd)
+    for name, a, b in zip(('gc', 'ggamma', 'gbeta'), out1, out):
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-6, name

@@ -220,6 +220,22 @@ int gpode_bn_bwd_apply(const float* x, const float* gy, const float* gamma, cons
   return gp::bn_bwd_apply(x, gy, gamma, beta, save_mean, save_invstd, sums_gathered, weights, nranks, count_all, gx, ggamma, gbeta, gx_chansum, B, C, HW, relu,
                           scratch, GP_ST);
 }
+int gpode_dec10_bn_scratch_floats(void) { return gp::dec10_bn_scratch_floats(); }
+int gpode_dec10_bn_bwd_sums(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* save_mean,
+                            const float* save_invstd, float* sums, int B, float* scratch, void* stream) {
+  if (!c || !gy || !w || !gamma || !beta || !save_mean || !save_invstd || !scratch) return gp::set_error("gpode_dec10_bn_bwd_sums: null pointer");
+  if (B < 1) return gp::set_error("gpode_dec10_bn_bwd_sums: B >= 1");
+  return gp::dec10_bn_bwd_sums(c, gy, w, gamma, beta, save_mean, save_invstd, sums, B, scratch, GP_ST);
+}
+int gpode_dec10_bn_bwd_apply(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* save_mean,
+                             const float* save_invstd, const float* sums_gathered, const float* weights, int nranks, float count_all,
+                             float* gc, float* ggamma, float* gbeta, float* gc_chansum, int B, float* scratch, void* stream) {
+  if (!c || !gy || !w || !gamma || !beta || !save_mean || !save_invstd || !gc || !ggamma || !gbeta || !scratch)
+    return gp::set_error("gpode_dec10_bn_bwd_apply: null pointer");
+  if (B < 1) return gp::set_error("gpode_dec10_bn_bwd_apply: B >= 1");
+  return gp::dec10_bn_bwd_apply(c, gy, w, gamma, beta, save_mean, save_invstd, sums_gathered, weights, nranks, count_all, gc, ggamma, gbeta, gc_chansum,
+                                B, scratch, GP_ST);
+}
 int gpode_bn_eval(const float* x, const float* gy, const float* gamma, const float* beta, const float* running_mean,
                   const float* running_var, float eps, float* out, int B, int C, int HW, int relu, void* stream) {
   if (!x || !gamma || !beta || !running_mean || !running_var || !out) return gp::set_error("gpode_bn_eval: null pointer");

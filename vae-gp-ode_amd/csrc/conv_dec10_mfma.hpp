@@ -12,6 +12,8 @@
 // Persistent grids (<= one 512-thread workgroup per CU, two wavefronts per SIMD).
 #pragma once
 #include "conv_mfma.hpp"
+#include "bn_math.hpp"
+#include "wave_reduce.hpp"
 
 namespace gp {
 namespace dec10 {
@@ -168,6 +170,174 @@ __global__ __launch_bounds__(512) void k_bwd_data(const float* __restrict__ gy, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) op[(size_t)r * NP] = acc[r];
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// d/d input FUSED with the backward of the BatchNorm + ReLU in front of this layer (vae.py:119-120 feeding :121).  The
+// gradient w.r.t. the normalised activation, ga = d/d input above, costs 25 multiply-adds per element from a 3 KB plane of gy,
+// while writing it and reading it back twice (once for the BatchNorm sums, once for the BatchNorm input gradient) moves
+// 3 x 16 x 784 floats per image through HBM -- so it is recomputed in both passes and never stored:
+//   MODE 0  part[wg][c] = {sum g, sum g xhat},  g = ga masked by the ReLU        (reads c = the BatchNorm input, gy)
+//   MODE 1  gc = gamma invstd (g - mean(g) - xhat mean(g xhat)),  part_gx[wg][c] = sum gc   (reads c, gy; writes gc)
+// Same tile loop as k_bwd_data; c is fetched NT tiles ahead (4 NT loads in flight per lane).  2 workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+constexpr int BN_NT = 4;
+
+// sA[c], sB[c] <- sums over the workgroups' partials part[wg][c][0..1], identical in every workgroup (fixed order)
+__device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int nsplit, float* sA, float* sB) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c = 2 * wave + q;
+    float a = 0.f, b = 0.f;
+    for (int sp = lane; sp < nsplit; sp += 64) {
+      a += part[((size_t)sp * CI + c) * 2];
+      b += part[((size_t)sp * CI + c) * 2 + 1];
+    }
+    const float in2[2] = {a, b};
+    float out2[2];
+    wave_sum_multi<2>(in2, out2);
+    if (lane == 0) { sA[c] = out2[0]; sB[c] = out2[1]; }
+  }
+}
+
+template <int IPB, int MODE>
+__global__ __launch_bounds__(512, 4) void k_bwd_data_bn(const float* __restrict__ gy, const float* __restrict__ w, const float* __restrict__ x,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd, int B,
+                                                        float* __restrict__ part,                       // MODE 0: out; MODE 1: in
+                                                        int nsplit, float count, const float* __restrict__ gathered,
+                                                        const float* __restrict__ wts, int W, float* __restrict__ ggamma,
+                                                        float* __restrict__ gbeta, float* __restrict__ gx, float* __restrict__ part_gx) {
+  float* s_g = igemm_smem;                           // [IPB][32][32], index = o + 2, zero borders
+  float* s_red = s_g + IPB * PLANE;                  // [8][CI][2]
+  float* s_A = s_red + 8 * CI * 2;                   // [CI] sum g  (MODE 1)
+  float* s_B = s_A + CI;                             // [CI] sum g xhat
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  constexpr int NKS = (KK + 3) / 4;
+  constexpr int NLD = (IPB * NP / 4 + 511) / 512;
+  for (int e = tid; e < IPB * PLANE; e += 512) s_g[e] = 0.f;
+  float wa[NKS];
+  int toff[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int tap = 4 * ks + lk;
+    wa[ks] = tap < KK ? w[(size_t)lr * KK + tap] : 0.f;
+    toff[ks] = tap < KK ? (tap / 5) * WP + tap % 5 : 0;
+  }
+  // the lane's channels 4 lk + r
+  float cm[4], cis[4], cg[4], cb[4], ca_[4], cb_[4], sc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = 4 * lk + r;
+    cm[r] = mean[c]; cis[r] = invstd[c]; cg[r] = gamma[c]; cb[r] = beta[c];
+    ca_[r] = 0.f; cb_[r] = 0.f; sc[r] = cg[r] * cis[r];
+  }
+  if (MODE == 1) {
+    reduce_parts(part, nsplit, s_A, s_B);
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < CI) { gbeta[tid] = s_A[tid]; ggamma[tid] = s_B[tid]; }   // this rank's own sums: the affine gradients
+    if (gathered) {                                  // centring terms from the weighted sums over all ranks (gathered[r][2 CI])
+      __syncthreads();
+      if (tid < 2 * CI) {
+        float v = 0.f;
+        for (int rk = 0; rk < W; ++rk) v = fmaf(wts[rk], gathered[(size_t)rk * 2 * CI + tid], v);
+        (tid & 1 ? s_B : s_A)[tid >> 1] = v;
+      }
+      __syncthreads();
+    }
+    const float ic = 1.f / count;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ca_[r] = s_A[4 * lk + r] * ic; cb_[r] = s_B[4 * lk + r] * ic; }
+  }
+  float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+  const int ngroups = (B + IPB - 1) / IPB;
+  float4 pre[NLD];
+  auto prefetch = [&](int grp) {
+    const int b0 = grp * IPB, nf4 = min(IPB, B - b0) * (NP / 4);
+    const float4* src = reinterpret_cast<const float4*>(gy) + (size_t)b0 * (NP / 4);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int f = tid + 512 * i;
+      if (f < nf4) pre[i] = src[f];
+    }
+  };
+  if ((int)blockIdx.x < ngroups) prefetch(blockIdx.x);
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int b0 = grp * IPB, nimg = min(IPB, B - b0);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int f = tid + 512 * i;
+      if (f < nimg * (NP / 4)) {
+        const float v[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = 4 * f + k, im = e / NP, q = e % NP;
+          s_g[im * PLANE + (q / H + 2) * WP + q % H + 2] = v[k];
+        }
+      }
+    }
+    __syncthreads();
+    if (grp + (int)gridDim.x < ngroups) prefetch(grp + gridDim.x);
+    const int ntiles = nimg * NTILE;
+    for (int t0 = wave; t0 < ntiles; t0 += 8 * BN_NT) {
+      float xv[BN_NT][4];
+#pragma unroll
+      for (int u = 0; u < BN_NT; ++u) {
+        const int t = t0 + 8 * u;
+        if (t < ntiles) {                            // wave-uniform
+          const int im = t / NTILE, p = (t % NTILE) * 16 + lr;
+          const float* xp = x + ((size_t)(b0 + im) * CI + 4 * lk) * NP + p;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xv[u][r] = xp[(size_t)r * NP];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < BN_NT; ++u) {
+        const int t = t0 + 8 * u;
+        if (t < ntiles) {
+          const int im = t / NTILE, p = (t % NTILE) * 16 + lr;
+          const float* gp = s_g + im * PLANE + (p / H) * WP + p % H;
+          float bf[NKS];
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) bf[ks] = gp[toff[ks]];
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks], bf[ks], acc, 0, 0, 0);
+          float* op = gx + ((size_t)(b0 + im) * CI + 4 * lk) * NP + p;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float xh = bn_xhat(xv[u][r], cm[r], cis[r]);
+            const float g = (__fmaf_rn(xh, cg[r], cb[r]) > 0.f) ? acc[r] : 0.f;
+            if (MODE == 0) {
+              a0[r] += g;
+              a1[r] = fmaf(g, xh, a1[r]);
+            } else {
+              const float o = sc[r] * (g - ca_[r] - xh * cb_[r]);
+              op[(size_t)r * NP] = o;
+              a0[r] += o;
+            }
+          }
+        }
+      }
+    }
+  }
+  // the lane's 16-lane row shares its channels: row sums, then the 8 wavefronts in a fixed order
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float r0 = row_allreduce16(a0[r]), r1 = row_allreduce16(a1[r]);
+    if (lr == 0) { s_red[(wave * CI + 4 * lk + r) * 2] = r0; s_red[(wave * CI + 4 * lk + r) * 2 + 1] = r1; }
+  }
+  __syncthreads();
+  float* outp = MODE == 0 ? part : part_gx;
+  if (tid < 2 * CI && outp) {
+    float v = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 8; ++wv) v += s_red[wv * CI * 2 + tid];
+    outp[(size_t)blockIdx.x * CI * 2 + tid] = v;
   }
 }
 

@@ -109,6 +109,13 @@ int bn_finalize(const float* gathered, int W, const float* gamma, const float* b
                 float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, float* table, int C,
                 hipStream_t st);
 int bn_apply(const float* x, const float* table, float* y, int B, int C, int HW, int relu, hipStream_t st);
+// decnn.10's input gradient fused with the BatchNorm + ReLU backward in front of it (vae_conv_tiled.hip)
+int dec10_bn_scratch_floats();
+int dec10_bn_bwd_sums(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* mean,
+                      const float* invstd, float* sums, int B, float* scratch, hipStream_t st);
+int dec10_bn_bwd_apply(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* mean,
+                       const float* invstd, const float* gathered, const float* wts, int W, float count_all, float* gc, float* ggamma,
+                       float* gbeta, float* gc_chansum, int B, float* scratch, hipStream_t st);
 int bn_bwd_sums(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                 float* sums, int B, int C, int HW, int relu, float* scratch, hipStream_t st);
 int bn_bwd_apply(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,

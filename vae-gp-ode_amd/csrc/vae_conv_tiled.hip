@@ -546,6 +546,69 @@ int tiled_fwd(const float* x, const float* w, const float* bias, float* y, int B
   return -1;
 }
 
+// decnn.10's input gradient fused with the backward of the BatchNorm + ReLU in front of it (conv_dec10_mfma.hpp, k_bwd_data_bn).
+// scratch: part[nwg][16][2] | part_gx[nwg][16][2], nwg <= kDec10BnMaxWg.  The grid is a function of B alone, so the two
+// passes (and the partials they exchange through scratch) agree.
+constexpr int kDec10BnMaxWg = 512;
+int dec10_bn_scratch_floats() { return 2 * kDec10BnMaxWg * dec10::CI * 2; }
+
+__global__ __launch_bounds__(512) void k_dec10_parts_reduce(const float* __restrict__ part, int nsplit, float* __restrict__ out, int stride2) {
+  __shared__ float sA[dec10::CI], sB[dec10::CI];
+  dec10::reduce_parts(part, nsplit, sA, sB);
+  __syncthreads();
+  const int tid = threadIdx.x;
+  if (stride2) { if (tid < 2 * dec10::CI) out[tid] = (tid & 1 ? sB : sA)[tid >> 1]; }   // {sum g, sum g xhat} interleaved
+  else if (tid < dec10::CI) out[tid] = sA[tid];
+}
+
+template <int IPB, int MODE, typename... A>
+static int launch_dec10_bn(int B, hipStream_t st, A... args) {
+  const size_t lds = sizeof(float) * ((size_t)IPB * dec10::PLANE + 8 * dec10::CI * 2 + 2 * dec10::CI);
+  auto kern = dec10::k_bwd_data_bn<IPB, MODE>;
+  if (set_max_lds((const void*)kern, lds)) return 1;
+  const int ngroups = (B + IPB - 1) / IPB, cap = 2 * num_cus() < kDec10BnMaxWg ? 2 * num_cus() : kDec10BnMaxWg;
+  hipLaunchKernelGGL(kern, ngroups < cap ? ngroups : cap, 512, lds, st, args...);
+  return 0;
+}
+static int dec10_bn_nwg(int B, int& ipb) {
+  ipb = B >= 4 * num_cus() ? 4 : 2;
+  const int ngroups = (B + ipb - 1) / ipb, cap = 2 * num_cus() < kDec10BnMaxWg ? 2 * num_cus() : kDec10BnMaxWg;
+  return ngroups < cap ? ngroups : cap;
+}
+
+int dec10_bn_bwd_sums(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* mean,
+                      const float* invstd, float* sums, int B, float* scratch, hipStream_t st) {
+  if (((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(c)) & 15) != 0) return set_error("gpode_dec10_bn_bwd_sums: c / gy must be 16-byte aligned");
+  int ipb;
+  const int nwg = dec10_bn_nwg(B, ipb);
+  float* np_ = nullptr;
+  const float* cnp = nullptr;
+  int rc;
+  if (ipb == 4) rc = launch_dec10_bn<4, 0>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, 0, 0.f, cnp, cnp, 0, np_, np_, np_, np_);
+  else rc = launch_dec10_bn<2, 0>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, 0, 0.f, cnp, cnp, 0, np_, np_, np_, np_);
+  if (rc) return rc;
+  if (sums) hipLaunchKernelGGL(k_dec10_parts_reduce, 1, 512, 0, st, scratch, nwg, sums, 1);
+  return check_launch("dec10_bn_bwd_sums");
+}
+
+int dec10_bn_bwd_apply(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* mean,
+                       const float* invstd, const float* gathered, const float* wts, int W, float count_all, float* gc, float* ggamma,
+                       float* gbeta, float* gc_chansum, int B, float* scratch, hipStream_t st) {
+  if (((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(gc)) & 15) != 0)
+    return set_error("gpode_dec10_bn_bwd_apply: c / gy / gc must be 16-byte aligned");
+  if (gathered && (W < 1 || !wts)) return set_error("gpode_dec10_bn_bwd_apply: gathered sums need their weights");
+  int ipb;
+  const int nwg = dec10_bn_nwg(B, ipb);
+  float* part_gx = gc_chansum ? scratch + (size_t)kDec10BnMaxWg * dec10::CI * 2 : nullptr;
+  const float count = gathered ? count_all : (float)B * dec10::NP;
+  int rc;
+  if (ipb == 4) rc = launch_dec10_bn<4, 1>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, nwg, count, gathered, wts, W, ggamma, gbeta, gc, part_gx);
+  else rc = launch_dec10_bn<2, 1>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, nwg, count, gathered, wts, W, ggamma, gbeta, gc, part_gx);
+  if (rc) return rc;
+  if (gc_chansum) hipLaunchKernelGGL(k_dec10_parts_reduce, 1, 512, 0, st, part_gx, nwg, gc_chansum, 0);
+  return check_launch("dec10_bn_bwd_apply");
+}
+
 // ConvTranspose2d d/d weight (conv geometry: x := grad_output, gy := the layer's input)
 int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch, int B, int Ci, int H, int W, int Co, int K, int S,
                      int P, int Ho, int Wo, const float* in_bn, hipStream_t st) {

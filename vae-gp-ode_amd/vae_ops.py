@@ -1,6 +1,7 @@
 """autograd bindings of the conv-VAE HIP kernels (csrc/vae_conv.hip).  Every forward AND backward is a
 call into libgpode_hip.so; torch only allocates the tensors and records the graph."""
 import ctypes
+import os
 
 import torch
 
@@ -63,6 +64,29 @@ def _bn_global_bwd(sync, x, gy, gamma, beta, mean, invstd, relu):
               _ptr(sync.weights(x.device)), sync.world, ctypes.c_float(sync.count_all(B * HW)), _ptr(gx), _ptr(gg), _ptr(gb), _ptr(cs),
               B, C, HW, int(relu), _ptr(scratch), _stream())
     return gx, gg, gb, cs
+
+
+_dec10_fused = os.environ.get('GPODE_DEC10_BN_UNFUSED', '0') != '1'
+
+
+def _dec10_bn_bwd(sync, c, gy, w, gamma, beta, mean, invstd):
+    """decnn.10's input gradient + the BatchNorm/ReLU backward in front of it in two passes over c (include/gpode.h,
+    gpode_dec10_bn_bwd_*): (gc, ggamma, gbeta, channel sums of gc)."""
+    B = c.shape[0]
+    scratch = _scratch(_lib.load().gpode_dec10_bn_scratch_floats(), c)
+    gc, gg, gb, cs = _new(c.shape, c), _new((16,), c), _new((16,), c), _new((16,), c)
+    head = (_ptr(c), _ptr(gy), _ptr(w), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd))
+    if sync is None:
+        _lib.call('gpode_dec10_bn_bwd_sums', *head, _ptr(None), B, _ptr(scratch), _stream())
+        _lib.call('gpode_dec10_bn_bwd_apply', *head, _ptr(None), _ptr(None), 0, ctypes.c_float(0.0), _ptr(gc), _ptr(gg), _ptr(gb), _ptr(cs),
+                  B, _ptr(scratch), _stream())
+    else:
+        sums = _new((32,), c)
+        _lib.call('gpode_dec10_bn_bwd_sums', *head, _ptr(sums), B, _ptr(scratch), _stream())
+        gathered = sync.gather(sums)
+        _lib.call('gpode_dec10_bn_bwd_apply', *head, _ptr(gathered), _ptr(sync.weights(c.device)), sync.world,
+                  ctypes.c_float(sync.count_all(B * 784)), _ptr(gc), _ptr(gg), _ptr(gb), _ptr(cs), B, _ptr(scratch), _stream())
+    return gc, gg, gb, cs
 
 
 fused_bias_grads = 0   # how many bias gradients arrived ready-made from a BatchNorm backward (see _BatchNormTrain.backward)
@@ -189,6 +213,11 @@ class _BnReluConvT(torch.autograd.Function):
                 if gb is None:
                     gb = _new((Cout,), c)
                     _lib.call('gpode_chan_sum', _ptr(gy), _ptr(gb), B, Cout, Ht * Wt, _ptr(_bn_scratch(B, Cout, c)), _stream())
+        if _dec10_fused and (Cout, Cin, K, S, P, Hi, Wi, Ht, Wt) == (1, 16, 5, 1, 2, 28, 28, 28, 28):
+            # the decoder's last stage: the gradient w.r.t. the normalised activation is recomputed inside both BatchNorm passes
+            gc, gg, gbeta, cs = _dec10_bn_bwd(ctx.sync, c, gy, w, gamma, beta, mean, invstd)
+            gc._gpode_chansum = cs
+            return gc, gg, gbeta, None, None, None, None, None, gw, gb, None, None, None
         # gradient w.r.t. the (never materialised) normalised activation, then through the BatchNorm to c
         ga = _new(c.shape, c)
         _lib.call('gpode_conv2d_fwd', _ptr(gy), _ptr(w), _ptr(None), _ptr(ga), B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, _stream())
