@@ -235,6 +235,27 @@ int gpode_loglik_rowsum_fwd(const float* X, const float* z, float* out, size_t r
 int gpode_loglik_rowsum_bwd(const float* X, const float* z, const float* grow, float* gz, size_t rows, size_t inner, size_t nX,
                             void* stream);
 
+/* The last two stages of the training step's forward pass, fused (and their adjoints):
+ *   gpode_sigmoid_loglik_fwd  z = sigmoid(a) (vae.py:84, the decoder's nn.Sigmoid) and the Bernoulli log-likelihood of X under z
+ *                             (vae.py:136-153) summed per row as create_model.py:49 sums it; every row is cut into nsplit slices,
+ *                             part[row][split] (gpode_sigmoid_loglik_splits(rows, inner) proposes nsplit).  X (nX floats) is broadcast
+ *                             over the rows * inner / nX copies of it.  Same arithmetic as gpode_act_fwd + gpode_loglik_rowsum_fwd.
+ *   gpode_sigmoid_loglik_bwd  ga = grow[row] * d/da, the chain gpode_loglik_rowsum_bwd -> gpode_act_bwd in one pass
+ *   gpode_elbo_all_fwd        out[4] = {loss, -mean lhood, mean kl, kl_u} (create_model.py:61-73) from the nl_values partial sums
+ *                             of nl_rows likelihood rows, the encoder's rows hs = (mu | logvar), N x 2q (hv: the velocity half of a
+ *                             second-order model, or NULL) -- KL(q(z0) || N(0, I)), create_model.py:47-49 -- and the inducing
+ *                             posterior (Um M x Do, Us packed lower triangles Do x M(M+1)/2) -- KL(q(u) || N(0, I)), svpy.py:144-175
+ *   gpode_elbo_all_bwd        gradients of the four outputs (device scalars, NULL = 0) -> glrow[nl_rows], ghs / ghv (N x 2q), dUm, dUs */
+int gpode_sigmoid_loglik_splits(size_t rows, size_t inner);
+int gpode_sigmoid_loglik_fwd(const float* X, const float* a, float* z, float* part, size_t rows, size_t inner, size_t nX, int nsplit,
+                             void* stream);
+int gpode_sigmoid_loglik_bwd(const float* X, const float* z, const float* grow, float* ga, size_t rows, size_t inner, size_t nX,
+                             void* stream);
+int gpode_elbo_all_fwd(const float* lpart, int nl_rows, int nl_values, const float* hs, const float* hv, int N, int q, int M, int Do,
+                       const float* Um, const float* Us, float nobs, float* out, void* stream);
+int gpode_elbo_all_bwd(const float* g_loss, const float* g_nll, const float* g_kl, const float* g_klu, int nl_rows, const float* hs,
+                       const float* hv, int N, int q, int M, int Do, const float* Um, const float* Us, float nobs, float* glrow, float* ghs,
+                       float* ghv, float* dUm, float* dUs, void* stream);
 /* ELBO glue on (N,q)-sized tensors (one launch each):
  *   mu / logvar are (N,q) with row stride ld (ld = 2q: the two halves of the encoder's fc output, vae.py:74), gradients
  *   are written with row stride ldg;

@@ -407,3 +407,29 @@ def test_df_width_outside_the_compiled_list_is_refused_loudly():
     gp = SVGP_Layer(5, 5, 8, 16, kernel='DF').cuda()
     with pytest.raises(_lib.GpodeError, match='divergence-free kernel is compiled for D in'):
         gp.build_cache()
+
+
+def test_side_stream_parameter_gradient_does_not_depend_on_the_main_stream():
+    """ops.param_grad under launch_on(side) while the main stream is held up behind the fork: everything that writes its
+    result must run on the side stream.  (A torch-native fill of the result buffer launches on torch's CURRENT stream; queued
+    behind a busy main stream it used to land after the side-stream reduction had written the buffer and wipe it -- seen as a
+    run-to-run wobble of the GP parameter gradients in overlap / HIP-graph mode.)"""
+    from vae_gp_ode_amd import ops
+    name, kernel, order = GP_CASES[0]
+    g = load_golden(name)
+    c = build(g, kernel, want_Lu=False)
+    zt, xs = ops.rollout(c, g['z0'].cuda(), g['ts'].cuda(), order, 'rk4', save_stages=True)
+    gz0, ast = ops.rollout_bwd(c, xs, g['gw'].cuda(), g['ts'].cuda(), order, 'rk4')
+    x, a = xs.reshape(-1, c.Di), ast.reshape(-1, c.Do)
+    ref = ops.param_grad(c, x, a).clone()
+    torch.cuda.synchronize()
+    side = ops.fork_side_stream()
+    torch.cuda._sleep(int(2e8))                      # ~0.1 s of main-stream work queued behind the fork point
+    keep = []
+    with ops.launch_on(side):
+        got = ops.param_grad(c, x, a, keep=keep)
+    ops.join_side_stream()
+    torch.cuda.synchronize()
+    pv = PackView(kernel, c.Di, c.Do, c.M, c.S)
+    for view in (pv.rff, pv.ind, pv.uni):
+        assert torch.equal(view(got.cpu().double()), view(ref.cpu().double()))

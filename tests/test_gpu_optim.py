@@ -263,9 +263,9 @@ def test_graph_replayed_data_parallel_run_equals_the_eager_one(tmp_path):
     assert len(a) == len(b) == 18
     worst = max(abs(x - y) / max(abs(x), 1.0) for x, y in zip(a, b))
     print('graph-replayed vs eager data-parallel run, worst relative loss difference over 18 steps: %.1e' % worst)
-    # the log prints two decimals (one unit = 3e-5 of a loss of 300) and 18 Adam steps amplify a last-bit difference of the
-    # first; a step taken with stale or uninitialised gradients moves every later loss by > 1e-2
-    assert worst < 1e-4, (a, b)
+    # (until the fill of the parameter-gradient buffer left the main stream -- tests/test_gpu_backward.py,
+    # test_side_stream_parameter_gradient_does_not_depend_on_the_main_stream -- this comparison wobbled between 1e-6 and 8e-4)
+    assert worst < 2e-5, (a, b)
 
 
 def test_nan_guard_reloads_the_last_checkpoint(tmp_path, monkeypatch, caplog):

@@ -7,7 +7,7 @@ def run(tmp, tag, world, extra, port):
     env = dict(os.environ, GPODE_DIST_BACKEND='gloo', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
     base = ['-m', 'vae_gp_ode_amd.main', '--task', 'synthetic', '--Ndata', '10', '--Ntest', '4', '--batch', '4', '--T', '6', '--solver', 'rk4',
             '--num_inducing', '16', '--num_features', '32', '--lr', '1e-3', '--log_freq', '1', '--Nepoch', '6', '--save', 'results/' + tag,
-            '--sync_bn', 'False'] + extra
+            '--sync_bn', 'False'] + extra + os.environ.get('DBG_EXTRA', '').split()
     if world == 1:
         cmd = [sys.executable] + base
     else:

@@ -74,6 +74,11 @@ SIGNATURES.update({
     'gpode_reparam_bwd': (_i, [_c_float_p, _c_float_p, _i, _c_float_p, _c_float_p, _c_float_p, _i, _i, _i, _vp]),
     'gpode_normal_kl_fwd': (_i, [_c_float_p, _c_float_p, _i, _c_float_p, _i, _i, _vp]),
     'gpode_normal_kl_bwd': (_i, [_c_float_p, _c_float_p, _c_float_p, _i, _c_float_p, _c_float_p, _i, _i, _i, _vp]),
+    'gpode_sigmoid_loglik_splits': (_i, [_sz, _sz]),
+    'gpode_sigmoid_loglik_fwd': (_i, [_c_float_p] * 4 + [_sz, _sz, _sz, _i, _vp]),
+    'gpode_sigmoid_loglik_bwd': (_i, [_c_float_p] * 4 + [_sz, _sz, _sz, _vp]),
+    'gpode_elbo_all_fwd': (_i, [_c_float_p, _i, _i, _c_float_p, _c_float_p, _i, _i, _i, _i, _c_float_p, _c_float_p, _f, _c_float_p, _vp]),
+    'gpode_elbo_all_bwd': (_i, [_c_float_p] * 4 + [_i, _c_float_p, _c_float_p, _i, _i, _i, _i, _c_float_p, _c_float_p, _f] + [_c_float_p] * 5 + [_vp]),
     'gpode_elbo_fwd': (_i, [_c_float_p, _i, _c_float_p, _i, _c_float_p, _f, _c_float_p, _vp]),
     'gpode_elbo_bwd': (_i, [_c_float_p, _i, _i, _f, _c_float_p, _c_float_p, _c_float_p, _vp]),
     'gpode_gather_multi': (_i, [_vp, _vp, _i, ctypes.c_longlong, _c_float_p, _vp]),

@@ -289,6 +289,32 @@ int gpode_normal_kl_bwd(const float* grow, const float* mu, const float* logvar,
   if (!grow || !mu || !logvar || !gmu || !glogvar || q < 1 || ld < q || ldg < q) return gp::set_error("gpode_normal_kl_bwd: bad argument");
   return gp::normal_kl_bwd(grow, mu, logvar, ld, gmu, glogvar, ldg, N, q, GP_ST);
 }
+int gpode_sigmoid_loglik_splits(size_t rows, size_t inner) { return gp::sigmoid_loglik_splits(rows, inner); }
+int gpode_sigmoid_loglik_fwd(const float* X, const float* a, float* z, float* part, size_t rows, size_t inner, size_t nX, int nsplit,
+                             void* stream) {
+  if (!X || !a || !z || !part) return gp::set_error("gpode_sigmoid_loglik_fwd: null pointer");
+  if (!rows || !inner || !nX) return gp::set_error("gpode_sigmoid_loglik_fwd: empty input");
+  return gp::sigmoid_loglik_fwd(X, a, z, part, rows, inner, nX, nsplit, GP_ST);
+}
+int gpode_sigmoid_loglik_bwd(const float* X, const float* z, const float* grow, float* ga, size_t rows, size_t inner, size_t nX,
+                             void* stream) {
+  if (!X || !z || !grow || !ga) return gp::set_error("gpode_sigmoid_loglik_bwd: null pointer");
+  if (!rows || !inner || !nX) return gp::set_error("gpode_sigmoid_loglik_bwd: empty input");
+  return gp::sigmoid_loglik_bwd(X, z, grow, ga, rows, inner, nX, GP_ST);
+}
+int gpode_elbo_all_fwd(const float* lpart, int nl_rows, int nl_values, const float* hs, const float* hv, int N, int q, int M, int Do,
+                       const float* Um, const float* Us, float nobs, float* out, void* stream) {
+  if (!lpart || !hs || !Um || !Us || !out) return gp::set_error("gpode_elbo_all_fwd: null pointer");
+  if (nl_rows < 1 || nl_values < nl_rows || N < 1 || q < 1 || M < 1 || Do < 1) return gp::set_error("gpode_elbo_all_fwd: bad sizes");
+  return gp::elbo_all_fwd(lpart, nl_rows, nl_values, hs, hv, N, q, M, Do, Um, Us, nobs, out, GP_ST);
+}
+int gpode_elbo_all_bwd(const float* g_loss, const float* g_nll, const float* g_kl, const float* g_klu, int nl_rows, const float* hs,
+                       const float* hv, int N, int q, int M, int Do, const float* Um, const float* Us, float nobs, float* glrow, float* ghs,
+                       float* ghv, float* dUm, float* dUs, void* stream) {
+  if (!hs || !Um || !Us || !glrow || !ghs || !dUm || !dUs || (hv && !ghv)) return gp::set_error("gpode_elbo_all_bwd: null pointer");
+  if (nl_rows < 1 || N < 1 || q < 1 || M < 1 || Do < 1) return gp::set_error("gpode_elbo_all_bwd: bad sizes");
+  return gp::elbo_all_bwd(g_loss, g_nll, g_kl, g_klu, nl_rows, hs, hv, N, q, M, Do, Um, Us, nobs, glrow, ghs, ghv, dUm, dUs, GP_ST);
+}
 int gpode_elbo_fwd(const float* lhood, int nl, const float* klrow, int nk, const float* kl_u, float nobs, float* out, void* stream) {
   if (!lhood || !klrow || !kl_u || !out || nl < 1 || nk < 1) return gp::set_error("gpode_elbo_fwd: bad argument");
   return gp::elbo_fwd(lhood, nl, klrow, nk, kl_u, nobs, out, GP_ST);

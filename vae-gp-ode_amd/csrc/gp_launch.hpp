@@ -136,6 +136,14 @@ int reparam_fwd(const float* mu, const float* logvar, int ld, const float* eps, 
 int reparam_bwd(const float* gz, const float* logvar, int ld, const float* eps, float* gmu, float* glogvar, int ldg, int N, int q, hipStream_t st);
 int normal_kl_fwd(const float* mu, const float* logvar, int ld, float* klrow, int N, int q, hipStream_t st);
 int normal_kl_bwd(const float* grow, const float* mu, const float* logvar, int ld, float* gmu, float* glogvar, int ldg, int N, int q, hipStream_t st);
+int sigmoid_loglik_splits(size_t rows, size_t inner);
+int sigmoid_loglik_fwd(const float* X, const float* a, float* z, float* part, size_t rows, size_t inner, size_t nX, int nsplit, hipStream_t st);
+int sigmoid_loglik_bwd(const float* X, const float* z, const float* grow, float* ga, size_t rows, size_t inner, size_t nX, hipStream_t st);
+int elbo_all_fwd(const float* lpart, int nl_rows, int nl_values, const float* hs, const float* hv, int N, int q, int M, int Do,
+                 const float* Um, const float* Us, float nobs, float* out, hipStream_t st);
+int elbo_all_bwd(const float* g0, const float* g1, const float* g2, const float* g3, int nl_rows, const float* hs, const float* hv, int N,
+                 int q, int M, int Do, const float* Um, const float* Us, float nobs, float* glrow, float* ghs, float* ghv, float* dUm,
+                 float* dUs, hipStream_t st);
 int elbo_fwd(const float* lhood, int nl, const float* klrow, int nk, const float* kl_u, float nobs, float* out, hipStream_t st);
 int elbo_bwd(const float* gout, int nl, int nk, float nobs, float* glhood, float* gklrow, float* gklu, hipStream_t st);
 int gather_multi(const float* const* grads, const long long* offs, int ntensors, long long total, float* flat, hipStream_t st);

@@ -518,6 +518,169 @@ __global__ void k_elbo_bwd(const float* __restrict__ gout, int nl, int nk, float
   if (e == 0) gklu[0] = g0 + gout[3];
 }
 
+// ---- the decoder's output activation fused with the likelihood, and the ELBO assembled in one launch -------------------
+// z = sigmoid(a) (vae.py:84, nn.Sigmoid) and sum over a row slice of log(z) X + log(1 - z)(1 - X) (vae.py:136-153 summed as
+// create_model.py:49 does): grid (nsplit, rows); part[row][split].  Same expressions as k_act_fwd / k_loglik_rowsum, so z and
+// every term are bit-identical to the separate kernels; only the order of the row sum differs.
+__global__ __launch_bounds__(256) void k_sigmoid_loglik_fwd(const float* __restrict__ X, const float* __restrict__ a, float* __restrict__ z,
+                                                             float* __restrict__ part, size_t inner, size_t nX, size_t chunk) {
+  __shared__ float red[4];
+  const size_t row = blockIdx.y, p0 = (size_t)blockIdx.x * chunk, p1 = p0 + chunk < inner ? p0 + chunk : inner;
+  float acc = 0.f;
+  auto one = [&](float av, float xv) {
+    const float zv = 1.f / (1.f + expf(-av));
+    acc += logf(zv) * xv + logf(1.f - zv) * (1.f - xv);
+    return zv;
+  };
+  if (((inner | nX | chunk) & 3) == 0) {             // rows, wraps of X and slices all start on 16-byte boundaries
+    for (size_t p = p0 + 4 * threadIdx.x; p < p1; p += 1024) {
+      const size_t e = row * inner + p;
+      const float4 av = *reinterpret_cast<const float4*>(a + e), xv = *reinterpret_cast<const float4*>(X + e % nX);
+      float4 zv;
+      zv.x = one(av.x, xv.x); zv.y = one(av.y, xv.y); zv.z = one(av.z, xv.z); zv.w = one(av.w, xv.w);
+      *reinterpret_cast<float4*>(z + e) = zv;
+    }
+  } else {
+    for (size_t p = p0 + threadIdx.x; p < p1; p += 256) {
+      const size_t e = row * inner + p;
+      z[e] = one(a[e], X[e % nX]);
+    }
+  }
+  float in1[1] = {acc}, out1[1];
+  wave_sum_multi<1>(in1, out1);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = out1[0];
+  __syncthreads();
+  if (threadIdx.x == 0) part[row * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// ga = d/da: k_loglik_rowsum_bwd followed by k_act_bwd (sigmoid), same expressions in the same order
+__global__ void k_sigmoid_loglik_bwd(const float* __restrict__ X, const float* __restrict__ z, const float* __restrict__ grow,
+                                     float* __restrict__ ga, size_t n, size_t inner, size_t nX) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float xv = X[e % nX], zv = z[e];
+    const float gz = grow[e / inner] * (xv / zv - (1.f - xv) / (1.f - zv));
+    ga[e] = gz * zv * (1.f - zv);
+  }
+}
+
+// out[0..3] = {loss, -mean lhood, mean kl, kl_u} (create_model.py:61-73) from the likelihood partial sums (nl_values of them over
+// nl_rows rows), the encoder's packed (mu | logvar) rows hs (and hv for second-order models; KL of a factorised Gaussian is additive)
+// and the inducing posterior (Um, packed Us: svpy.py:144-175, k_svgp_kl in gp_misc.hip).  ONE workgroup, fixed-order reductions.
+__global__ __launch_bounds__(1024) void k_elbo_all_fwd(const float* __restrict__ lpart, int nl_rows, int nl_values, const float* __restrict__ hs,
+                                                        const float* __restrict__ hv, int N, int q, int M, int Do,
+                                                        const float* __restrict__ Um, const float* __restrict__ Us, float nobs,
+                                                        float* __restrict__ out) {
+  __shared__ float red[16][3];
+  const size_t P = (size_t)M * (M + 1) / 2;
+  float u = 0.f, a = 0.f, b = 0.f;
+  for (size_t e = threadIdx.x; e < P * Do; e += blockDim.x) u = fmaf(Us[e], Us[e], u);
+  for (int e = threadIdx.x; e < M * Do; e += blockDim.x) {
+    const int m = e / Do, d = e % Do;
+    const float l = Us[(size_t)d * P + (size_t)m * (m + 1) / 2 + m];
+    const float v = Um[e];
+    u += v * v - logf(l * l);
+  }
+  for (int i = threadIdx.x; i < nl_values; i += blockDim.x) a += lpart[i];
+  for (int e = threadIdx.x; e < N * q; e += blockDim.x) {
+    const int n = e / q, d = e % q;
+    {
+      const float m = hs[(size_t)n * 2 * q + d], sg = expf(0.5f * hs[(size_t)n * 2 * q + q + d]);
+      const float vr = sg * sg;
+      b += 0.5f * (vr + m * m - 1.f - logf(vr));
+    }
+    if (hv) {
+      const float m = hv[(size_t)n * 2 * q + d], sg = expf(0.5f * hv[(size_t)n * 2 * q + q + d]);
+      const float vr = sg * sg;
+      b += 0.5f * (vr + m * m - 1.f - logf(vr));
+    }
+  }
+  const float in3[3] = {u, a, b};
+  float out3[3];
+  wave_sum_multi<3>(in3, out3);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = out3[0]; red[threadIdx.x >> 6][1] = out3[1]; red[threadIdx.x >> 6][2] = out3[2]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t[3] = {0.f, 0.f, 0.f};
+    for (int w = 0; w < 16; ++w) { t[0] += red[w][0]; t[1] += red[w][1]; t[2] += red[w][2]; }
+    const float ku = 0.5f * (t[0] - (float)M * (float)Do);
+    const float lh = t[1] / (float)nl_rows, kr = t[2] / (float)N;
+    out[0] = -(lh * nobs - kr * nobs - ku);
+    out[1] = -lh;
+    out[2] = kr;
+    out[3] = ku;
+  }
+}
+// g0..g3: gradients w.r.t. the four outputs (device scalars, NULL = 0) -> likelihood rows, packed encoder rows, Um, Us
+__global__ void k_elbo_all_bwd(const float* __restrict__ g0p, const float* __restrict__ g1p, const float* __restrict__ g2p,
+                               const float* __restrict__ g3p, int nl_rows, const float* __restrict__ hs, const float* __restrict__ hv, int N,
+                               int q, int M, int Do, const float* __restrict__ Um, const float* __restrict__ Us, float nobs,
+                               float* __restrict__ glrow, float* __restrict__ ghs, float* __restrict__ ghv, float* __restrict__ dUm,
+                               float* __restrict__ dUs) {
+  const size_t P = (size_t)M * (M + 1) / 2;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const float g0 = g0p ? *g0p : 0.f, g1 = g1p ? *g1p : 0.f, g2 = g2p ? *g2p : 0.f, g3 = g3p ? *g3p : 0.f;
+  if (e < (size_t)nl_rows) glrow[e] = (-g0 * nobs - g1) / (float)nl_rows;
+  if (e < (size_t)N * q) {
+    const float gk = (g0 * nobs + g2) / (float)N;
+    const int n = (int)(e / q), d = (int)(e % q);
+    const size_t im = (size_t)n * 2 * q + d, il = im + q;
+    ghs[im] = gk * hs[im];
+    ghs[il] = gk * 0.5f * (expf(hs[il]) - 1.f);
+    if (hv) {
+      ghv[im] = gk * hv[im];
+      ghv[il] = gk * 0.5f * (expf(hv[il]) - 1.f);
+    }
+  }
+  const float g = g0 + g3;
+  if (e < (size_t)M * Do) dUm[e] = g * Um[e];
+  if (e < P * Do) {
+    const size_t k = e % P;
+    int n = (int)((sqrtf(8.f * (float)k + 1.f) - 1.f) * 0.5f);
+    while ((size_t)(n + 1) * (n + 2) / 2 <= k) ++n;
+    while ((size_t)n * (n + 1) / 2 > k) --n;
+    const bool diag = (k - (size_t)n * (n + 1) / 2) == (size_t)n;
+    const float v = Us[e];
+    dUs[e] = g * (diag ? v - 1.f / v : v);
+  }
+}
+
+int sigmoid_loglik_splits(size_t rows, size_t inner) {
+  size_t ns = (1024 + rows - 1) / rows, cap = (inner + 1023) / 1024;
+  if (ns > cap) ns = cap;
+  if (ns > 64) ns = 64;
+  return ns < 1 ? 1 : (int)ns;
+}
+int sigmoid_loglik_fwd(const float* X, const float* a, float* z, float* part, size_t rows, size_t inner, size_t nX, int nsplit,
+                       hipStream_t st) {
+  if (nsplit < 1 || rows > 65535) return set_error("gpode_sigmoid_loglik_fwd: nsplit >= 1, rows <= 65535");
+  if ((rows * inner) % nX != 0) return set_error("gpode_sigmoid_loglik_fwd: X must tile the rows");
+  size_t chunk = (inner + nsplit - 1) / nsplit;
+  chunk = (chunk + 3) & ~(size_t)3;
+  if (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(z)) & 15) != 0) chunk |= 1;   // scalar path
+  hipLaunchKernelGGL(k_sigmoid_loglik_fwd, dim3(nsplit, (unsigned)rows), 256, 0, st, X, a, z, part, inner, nX, chunk);
+  return check_launch("sigmoid_loglik_fwd");
+}
+int sigmoid_loglik_bwd(const float* X, const float* z, const float* grow, float* ga, size_t rows, size_t inner, size_t nX, hipStream_t st) {
+  const size_t n = rows * inner;
+  hipLaunchKernelGGL(k_sigmoid_loglik_bwd, ew_grid(n), 256, 0, st, X, z, grow, ga, n, inner, nX);
+  return check_launch("sigmoid_loglik_bwd");
+}
+int elbo_all_fwd(const float* lpart, int nl_rows, int nl_values, const float* hs, const float* hv, int N, int q, int M, int Do,
+                 const float* Um, const float* Us, float nobs, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_elbo_all_fwd, 1, 1024, 0, st, lpart, nl_rows, nl_values, hs, hv, N, q, M, Do, Um, Us, nobs, out);
+  return check_launch("elbo_all_fwd");
+}
+int elbo_all_bwd(const float* g0, const float* g1, const float* g2, const float* g3, int nl_rows, const float* hs, const float* hv, int N,
+                 int q, int M, int Do, const float* Um, const float* Us, float nobs, float* glrow, float* ghs, float* ghv, float* dUm,
+                 float* dUs, hipStream_t st) {
+  size_t n = (size_t)M * (M + 1) / 2 * Do;
+  if ((size_t)N * q > n) n = (size_t)N * q;
+  if ((size_t)nl_rows > n) n = nl_rows;
+  if ((size_t)M * Do > n) n = (size_t)M * Do;
+  hipLaunchKernelGGL(k_elbo_all_bwd, (unsigned)((n + 255) / 256), 256, 0, st, g0, g1, g2, g3, nl_rows, hs, hv, N, q, M, Do, Um, Us, nobs, glrow,
+                     ghs, ghv, dUm, dUs);
+  return check_launch("elbo_all_bwd");
+}
+
 int reparam_fwd(const float* mu, const float* logvar, int ld, const float* eps, float* z, int N, int q, hipStream_t st) {
   hipLaunchKernelGGL(k_reparam_fwd, (N * q + 255) / 256, 256, 0, st, mu, logvar, ld, eps, z, N, q);
   return check_launch("reparam_fwd");

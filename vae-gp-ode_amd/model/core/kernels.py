@@ -55,6 +55,9 @@ class RBF(nn.Module):
         self._cache = cache
         self.rff_weights = noise['rff_w']
         if cache.Do != self.D_out or cache.Di != self.D_in:      # evaluated zero-padded (ops.WidthPad): expose the unpadded slices
+            if ops.launching_on_side():                          # SVGP_Layer.take_prebuilt_cache() calls again after the join
+                self.rff_omega = self.rff_phase = self.nu = None
+                return
             pad = ops.width_pad(self.kernel_id, self.D_in, self.D_out)
             idx = pad.index(cache.omega.device)
             self.rff_weights = noise['rff_w'][:, :self.D_out]

@@ -13,11 +13,11 @@ class ODEGPVAE(nn.Module):
         self.v_steps = steps
         self.order = order
 
-    def build_decoding(self, ztL, dims):
+    def build_decoding(self, ztL, dims, logits=False):
         """ztL (L,N,T,order*q) -> Xrec (L,N,T,nc,d,d); only positions are decoded for order 2 (odegpvae.py:18-35)."""
         L, N, T, nc, d, _ = dims
         lat = ztL if self.order == 1 else ztL[..., :ztL.shape[-1] // 2]
-        return self.vae.decoder(lat).view([L, N, T, nc, d, d])
+        return (self.vae.decoder(lat, logits=True) if logits else self.vae.decoder(lat)).view([L, N, T, nc, d, d])
 
     def sample_trajectories(self, z0, T, L=1):
         """L independent function draws, each shared by the whole minibatch (odegpvae.py:37-45)."""
@@ -41,7 +41,7 @@ class ODEGPVAE(nn.Module):
         mu_v, logv_v = vel(torch.squeeze(X[:, 0:self.v_steps]))
         return torch.concat([z0, vel.sample(mu=mu_v, logvar=logv_v)], dim=1), (mu_s, logv_s), (mu_v, logv_v)
 
-    def forward(self, X, L=1, T_custom=None):
+    def forward(self, X, L=1, T_custom=None, logits=False):
         """X (N,T,nc,d,d) -> (Xrec (L,N,T',nc,d,d), (mu_s, logv_s), (mu_v, logv_v)); T' = T_custom or T (odegpvae.py:48-70)."""
         N, T, nc, d, _ = X.shape
         horizon = T_custom if T_custom else T
@@ -50,4 +50,4 @@ class ODEGPVAE(nn.Module):
             field.prebuild_cache()                   # overlap mode only: the draw's cache builds next to the encoder
         z0, code_s, code_v = self.encode_initial_state(X)
         ztL = self.sample_trajectories(z0, horizon, L)
-        return self.build_decoding(ztL, (L, N, horizon, nc, d, d)), code_s, code_v
+        return self.build_decoding(ztL, (L, N, horizon, nc, d, d), logits), code_s, code_v

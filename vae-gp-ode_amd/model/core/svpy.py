@@ -131,6 +131,10 @@ class SVGP_Layer(torch.nn.Module):
             return None
         self._prebuilt = None
         torch.cuda.current_stream().wait_stream(ops.side_stream())
+        if self.width_pad is not None:
+            # the unpadded attribute slices are torch-native gathers of the cache's tensors: they launch on the current stream,
+            # so they are taken here, after the join, not next to the side-stream kernels that write those tensors
+            self.kern._set_cache(cache, cache.noise)
         return cache
 
     def forward(self, x):

@@ -90,7 +90,9 @@ class Decoder(nn.Module):
             nn.ConvTranspose2d(n_filt * 2, 1, kernel_size=5, stride=1, padding=(2, 2)),
             nn.Sigmoid())
 
-    def forward(self, x):
+    def forward(self, x, logits=False):
+        """``logits=True`` stops in front of the final nn.Sigmoid (create_model.compute_loss applies it fused with the likelihood)."""
+        out = (lambda a: a) if logits else V.sigmoid
         flat = x.contiguous().view([int(np.prod(list(x.shape[:-1]))), x.shape[-1]])
         d = self.decnn
         h = V.linear(flat, self.fc.weight, self.fc.bias)
@@ -101,11 +103,11 @@ class Decoder(nn.Module):
             c = V.conv_transpose2d(h, d[1].weight, d[1].bias, 1, 0)                                   # 4 -> 6
             c = V.bn_relu_conv_transpose2d(c, d[2], d[4].weight, d[4].bias, 2, 1)                     # 6 -> 13
             c = V.bn_relu_conv_transpose2d(c, d[5], d[7].weight, d[7].bias, 2, 1, 1)                  # 13 -> 28
-            return V.sigmoid(V.bn_relu_conv_transpose2d(c, d[8], d[10].weight, d[10].bias, 1, 2))
+            return out(V.bn_relu_conv_transpose2d(c, d[8], d[10].weight, d[10].bias, 1, 2))
         h = _bn(V.conv_transpose2d(h, d[1].weight, d[1].bias, 1, 0), d[2], relu=True)     # 4 -> 6
         h = _bn(V.conv_transpose2d(h, d[4].weight, d[4].bias, 2, 1), d[5], relu=True)     # 6 -> 13
         h = _bn(V.conv_transpose2d(h, d[7].weight, d[7].bias, 2, 1, 1), d[8], relu=True)  # 13 -> 28
-        return V.sigmoid(V.conv_transpose2d(h, d[10].weight, d[10].bias, 1, 2))
+        return out(V.conv_transpose2d(h, d[10].weight, d[10].bias, 1, 2))
 
     @property
     def device(self):

@@ -1,4 +1,6 @@
 """Model factory + ELBO (operator API of experiments/model/create_model.py)."""
+import os
+
 import torch
 from torch.distributions import kl_divergence as kl
 
@@ -6,6 +8,9 @@ from .core.flow import Flow
 from .core.odegpvae import ODEGPVAE
 from .core.svpy import SVGP_Layer
 from .core.vae import VAE
+
+
+_FUSED_LOSS = os.environ.get('GPODE_UNFUSED_LOSS', '0') != '1'
 
 
 def build_model(args):
@@ -31,6 +36,13 @@ def compute_loss(model, data, L):
     """-> (loss, nll, kl_reg, kl_u) (create_model.py:61-73).  Same terms as elbo() above; the per-row pieces go through
     three fused launches (KL rows, likelihood row sums, loss algebra) instead of ~25 elementwise ones."""
     from .. import vae_ops as V
+    field = model.flow.odefunc.diffeq
+    if _FUSED_LOSS and hasattr(field, 'us_packed') and model.vae.decoder.distribution == 'bernoulli':
+        # the decoder stops at its logits; sigmoid + likelihood row sums are one pass over them, and the three KL / mean / loss
+        # launches one more (gpode_sigmoid_loglik_fwd, gpode_elbo_all_fwd)
+        logits, (s0_mu, s0_logv), (v0_mu, v0_logv) = model(data, L, logits=True)
+        lpart, _ = V.sigmoid_loglik_parts(data, logits, L * data.shape[0])
+        return V.elbo_all(lpart, s0_mu, s0_logv, v0_mu, v0_logv, field.Um.optvar, field.us_packed(), field.M, model.num_observations)
     Xrec, (s0_mu, s0_logv), (v0_mu, v0_logv) = model(data, L)
     kl_rows = model.vae.encoder.kl_rows(s0_mu, s0_logv, v0_mu, v0_logv)               # (N,)
     lhood_rows = model.vae.decoder.log_prob_rowsum(data, Xrec, L)                     # (L, N)

@@ -4,6 +4,7 @@ Every function takes CUDA(=HIP) fp32 tensors, hands raw device pointers + the CU
 libgpode_hip.so and returns torch tensors.  Nothing here computes on the CPU.
 """
 import ctypes
+import os
 
 import torch
 
@@ -56,6 +57,11 @@ class launch_on:
         _launch_override.pop()
 
 
+def launching_on_side():
+    """True inside ``launch_on``: torch-native ops would run on another stream than this package's kernels."""
+    return bool(_launch_override)
+
+
 def set_overlap(on):
     """Run the GP cache build / cache backward on a side stream (see above).  Gradients of the GP parameters are then
     completed by join_side_stream(), which the optimiser and the gradient all-reduce of this package call themselves."""
@@ -78,6 +84,18 @@ def fork_side_stream():
     side.wait_stream(torch.cuda.current_stream())
     _overlap['forked'] = True
     return side
+
+
+def _main_marker():
+    """One trivial kernel on the CURRENT stream (a 1-element fill of a private buffer).  Placed directly behind the fork of the
+    backward pass: a captured training step whose main branch has no node of its own between that fork and the encoder's
+    backward replays 0.07-0.15 ms slower (configs[1] 3.19 -> 3.12 ms, configs[0] 1.07 -> 0.93 ms; the first three nodes of
+    the following replay then start ~55 us apart -- profiles/r02b_notes.txt).  Measured, not understood: a property of how the
+    graph executor lays branches onto hardware queues."""
+    d = _overlap.get('marker')
+    if d is None or d.device != torch.device('cuda', torch.cuda.current_device()):
+        d = _overlap['marker'] = torch.zeros(1, dtype=torch.float32, device='cuda')
+    d.zero_()
 
 
 def join_side_stream():
@@ -219,18 +237,24 @@ def rhs_vjp(cache, x, a):
     return gx
 
 
-def param_grad(cache, x, a, gpack=None, nchunk=256, keep=None):
+_PGRAD_CHUNKS = int(os.environ.get('GPODE_PGRAD_CHUNKS', '256'))
+
+
+def param_grad(cache, x, a, gpack=None, nchunk=None, keep=None):
     """Gradient of sum_r <a_r, f(x_r)> w.r.t. every field of the pack, in pack layout.
     ``keep`` (a list): the chunk scratch is appended to it -- a caller that launches on a side stream must hold it until that
     stream has been joined (the caching allocator only knows the stream the block was allocated on)."""
     x = _chk(x, 'x'); a = _chk(a, 'a')
     R = x.shape[0]
-    nchunk = max(1, min(nchunk, R))
+    nchunk = max(1, min(_PGRAD_CHUNKS if nchunk is None else nchunk, R))
     pf = cache.pack.numel()
     slab = torch.empty(nchunk * pf, dtype=torch.float32, device=x.device)
     acc = 1 if gpack is not None else 0
     if gpack is None:
-        gpack = torch.zeros(pf, dtype=torch.float32, device=x.device)
+        # NOT torch.zeros: a torch-native fill launches on torch's current stream, and under launch_on(side) that is not the
+        # stream the chunk reduction writes gpack on -- the fill could land after it (seen as a run-to-run wobble of the GP
+        # parameter gradients whenever the side stream was ahead).  accumulate = 0: the reduction writes every entry.
+        gpack = torch.empty(pf, dtype=torch.float32, device=x.device)
     _lib.call('gpode_param_grad', KERNEL_ID[cache.kernel], cache.Di, cache.Do, cache.M, cache.S, _ptr(cache.pack),
               _ptr(x), _ptr(a), R, _ptr(slab), nchunk, _ptr(gpack), acc, _stream())
     if keep is not None:
@@ -417,6 +441,7 @@ class _Flow(torch.autograd.Function):
         if _overlap['on'] and leaves:
             # parameter gradients on the side stream, next to the encoder's backward; join_side_stream() adds them
             side = fork_side_stream()
+            _main_marker()
             scratch = []
             with launch_on(side):
                 gpack = param_grad(c, xs.reshape(-1, c.Di), ast.reshape(-1, c.Do), keep=scratch)

@@ -454,6 +454,74 @@ class _Elbo(torch.autograd.Function):
         return gl, gk, gu, None
 
 
+class _SigmoidLogLikParts(torch.autograd.Function):
+    """Decoder logits -> partial row sums of the Bernoulli log-likelihood of X under sigmoid(logits) (gpode_sigmoid_loglik_fwd):
+    the decoder's nn.Sigmoid (vae.py:84) and the summed log_prob (vae.py:136-153, create_model.py:49) in one pass over the logits."""
+
+    @staticmethod
+    def forward(ctx, X, a, rows):
+        X, a = _chk(X, 'X'), _chk(a, 'logits')
+        inner = a.numel() // rows
+        ns = _lib.load().gpode_sigmoid_loglik_splits(rows, inner)
+        z, part = torch.empty_like(a), _new((rows, ns), a)
+        _lib.call('gpode_sigmoid_loglik_fwd', _ptr(X), _ptr(a), _ptr(z), _ptr(part), rows, inner, X.numel(), ns, _stream())
+        ctx.save_for_backward(X, z)
+        ctx.rows, ctx.inner = rows, inner
+        ctx.mark_non_differentiable(z)
+        return part, z
+
+    @staticmethod
+    def backward(ctx, gpart, _gz):
+        X, z = ctx.saved_tensors
+        # the ELBO hands every slice of a row the row's gradient: column 0 is the row gradient
+        grow = gpart[:, 0].contiguous() if gpart.shape[1] > 1 else gpart.contiguous()
+        ga = torch.empty_like(z)
+        _lib.call('gpode_sigmoid_loglik_bwd', _ptr(X), _ptr(z), _ptr(grow), _ptr(ga), ctx.rows, ctx.inner, X.numel(), _stream())
+        return None, ga, None
+
+
+class _ElboAll(torch.autograd.Function):
+    """(loss, -mean lhood, mean KL(z0), KL(u)) of create_model.py:61-73 from the likelihood partial sums, the encoder's packed
+    (mu | logvar) rows and the inducing posterior, one launch forward and one backward (gpode_elbo_all_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, lpart, hs, hv, Um, Us, rows, M, nobs):
+        lpart, hs, Um, Us = _chk(lpart, 'lpart'), _chk(hs, 'hs'), _chk(Um, 'Um'), _chk(Us, 'Us_sqrt.optvar')
+        hv = _chk(hv, 'hv') if hv is not None else None
+        N, q = hs.shape[0], hs.shape[1] // 2
+        out = _new((4,), lpart)
+        _lib.call('gpode_elbo_all_fwd', _ptr(lpart), rows, lpart.numel(), _ptr(hs), _ptr(hv), N, q, M, Um.shape[1], _ptr(Um), _ptr(Us),
+                  ctypes.c_float(nobs), _ptr(out), _stream())
+        ctx.save_for_backward(hs, hv, Um, Us)
+        ctx.dims = (rows, N, q, M, float(nobs), tuple(lpart.shape))
+        ctx.set_materialize_grads(False)
+        return out[0], out[1], out[2], out[3]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2, g3):
+        hs, hv, Um, Us = ctx.saved_tensors
+        rows, N, q, M, nobs, lshape = ctx.dims
+        gs = [None if g is None else g.contiguous().float() for g in (g0, g1, g2, g3)]
+        glrow = _new((rows,), hs)
+        ghs, ghv = torch.empty_like(hs), (torch.empty_like(hv) if hv is not None else None)
+        dUm, dUs = torch.empty_like(Um), torch.empty_like(Us)
+        _lib.call('gpode_elbo_all_bwd', *[_ptr(g) for g in gs], rows, _ptr(hs), _ptr(hv), N, q, M, Um.shape[1], _ptr(Um), _ptr(Us),
+                  ctypes.c_float(nobs), _ptr(glrow), _ptr(ghs), _ptr(ghv), _ptr(dUm), _ptr(dUs), _stream())
+        # every slice of a likelihood row carries the row's gradient (a broadcast view: nothing is copied)
+        return glrow.view(rows, 1).expand(lshape), ghs, ghv, dUm, dUs, None, None, None
+
+
+def sigmoid_loglik_parts(X, logits, rows):
+    """-> (partial row sums (rows, nsplit) of the Bernoulli log-likelihood, z = sigmoid(logits))."""
+    return _SigmoidLogLikParts.apply(X, logits, rows)
+
+
+def elbo_all(lpart, mu_s, logvar_s, mu_v, logvar_v, Um, Us_packed, M, nobs):
+    """-> (loss, nll, kl_reg, kl_u), see _ElboAll."""
+    hv = _pack(mu_v, logvar_v) if mu_v is not None else None
+    return _ElboAll.apply(lpart, _pack(mu_s, logvar_s), hv, Um, Us_packed, lpart.shape[0], M, float(nobs))
+
+
 def _pack(mu, logvar):
     h = _packed_halves(mu, logvar)
     return h if h is not None else torch.cat((mu, logvar), dim=1)
