@@ -241,7 +241,8 @@ int gpode_loglik_rowsum_bwd(const float* X, const float* z, const float* grow, f
  *                             part[row][split] (gpode_sigmoid_loglik_splits(rows, inner) proposes nsplit).  X (nX floats) is broadcast
  *                             over the rows * inner / nX copies of it.  Same arithmetic as gpode_act_fwd + gpode_loglik_rowsum_fwd.
  *   gpode_sigmoid_loglik_bwd  ga = grow[row] * d/da, the chain gpode_loglik_rowsum_bwd -> gpode_act_bwd in one pass
- *   gpode_elbo_all_fwd        out[4] = {loss, -mean lhood, mean kl, kl_u} (create_model.py:61-73) from the nl_values partial sums
+ *   gpode_elbo_all_fwd        out[0..3] = {loss, -mean lhood, mean kl, kl_u} (out: 4 + 256 floats, the tail is scratch for the
+ *                             sum over a big Us) (create_model.py:61-73) from the nl_values partial sums
  *                             of nl_rows likelihood rows, the encoder's rows hs = (mu | logvar), N x 2q (hv: the velocity half of a
  *                             second-order model, or NULL) -- KL(q(z0) || N(0, I)), create_model.py:47-49 -- and the inducing
  *                             posterior (Um M x Do, Us packed lower triangles Do x M(M+1)/2) -- KL(q(u) || N(0, I)), svpy.py:144-175

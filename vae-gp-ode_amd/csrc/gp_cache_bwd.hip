@@ -909,56 +909,52 @@ __global__ __launch_bounds__(256) void k_chain_rbf(int Di, int Do, int M, int S,
 
 // DF step 1: per feature s, gradient w.r.t. omega[p,s,q] from the om fields and through B(omega):
 //   gom[s][p*D+q]
+// One workgroup per feature, thread (p, q): the D x D tables sit in LDS (one thread per feature with five D x D register arrays
+// was 0.87 ms at D = 16 -- four 64-thread workgroups, spilling -- and 13 us on the critical tail of the step at D = 6).
 template <int D>
-__global__ void k_df_gomega(int S, const float* __restrict__ pack, const float* __restrict__ gpack,
-                            const float* __restrict__ var, float* __restrict__ gom) {
+__global__ __launch_bounds__(((D * D + 63) / 64) * 64) void k_df_gomega(int S, const float* __restrict__ pack, const float* __restrict__ gpack,
+                                                                         const float* __restrict__ var, float* __restrict__ gom) {
   constexpr int RQ = cdiv(2 * D + 3, 4);
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S) return;
+  __shared__ float om[D][D + 1], gB[D][D + 1], G[D][D + 1], nrm[D];   // om[p][q] = omega[p,s,q]
+  const int s = blockIdx.x, t = threadIdx.x;
   const int lane = s & 63, j0 = s >> 6;
-  float om[D][D], gB[D][D], nrm[D], G[D][D], go[D][D];  // om[p][q] = omega[p,s,q]
-#pragma unroll
-  for (int i = 0; i < D; ++i) {
-    const size_t base = (size_t)(j0 * D + i) * RQ;  // record (s,i): fields om_k = omega[k,s,i]/(2 pi), bs_j
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-      om[k][i] = rec_field(pack, base, lane, k) * GP_2PI;
-      go[k][i] = rec_field(gpack, base, lane, k) * GP_INV2PI;
-    }
-#pragma unroll
-    for (int j = 0; j < D; ++j) gB[i][j] = rec_field(gpack, base, lane, D + 3 + j) * sqrtf(var[j] / (float)S);
+  const bool on = t < D * D;
+  const int p = on ? t / D : 0, q = on ? t % D : 0;
+  float go = 0.f;
+  if (on) {
+    // thread (k = p, i = q) of record (s, i): fields om_k = omega[k,s,i]/(2 pi), bs_j
+    const size_t base = (size_t)(j0 * D + q) * RQ;
+    om[p][q] = rec_field(pack, base, lane, p) * GP_2PI;
+    go = rec_field(gpack, base, lane, p) * GP_INV2PI;
+    // gB[i][j]: thread (i = p, j = q)
+    gB[p][q] = rec_field(gpack, (size_t)(j0 * D + p) * RQ, lane, D + 3 + q) * sqrtf(var[q] / (float)S);
   }
-#pragma unroll
-  for (int j = 0; j < D; ++j) {
+  __syncthreads();
+  if (t < D) {
     float n2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < D; ++k) n2 = fmaf(om[k][j], om[k][j], n2);
-    nrm[j] = sqrtf(n2);
+    for (int k = 0; k < D; ++k) n2 = fmaf(om[k][t], om[k][t], n2);
+    nrm[t] = sqrtf(n2);
   }
+  if (on) {
+    float g = 0.f;
 #pragma unroll
-  for (int i = 0; i < D; ++i)
+    for (int k = 0; k < D; ++k) g = fmaf(om[p][k], om[q][k], g);
+    G[p][q] = g;
+  }
+  __syncthreads();
+  if (on) {
+    // B[i][j] = nrm_j d_ij - G[i][j]/nrm_j
+    float t1 = 0.f;
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-      float g = 0.f;
+    for (int i = 0; i < D; ++i) t1 = fmaf(gB[i][q], ((i == q) ? 1.f : 0.f) + G[i][q] / (nrm[q] * nrm[q]), t1);
+    float g = t1 * om[p][q] / nrm[q];
 #pragma unroll
-      for (int k = 0; k < D; ++k) g = fmaf(om[i][k], om[j][k], g);
-      G[i][j] = g;
-    }
-  // B[i][j] = nrm_j d_ij - G[i][j]/nrm_j
+    for (int j = 0; j < D; ++j) g = fmaf(-gB[p][j] / nrm[j], om[j][q], g);
 #pragma unroll
-  for (int p = 0; p < D; ++p)
-#pragma unroll
-    for (int q = 0; q < D; ++q) {
-      float t1 = 0.f;
-#pragma unroll
-      for (int i = 0; i < D; ++i) t1 = fmaf(gB[i][q], ((i == q) ? 1.f : 0.f) + G[i][q] / (nrm[q] * nrm[q]), t1);
-      float g = t1 * om[p][q] / nrm[q];
-#pragma unroll
-      for (int j = 0; j < D; ++j) g = fmaf(-gB[p][j] / nrm[j], om[j][q], g);
-#pragma unroll
-      for (int i = 0; i < D; ++i) g = fmaf(-gB[i][p] / nrm[p], om[i][q], g);
-      gom[(size_t)s * D * D + p * D + q] = go[p][q] + g;
-    }
+    for (int i = 0; i < D; ++i) g = fmaf(-gB[i][p] / nrm[p], om[i][q], g);
+    gom[(size_t)s * D * D + p * D + q] = go + g;
+  }
 }
 
 // DF step 2: chain rule to the raw parameters.  One workgroup per output scalar (D*D lengthscales, D variances),
@@ -1155,7 +1151,7 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
   if (Do == D_) {                                                                                                          \
     hipLaunchKernelGGL(k_Kbwd_df<D_>, M, 64, 0, st, M, b.np, Z, ws + w.ell, ws + w.var, bws + b.S, bws + b.gZpart,         \
                        bws + b.kpart);                                                                                     \
-    hipLaunchKernelGGL(k_df_gomega<D_>, cdiv(S, 64), 64, 0, st, S, pack, gpack, ws + w.var, bws + b.gom);                  \
+    hipLaunchKernelGGL(k_df_gomega<D_>, S, ((D_ * D_ + 63) / 64) * 64, 0, st, S, pack, gpack, ws + w.var, bws + b.gom);                  \
     hipLaunchKernelGGL(k_chain_df<D_>, D_ * D_ + D_ + cdiv(M * D_, 256), 256, 0, st, M, S, pack, gpack, raw_ell, raw_var, bws + b.gom, bws + b.vjpZ,      \
                        bws + b.gZpart, bws + b.kpart, g_raw_ell, g_raw_var, g_Z);                                          \
     return check_launch("cache bwd: chain df");                                                                            \

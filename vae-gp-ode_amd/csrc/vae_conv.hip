@@ -565,14 +565,33 @@ __global__ void k_sigmoid_loglik_bwd(const float* __restrict__ X, const float* _
 // out[0..3] = {loss, -mean lhood, mean kl, kl_u} (create_model.py:61-73) from the likelihood partial sums (nl_values of them over
 // nl_rows rows), the encoder's packed (mu | logvar) rows hs (and hv for second-order models; KL of a factorised Gaussian is additive)
 // and the inducing posterior (Um, packed Us: svpy.py:144-175, k_svgp_kl in gp_misc.hip).  ONE workgroup, fixed-order reductions.
+// sum of squares of a long vector in kElboParts fixed slices (the packed Us of a big inducing set: 2.1 M entries at M = 512, D = 16
+// took one workgroup 0.87 ms)
+constexpr int kElboParts = 256;
+__global__ __launch_bounds__(256) void k_sumsq_parts(const float* __restrict__ v, size_t n, float* __restrict__ part) {
+  __shared__ float red[4];
+  const size_t chunk = (n + kElboParts - 1) / kElboParts, e0 = blockIdx.x * chunk, e1 = e0 + chunk < n ? e0 + chunk : n;
+  float acc = 0.f;
+  for (size_t e = e0 + threadIdx.x; e < e1; e += 256) acc = fmaf(v[e], v[e], acc);
+  float in1[1] = {acc}, out1[1];
+  wave_sum_multi<1>(in1, out1);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = out1[0];
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ __launch_bounds__(1024) void k_elbo_all_fwd(const float* __restrict__ lpart, int nl_rows, int nl_values, const float* __restrict__ hs,
                                                         const float* __restrict__ hv, int N, int q, int M, int Do,
                                                         const float* __restrict__ Um, const float* __restrict__ Us, float nobs,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, const float* __restrict__ usq_part) {
   __shared__ float red[16][3];
   const size_t P = (size_t)M * (M + 1) / 2;
   float u = 0.f, a = 0.f, b = 0.f;
-  for (size_t e = threadIdx.x; e < P * Do; e += blockDim.x) u = fmaf(Us[e], Us[e], u);
+  if (usq_part) {                                    // ||Us||_F^2 arrives as kElboParts partial sums
+    for (int e = threadIdx.x; e < kElboParts; e += blockDim.x) u += usq_part[e];
+  } else {
+    for (size_t e = threadIdx.x; e < P * Do; e += blockDim.x) u = fmaf(Us[e], Us[e], u);
+  }
   for (int e = threadIdx.x; e < M * Do; e += blockDim.x) {
     const int m = e / Do, d = e % Do;
     const float l = Us[(size_t)d * P + (size_t)m * (m + 1) / 2 + m];
@@ -666,7 +685,14 @@ int sigmoid_loglik_bwd(const float* X, const float* z, const float* grow, float*
 }
 int elbo_all_fwd(const float* lpart, int nl_rows, int nl_values, const float* hs, const float* hv, int N, int q, int M, int Do,
                  const float* Um, const float* Us, float nobs, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(k_elbo_all_fwd, 1, 1024, 0, st, lpart, nl_rows, nl_values, hs, hv, N, q, M, Do, Um, Us, nobs, out);
+  // out: 4 results + kElboParts floats of scratch
+  const size_t nus = (size_t)M * (M + 1) / 2 * Do;
+  const float* usq = nullptr;
+  if (nus > ((size_t)1 << 16)) {
+    hipLaunchKernelGGL(k_sumsq_parts, kElboParts, 256, 0, st, Us, nus, out + 4);
+    usq = out + 4;
+  }
+  hipLaunchKernelGGL(k_elbo_all_fwd, 1, 1024, 0, st, lpart, nl_rows, nl_values, hs, hv, N, q, M, Do, Um, Us, nobs, out, usq);
   return check_launch("elbo_all_fwd");
 }
 int elbo_all_bwd(const float* g0, const float* g1, const float* g2, const float* g3, int nl_rows, const float* hs, const float* hv, int N,

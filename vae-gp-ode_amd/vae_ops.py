@@ -489,7 +489,7 @@ class _ElboAll(torch.autograd.Function):
         lpart, hs, Um, Us = _chk(lpart, 'lpart'), _chk(hs, 'hs'), _chk(Um, 'Um'), _chk(Us, 'Us_sqrt.optvar')
         hv = _chk(hv, 'hv') if hv is not None else None
         N, q = hs.shape[0], hs.shape[1] // 2
-        out = _new((4,), lpart)
+        out = _new((4 + 256,), lpart)                # four results + the library's scratch
         _lib.call('gpode_elbo_all_fwd', _ptr(lpart), rows, lpart.numel(), _ptr(hs), _ptr(hv), N, q, M, Um.shape[1], _ptr(Um), _ptr(Us),
                   ctypes.c_float(nobs), _ptr(out), _stream())
         ctx.save_for_backward(hs, hv, Um, Us)
