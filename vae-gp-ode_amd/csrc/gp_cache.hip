@@ -303,11 +303,41 @@ template <int J> __device__ __forceinline__ void chol_pivots(float (&row)[NB], i
   }
 }
 
+// The same elimination with the division in front (LDL^T order): the multiplier column of pivot J is w = a_J / p_J, the update
+// a_C -= w * a_J[C] broadcasts the UNSCALED column (every broadcast of a pivot can issue as soon as the pivot starts), and the
+// scaling of the finished column by rsqrt(p_J) -- its final Cholesky values, sqrt(p_J) on the diagonal since a_J[J] = p_J --
+// leaves the dependent chain: per pivot it is  w = a_J * (1/p) -> update of column J+1 -> broadcast of p_(J+1) -> v_rcp + one
+// Newton step  (6 instructions; the classic order above has 12: v_rsq, Newton, scale, select, negate in line).  The 32 pivots
+// are a serial chain (tools/draw_probe.py: ~300 cycles per pivot, chain-bound from pivot ~12 on), so its length is the time.
+__device__ __forceinline__ float chol_rcp(float p) {
+  const float r = __builtin_amdgcn_rcpf(p);
+  return r * fmaf(-p, r, 2.f);
+}
+template <int J> __device__ __forceinline__ void ldl_pivots(float (&row)[NB], bool& bad, float piv, float rinv) {
+  if constexpr (J < NB) {
+    const float nw = -(row[J] * rinv);
+    float piv_n = 1.f, rinv_n = 1.f;
+    if constexpr (J + 1 < NB) {
+      chol_cols_group<J, J + 1>(row, nw);            // columns J+1 .. J+4 (broadcasts of the unscaled row[J])
+      piv_n = GP_BCAST(row[J + 1], J + 1);
+      bad |= !(piv_n > 0.f);
+      rinv_n = chol_rcp(piv_n);
+      chol_cols<J, J + 5>(row, nw);
+    }
+    row[J] *= chol_rsqrt(piv);                       // off the chain; lane J: p * rsqrt(p) = sqrt(p)
+    ldl_pivots<J + 1>(row, bad, piv_n, rinv_n);
+  }
+}
+
 // returns true when a pivot was not positive (matrix not positive definite)
 __device__ __forceinline__ bool chol32_panel_wave(float (&row)[NB], int lane) {
   const float piv = GP_BCAST(row[0], 0);
   bool bad = !(piv > 0.f);
+#ifdef GPODE_CHOL_CLASSIC
   chol_pivots<0>(row, lane, bad, piv, chol_rsqrt(piv));
+#else
+  ldl_pivots<0>(row, bad, piv, chol_rcp(piv));
+#endif
   return bad;
 }
 
@@ -392,6 +422,147 @@ __global__ __launch_bounds__(256) void k_chol_rl(float* __restrict__ Aall, float
       float* dst = A + (size_t)(i * NB + r) * np + j * NB + tx;
       *dst = *dst - acc;
     }
+  }
+}
+
+// TWO block columns (k, k+1) per launch -- the launch chain of a mid-sized factor (n = 600: 19 dependent launches of ~11 us) is
+// bound by launch + factorisation latency, not by work, so a workgroup redoes what it would otherwise wait a launch for:
+//   stage 1  [D_k ; A_ik], [D_k ; A_jk], [D_k ; A_(k+1)k] -> L_ik, L_jk, L_1        (three wavefronts side by side)
+//   stage 2  E = A_(k+1)(k+1) - L_1 L_1^T,  Q_i = A_i(k+1) - L_ik L_1^T,  Q_j likewise   (the column k+1 after step k)
+//   stage 3  [E ; Q_i], [E ; Q_j] -> L_(k+1)(k+1), L_i(k+1), L_j(k+1)
+//   stage 4  A_ij -= L_ik L_jk^T + L_i(k+1) L_j(k+1)^T
+// Tiles of column k stop after stage 1 and publish L_ik, tiles of column k+1 after stage 3 and publish L_i(k+1).  Nothing a
+// workgroup reads is written in place by another one (columns k and k+1 of A are only read; factors go to Lmat / Dfac).
+__device__ __forceinline__ void tile_load(float (&dst)[NB][NB + 1], const float* __restrict__ A, int np, int r0, int c0, int tx, int ty) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dst[ty + 8 * q][tx] = A[(size_t)(r0 + ty + 8 * q) * np + c0 + tx];
+}
+// dst = src - X Y^T (32 x 32 tiles in LDS), 256 threads
+__device__ __forceinline__ void tile_sub_xyt(float (&dst)[NB][NB + 1], const float (&src)[NB][NB + 1], const float (&X)[NB][NB + 1],
+                                             const float (&Y)[NB][NB + 1], int tx, int ty) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = ty + 8 * q;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int p = 0; p < NB; ++p) acc = fmaf(X[r][p], Y[tx][p], acc);
+    dst[r][tx] = src[r][tx] - acc;
+  }
+}
+// one wavefront: factor [Dt ; Pt] (rows of the diagonal tile in lanes 0..31, of the panel tile in lanes 32..63); the panel half goes
+// to Lp, the diagonal half (lower triangle, zeros above) to Ld when given
+__device__ __forceinline__ bool tile_factor(const float (&Dt)[NB][NB + 1], const float (&Pt)[NB][NB + 1], float (&Lp)[NB][NB + 1],
+                                            float (*Ld)[NB + 1], int lane) {
+  const int r = lane & 31;
+  const bool panel = lane >= 32;
+  float row[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) row[c] = panel ? Pt[r][c] : Dt[r][c];
+  const bool bad = chol32_panel_wave(row, lane);
+  if (panel) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c) Lp[r][c] = row[c];
+  } else if (Ld) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c) Ld[r][c] = c <= r ? row[c] : 0.f;
+  }
+  return bad;
+}
+
+__global__ __launch_bounds__(256) void k_chol_rl2(float* __restrict__ Aall, float* __restrict__ Lall, int np, size_t batch_stride,
+                                                   float* __restrict__ Dfac_all, size_t dfac_stride, int k, int* __restrict__ info,
+                                                   int nblk, int nreal) {
+  __shared__ float sD[NB][NB + 1], sPi[NB][NB + 1], sPj[NB][NB + 1], sP1[NB][NB + 1];      // column k: A_kk, A_ik, A_jk, A_(k+1)k
+  __shared__ float sE[NB][NB + 1], sQi[NB][NB + 1], sQj[NB][NB + 1];                        // column k+1: A_(k+1)(k+1), A_i(k+1), A_j(k+1)
+  __shared__ float lD[NB][NB + 1], lPi[NB][NB + 1], lPj[NB][NB + 1], lP1[NB][NB + 1];      // L_kk, L_ik, L_jk, L_(k+1)k
+  __shared__ float lE[NB][NB + 1], lQi[NB][NB + 1], lQj[NB][NB + 1];                        // L_(k+1)(k+1), L_i(k+1), L_j(k+1)
+  float* A = Aall + (size_t)blockIdx.y * batch_stride;
+  float* Lm = Lall + (size_t)blockIdx.y * batch_stride;
+  float* DfacB = Dfac_all + (size_t)blockIdx.y * dfac_stride;
+  const int t = blockIdx.x;
+  int ii = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+  while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+  while (ii * (ii + 1) / 2 > t) --ii;
+  const int i = k + ii, j = k + (t - ii * (ii + 1) / 2);            // tile (i, j), k <= j <= i
+  const int k1 = k + 1;
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5, wv = tid >> 6, lane = tid & 63;
+  const int c0 = k * NB, c1 = k1 * NB;
+  const bool colk = j == k;                            // stops after stage 1
+  const bool colk1 = j == k1;                          // stops after stage 3
+  const bool needI = i > k, needJ = j > k && j != i;   // panel tiles of column k this workgroup factors
+  const bool need1 = !colk && i != k1 && j != k1;      // L_(k+1)k is not already one of them
+  tile_load(sD, A, np, c0, c0, tx, ty);
+  if (needI) tile_load(sPi, A, np, i * NB, c0, tx, ty);
+  if (needJ) tile_load(sPj, A, np, j * NB, c0, tx, ty);
+  if (need1) tile_load(sP1, A, np, c1, c0, tx, ty);
+  if (!colk) {
+    tile_load(sE, A, np, c1, c1, tx, ty);
+    if (i > k1) tile_load(sQi, A, np, i * NB, c1, tx, ty);
+    if (j > k1 && j != i) tile_load(sQj, A, np, j * NB, c1, tx, ty);
+  }
+  __syncthreads();
+  // ---- stage 1 ----
+  bool bad = false;
+  if (wv == 0) bad = tile_factor(sD, needI ? sPi : sD, lPi, lD, lane);     // (i == k: the panel half refactors D, unused)
+  else if (wv == 1 && needJ) tile_factor(sD, sPj, lPj, nullptr, lane);
+  else if (wv == 2 && need1) tile_factor(sD, sP1, lP1, nullptr, lane);
+  if (bad && t == 0 && lane == 0 && wv == 0) atomicOr(info, 1);
+  __syncthreads();
+  if (colk) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = ty + 8 * q;
+      if (i == k) {
+        DfacB[(size_t)k * NB * NB + r * NB + tx] = lD[r][tx];
+        if (r == tx && c0 + r < nreal) {
+          atomicMin(reinterpret_cast<unsigned*>(info) + 1, __float_as_uint(lD[r][tx]));
+          atomicMax(reinterpret_cast<unsigned*>(info) + 2, __float_as_uint(lD[r][tx]));
+        }
+      } else Lm[(size_t)(i * NB + r) * np + c0 + tx] = lPi[r][tx];
+    }
+    return;
+  }
+  // L_(k+1)k under its three names
+  const float (&L1)[NB][NB + 1] = (i == k1) ? lPi : ((j == k1) ? lPj : lP1);
+  // (j == k1 && j != i: needJ factored A_jk = A_(k+1)k into lPj;  i == k1 (then j == k1 too): it is lPi)
+  // ---- stage 2: column k+1 after step k ----
+  tile_sub_xyt(sE, sE, L1, L1, tx, ty);
+  if (i > k1) tile_sub_xyt(sQi, sQi, lPi, L1, tx, ty);
+  if (j > k1 && j != i) tile_sub_xyt(sQj, sQj, lPj, L1, tx, ty);
+  __syncthreads();
+  // ---- stage 3 ----
+  bool bad1 = false;
+  if (wv == 0) bad1 = tile_factor(sE, i > k1 ? sQi : sE, lQi, lE, lane);
+  else if (wv == 1 && j > k1 && j != i) tile_factor(sE, sQj, lQj, nullptr, lane);
+  if (bad1 && t == 2 && lane == 0 && wv == 0) atomicOr(info, 1);        // t == 2 is tile (k+1, k+1)
+  __syncthreads();
+  if (colk1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = ty + 8 * q;
+      if (i == k1) {
+        DfacB[(size_t)k1 * NB * NB + r * NB + tx] = lE[r][tx];
+        if (r == tx && c1 + r < nreal) {
+          atomicMin(reinterpret_cast<unsigned*>(info) + 1, __float_as_uint(lE[r][tx]));
+          atomicMax(reinterpret_cast<unsigned*>(info) + 2, __float_as_uint(lE[r][tx]));
+        }
+      } else Lm[(size_t)(i * NB + r) * np + c1 + tx] = lQi[r][tx];
+    }
+    return;
+  }
+  // ---- stage 4: trailing tile (j >= k + 2) ----
+  const float (&Lj0)[NB][NB + 1] = (j == i) ? lPi : lPj;
+  const float (&Lj1)[NB][NB + 1] = (j == i) ? lQi : lQj;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = ty + 8 * q;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int p = 0; p < NB; ++p) acc = fmaf(lPi[r][p], Lj0[tx][p], acc);
+#pragma unroll 8
+    for (int p = 0; p < NB; ++p) acc = fmaf(lQi[r][p], Lj1[tx][p], acc);
+    float* dst = A + (size_t)(i * NB + r) * np + j * NB + tx;
+    *dst = *dst - acc;
   }
 }
 
@@ -797,16 +968,21 @@ __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, 
       float dg = 1.f;
 #pragma unroll
       for (int r = 0; r < NB; ++r) dg = (r == c) ? Lc[r] : dg;
-      const float myinv = 1.f / dg;
-      float rb = q0 == 0 ? res[0] : (q0 == 1 ? res[1] : res[2]);
-      float xs[NB];
+      // rows past n are padding (row n is the rhs row): their unknowns are 0, which a zero reciprocal gives for free
+      const float myinv = (c0 + c < n) ? 1.f / dg : 0.f;
+      // Scaled by the reciprocal diagonal up front, y_c = res_c / L_cc and Lp[r] = L[r][c] / L_cc, a row of the substitution is
+      // broadcast -> one FMA: x_r = y_r when its turn comes, then y_c -= Lp[r] x_r for the columns left of it (the entries right
+      // of the diagonal are stored as zeros, the lane of row r itself is done).  No multiply, select or mask on the 32-long chain.
+#pragma unroll
+      for (int r = 0; r < NB; ++r) Lc[r] *= myinv;
+      float y = (q0 == 0 ? res[0] : (q0 == 1 ? res[1] : res[2])) * myinv;
+      float xs[NB], rb = 0.f;
 #pragma unroll
       for (int r = NB - 1; r >= 0; --r) {
-        const float t = rb * myinv;                          // in the lane of row r: x_r = res_r / L_rr
-        float xr = GP_BCAST(t, l0 + r);
-        xr = (c0 + r < n) ? xr : 0.f;                        // rows past n are padding (row n is the rhs row): x = 0
+        const float xr = GP_BCAST(y, l0 + r);
         xs[r] = xr;
-        rb = (c == r) ? xr : fmaf(-Lc[r], xr, rb);           // lanes c < r consume L[r][c]; lanes c > r hold x already
+        rb = (c == r) ? xr : rb;                             // this lane's own unknown (off the chain)
+        y = fmaf(-Lc[r], xr, y);
       }
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
@@ -993,7 +1169,14 @@ static void cholesky_blocked(float* A, float* Lmat, float* Dfac, int np, int nbl
         hipLaunchKernelGGL(k_syrk_mfma, dim3(Tt * (Tt + 1) / 2, w.batch), 256, 0, st, A, Lmat, w.np, bstride, jlim * NB, K * ST);
     }
   } else {
-    for (int k = 0; k < w.nblk; ++k) {
+    static const bool single = [] { const char* e = getenv("GPODE_CHOL_SINGLE_STEP"); return e && e[0] == '1'; }();
+    int k = 0;
+    if (!single)
+      for (; k + 1 < w.nblk; k += 2) {                 // two block columns per launch (k_chol_rl2)
+        const int T = w.nblk - k;
+        hipLaunchKernelGGL(k_chol_rl2, dim3(T * (T + 1) / 2, w.batch), 256, 0, st, A, Lmat, w.np, bstride, Dfac, dstride, k, info, w.nblk, nreal);
+      }
+    for (; k < w.nblk; ++k) {
       const int T = w.nblk - k;
       hipLaunchKernelGGL(k_chol_rl, dim3(T * (T + 1) / 2, w.batch), 256, 0, st, A, Lmat, w.np, bstride, Dfac, dstride, k, info, w.nblk, w.nblk, nreal);
     }
