@@ -25,6 +25,10 @@ def _chk(t, name, shape=None):
         raise _lib.GpodeError('%s must be float32, got %s' % (name, t.dtype))
     if shape is not None and tuple(t.shape) != tuple(shape):
         raise _lib.GpodeError('%s: expected shape %s, got %s' % (name, tuple(shape), tuple(t.shape)))
+    if not t.is_contiguous() and _launch_override:
+        # a torch-native copy launches on torch's current stream; inside launch_on() the kernels that read the copy do not
+        with torch.cuda.stream(_launch_override[-1]):
+            return t.contiguous()
     return t.contiguous()
 
 
@@ -33,7 +37,10 @@ def _chk(t, name, shape=None):
 # two serial, few-workgroup chains of the GP -- the cache build (Cholesky of K_uu, forward) and the cache backward
 # (triangular inverse, chain rule to the raw parameters) -- are launched on a side stream, where they run next to
 # the encoder's forward / backward kernels instead of in front of them.  Memory is always allocated on the current
-# stream; buffers a side-stream kernel touches are kept referenced until join_side_stream().
+# stream; buffers a side-stream kernel touches are kept referenced until join_side_stream().  Only THIS package's launches
+# follow launch_on(): a torch-native op inside such a region (a fill, a gather, .contiguous()) still runs on torch's current
+# stream, unordered against the side stream -- none may touch a buffer the side-stream kernels read or write
+# (profiles/r02b_notes.txt: a torch.zeros there made the GP parameter gradients wobble from run to run).
 # ---------------------------------------------------------------------------------------------
 _launch_override = []          # stack of torch streams that _stream() returns instead of the current stream
 _overlap = {'on': False, 'side': None, 'pending': [], 'forked': False}
