@@ -467,7 +467,8 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
             roof['integrator'] = {'bound': 'valu', 'kernel': 'rollout_team_kernel (rk4 rollout of the GP-ODE, one launch per draw)',
                                   'achieved': main['rollout_valu_frac'] * PEAK_FP32_TFLOPS, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
                                   'frac': main['rollout_valu_frac'], 'ms_per_launch': main['rollout_ms'],
-                                  'note': '%.3f MFLOP/trajectory x %d trajectories (SURVEY 8d; transcendentals count as 1 flop)' % (w['mflop'], w['batch'])}
+                                  'note': '%.3f MFLOP/trajectory x %d trajectories (SURVEY 8d; transcendentals count as 1 flop)' % (w['mflop'], w['batch']),
+                                  'saturated': main['rollout_saturated']}
             out['extra'] = {'configs': extra}
         if not a.no_cpu_baseline and n_gpus == 1:
             out['cpu_baseline'] = cpu_baseline_elbo(w, model, X)
@@ -542,6 +543,24 @@ def quick_elbo(w, dev, seed, steps=30, warmup=5):
     return ms, model, X
 
 
+def rollout_only_ms(w, dev, seed, reps=10):
+    """Median time of the rollout launch alone (HIP events on the launch stream) for workload `w`."""
+    from vae_gp_ode_amd import ops
+    flow, p, nz, z0, ts, nzd, z0d, tsd = make_inputs(w, seed, dev, 0)
+    gp = flow.odefunc.diffeq
+    with torch.no_grad():
+        c = gp.build_cache(noise=nzd)
+        for _ in range(3):
+            ops.rollout(c, z0d, tsd, w['order'], 'rk4')
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for e0, e1 in evs:
+            e0.record()
+            ops.rollout(c, z0d, tsd, w['order'], 'rk4')
+            e1.record()
+        torch.cuda.synchronize()
+    return float(np.median([e0.elapsed_time(e1) for e0, e1 in evs]))
+
+
 def other_configs(a, dev, main_name):
     """`extra.configs` of the line: configs[0] (the reference's CPU-runnable case and the north-star configuration, with the CPU
     oracle timed beside it in both modes) and configs[2], plus the integrator-only figures of the headline workload; one GPU."""
@@ -554,6 +573,11 @@ def other_configs(a, dev, main_name):
         rec['integrator_traj_per_s'] = w['batch'] / (ims * 1e-3)
         rec['rollout_ms'] = roll_ms
         rec['rollout_valu_frac'] = w['mflop'] * 1e6 * w['batch'] / (roll_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS
+        # the same rollout kernel with 16 x the trajectories per launch: the benchmark batches (32 - 256 per GPU) are one 4-wavefront
+        # team per CU or less, i.e. on the kernel's latency floor; this is where it saturates (tools/rollout_saturation.py)
+        big = rollout_only_ms(dict(w, batch=16 * max(w['batch'], 256)), dev, a.seed)
+        rec['rollout_saturated'] = {'trajectories': 16 * max(w['batch'], 256), 'rollout_ms': big,
+                                    'valu_frac': w['mflop'] * 1e6 * 16 * max(w['batch'], 256) / (big * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
         if name != main_name:
             ems, model, X = quick_elbo(w, dev, a.seed)
             rec['elbo_step_ms'] = ems
