@@ -241,7 +241,11 @@ __global__ void k_gUs(int M, int Do, const float* __restrict__ g_u, const float*
 
 // ---------------------------------------------------------------------------------------------
 // X = L^-T Phi,  Phi[i][j] = -r_i q_j + q_i v_j (i > j), half of that on the diagonal, 0 above
+// 32 x 32 output tile per workgroup, the tile products on the matrix cores: wavefront w owns the 16 x 16 quadrant
+// (w & 1, w >> 1), 8 v_mfma_f32_16x16x4_f32 per 32-deep k tile (exact fp32; the VALU version spent ~1.5 us per k tile on 160 LDS
+// reads per thread -- 29 + 33 us for the two products of the 608-row factor, on the exposed tail of the step).
 // ---------------------------------------------------------------------------------------------
+typedef float tf32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_gemm_phiX(const float* __restrict__ Linv_all, size_t batch_stride, int np, int nbn,
                                                     const float* __restrict__ vec_all, float* __restrict__ X_all) {
   __shared__ float sA[NB][NB + 1], sP[NB][NB + 1];
@@ -253,7 +257,8 @@ __global__ __launch_bounds__(256) void k_gemm_phiX(const float* __restrict__ Lin
   const float* vv = vec_all + (size_t)(4 * nb + b) * np;
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
   const float qj = vq[jb * NB + tx], vj = vv[jb * NB + tx];         // column quantities of this thread
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int lane = tid & 63, lr = lane & 15, lk = lane >> 4, mq = (tid >> 6) & 1, nq = tid >> 7;
+  tf32x4 macc = tf32x4{0.f, 0.f, 0.f, 0.f};
   float ra[4], rp[4];                                                // next block: Linv tile and the Phi tile generated on the fly
   auto load = [&](int ib) {
 #pragma unroll
@@ -272,15 +277,13 @@ __global__ __launch_bounds__(256) void k_gemm_phiX(const float* __restrict__ Lin
     for (int q = 0; q < 4; ++q) { sA[ty + 8 * q][tx] = ra[q]; sP[ty + 8 * q][tx] = rp[q]; }
     __syncthreads();
     if (ib + 1 < nbn) load(ib + 1);
-#pragma unroll 8
-    for (int p = 0; p < NB; ++p) {
-      const float pv = sP[p][tx];
+    // D[m = a][n = j] += sum_p Linv[p][a] Phi[p][j]:  A[m][k] = sA[k][m],  B[k][n] = sP[k][n]
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = fmaf(sA[p][ty + 8 * q], pv, acc[q]);
-    }
+    for (int ks = 0; ks < NB / 4; ++ks)
+      macc = __builtin_amdgcn_mfma_f32_16x16x4f32(sA[4 * ks + lk][16 * mq + lr], sP[4 * ks + lk][16 * nq + lr], macc, 0, 0, 0);
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) X[(size_t)(ab * NB + ty + 8 * q) * np + jb * NB + tx] = acc[q];
+  for (int r = 0; r < 4; ++r) X[(size_t)(ab * NB + 16 * mq + 4 * lk + r) * np + jb * NB + 16 * nq + lr] = macc[r];
 }
 
 // S = X L^-1
@@ -292,7 +295,8 @@ __global__ __launch_bounds__(256) void k_gemm_S(const float* __restrict__ X_all,
   const float* Li = Linv_all + (size_t)b * batch_stride;
   float* Sm = S_all + (size_t)b * batch_stride;
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int lane = tid & 63, lr = lane & 15, lk = lane >> 4, mq = (tid >> 6) & 1, nq = tid >> 7;
+  tf32x4 macc = tf32x4{0.f, 0.f, 0.f, 0.f};
   // tiles of k-block jb + 1 travel to registers while block jb is multiplied (the loop is latency-, not bandwidth-bound)
   float ra[4], rb[4];
   auto load = [&](int jb) {
@@ -310,15 +314,13 @@ __global__ __launch_bounds__(256) void k_gemm_S(const float* __restrict__ X_all,
     for (int q = 0; q < 4; ++q) { sA[ty + 8 * q][tx] = ra[q]; sB[ty + 8 * q][tx] = rb[q]; }
     __syncthreads();
     if (jb + 1 < nbn) load(jb + 1);
-#pragma unroll 8
-    for (int p = 0; p < NB; ++p) {
-      const float bv = sB[p][tx];
+    // D[m = r][n = c] += sum_p X[r][p] Linv[p][c]:  A[m][k] = sA[m][k],  B[k][n] = sB[k][n]
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = fmaf(sA[ty + 8 * q][p], bv, acc[q]);
-    }
+    for (int ks = 0; ks < NB / 4; ++ks)
+      macc = __builtin_amdgcn_mfma_f32_16x16x4f32(sA[16 * mq + lr][4 * ks + lk], sB[4 * ks + lk][16 * nq + lr], macc, 0, 0, 0);
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) Sm[(size_t)(ab * NB + ty + 8 * q) * np + cb * NB + tx] = acc[q];
+  for (int r = 0; r < 4; ++r) Sm[(size_t)(ab * NB + 16 * mq + 4 * lk + r) * np + cb * NB + 16 * nq + lr] = macc[r];
 }
 
 // ---------------------------------------------------------------------------------------------
