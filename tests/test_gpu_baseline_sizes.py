@@ -232,3 +232,51 @@ def test_configs4_forward_at_its_real_size():
     print('configs[4] N=128 T=64: trajectories <= %.1e up to t=16, then <= %.2f x the fp32 oracle\'s distance to fp64; '
           'decoder on the oracle\'s latents %.1e' % (worst_early, worst_ratio, e_x))
     assert e_x < 1e-4
+
+
+@pytest.mark.parametrize('late', ['main', 'side'])
+@pytest.mark.parametrize('name', ['configs[0]', 'configs[1]'])
+def test_overlap_mode_with_one_stream_held_up_gives_the_single_stream_gradients(name, late, monkeypatch):
+    """The side-stream overlap of the GP chains at the BASELINE shapes, with the MAIN (or the SIDE) stream held up for ~20 ms behind
+    every fork: whatever a side-stream kernel reads or writes must be ordered by the fork / join alone -- a torch-native op on the
+    main stream that touches such a buffer (a fill, a gather, a copy) lands long after (or long before) the side stream has used
+    it.  Loss terms and every parameter gradient must equal the run without overlap bit for bit (same kernels, same order of
+    every reduction)."""
+    from vae_gp_ode_amd import ops
+    from vae_gp_ode_amd.model.create_model import compute_loss
+    cfg = CONFIGS[name]
+
+    def run(overlap):
+        m, X, nz, eps_s, eps_v = _model_and_draw(cfg)
+        gp = m.flow.odefunc.diffeq
+        gp.set_noise({k: v.cuda() for k, v in nz.items()})
+        m.vae.encoder.next_eps = eps_s.cuda()
+        if eps_v is not None:
+            m.vae.encoder_v.next_eps = eps_v.cuda()
+        ops.set_overlap(overlap)
+        try:
+            out = compute_loss(m, X.cuda(), 1)
+            out[0].backward()
+            ops.join_side_stream()
+            torch.cuda.synchronize()
+        finally:
+            ops.set_overlap(False)
+        return [t.detach().clone() for t in out], {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    ref_out, ref_g = run(False)
+    fork = ops.fork_side_stream
+
+    def slow_fork():
+        side = fork()
+        if late == 'main':
+            torch.cuda._sleep(int(4e7))              # the main stream falls ~20 ms behind the side stream
+        else:
+            with torch.cuda.stream(side):
+                torch.cuda._sleep(int(4e7))
+        return side
+    monkeypatch.setattr(ops, 'fork_side_stream', slow_fork)
+    out, g = run(True)
+    for a, b in zip(out, ref_out):
+        assert torch.equal(a, b), (name, [float(t) for t in out], [float(t) for t in ref_out])
+    for k in ref_g:
+        assert torch.equal(g[k], ref_g[k]), (k, float((g[k] - ref_g[k]).abs().max()))
