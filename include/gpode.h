@@ -199,6 +199,14 @@ int gpode_bn_bwd_apply(const float* x, const float* gy, const float* gamma, cons
                        const float* save_invstd, const float* sums_gathered, const float* weights, int nranks, float count_all,
                        float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW, int relu, float* scratch,
                        void* stream);
+/* Deferred final reductions.  The backward entry points that end in "sum the partials of nsplit workgroups" (gpode_conv2d_bwd_weight*,
+ * gpode_bn_bwd, gpode_bn_bwd_apply, gpode_dec10_bn_bwd_apply, gpode_chan_sum) launch that last step themselves -- unless the call is
+ * made between gpode_defer_reductions(1) and gpode_defer_reductions(0): then it is recorded (the caller keeps the scratch buffer alive)
+ * and gpode_flush_reductions(stream) runs everything recorded so far in ONE launch; their outputs are valid after that.  This is what
+ * autograd's end-of-backward hook of the host mirror does (10-15 launches of a few microseconds of work become one graph node).
+ * mode 2 = drop what an aborted backward pass left behind, then as mode 1.  At most 24 pending jobs (further ones launch at once). */
+void gpode_defer_reductions(int mode);
+int gpode_flush_reductions(void* stream);
 /* The decoder's last stage backward, fused: decnn.10 = ConvTranspose2d(16 -> 1, 5, stride 1, padding 2) on 28 x 28 (vae.py:121) fed by
  * ReLU(BatchNorm2d(16)) (vae.py:119-120).  The gradient w.r.t. the normalised activation (25 multiply-adds per element from one
  * 3 KB plane of gy) is recomputed inside both BatchNorm backward passes instead of being written once and read twice:

@@ -220,6 +220,8 @@ int gpode_bn_bwd_apply(const float* x, const float* gy, const float* gamma, cons
   return gp::bn_bwd_apply(x, gy, gamma, beta, save_mean, save_invstd, sums_gathered, weights, nranks, count_all, gx, ggamma, gbeta, gx_chansum, B, C, HW, relu,
                           scratch, GP_ST);
 }
+void gpode_defer_reductions(int mode) { gp::defer_reductions(mode); }
+int gpode_flush_reductions(void* stream) { return gp::flush_reductions(GP_ST); }
 int gpode_dec10_bn_scratch_floats(void) { return gp::dec10_bn_scratch_floats(); }
 int gpode_dec10_bn_bwd_sums(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* save_mean,
                             const float* save_invstd, float* sums, int B, float* scratch, void* stream) {

@@ -116,6 +116,12 @@ int dec10_bn_bwd_sums(const float* c, const float* gy, const float* w, const flo
 int dec10_bn_bwd_apply(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* mean,
                        const float* invstd, const float* gathered, const float* wts, int W, float count_all, float* gc, float* ggamma,
                        float* gbeta, float* gc_chansum, int B, float* scratch, hipStream_t st);
+// final reductions of per-workgroup partials, recorded between defer_reductions(1) / (0) and run together by flush_reductions
+// (vae_norm.hip); outside such a bracket reduce_job launches at once
+struct RedJob { const float* part; float* out; int nsplit, n, kind, a, b, c; };
+int reduce_job(const RedJob& job, hipStream_t st);
+void defer_reductions(int mode);
+int flush_reductions(hipStream_t st);
 int bn_bwd_sums(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                 float* sums, int B, int C, int HW, int relu, float* scratch, hipStream_t st);
 int bn_bwd_apply(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,

@@ -373,7 +373,7 @@ int conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, 
   GP_CONV_KS(X)
 #undef X
   if (!ok) return set_error("gpode_conv2d_bwd_weight: kernel %d stride %d not built", K, S);
-  hipLaunchKernelGGL(k_sum_splits, (unsigned)((n + 255) / 256), 256, 0, st, scratch, used, n, gw);
+  if (reduce_job(RedJob{scratch, gw, used, (int)n, 0, 0, 0, 0}, st)) return 1;
   if (gbias) return chan_sum(gy, gbias, B, Co, Ho * Wo, scratch + (size_t)nsplit * n, st);
   return check_launch("conv_bwd_weight");
 }

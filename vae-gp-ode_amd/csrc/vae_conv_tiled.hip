@@ -458,7 +458,7 @@ static int launch_wgrad_mfma(const float* x, const float* gy, float* gw, float* 
   if (in_bn) hipLaunchKernelGGL(kb, nwg, NTHR, ldsm, st, x, gy, scratch, B, in_bn);
   else hipLaunchKernelGGL(km, nwg, NTHR, ldsm, st, x, gy, scratch, B, in_bn);
   const size_t n = (size_t)L::CI * L::CO * L::K * L::K;
-  hipLaunchKernelGGL(k_sum_splits_wgrad, (unsigned)((n + 63) / 64), 1024, 0, st, scratch, nwg, L::CI / 16, L::CO / 16, L::K * L::K, gw);
+  if (reduce_job(RedJob{scratch, gw, nwg, (int)n, 1, L::CI / 16, L::CO / 16, L::K * L::K}, st)) return 1;
   return check_launch("convT_wgrad_mfma");
 }
 
@@ -480,7 +480,7 @@ static int launch_T3(const float* x, const float* gy, float* gw, float* scratch,
   if (set_max_lds((const void*)kern, lds)) return 1;
   hipLaunchKernelGGL(kern, dim3(nsplit, L::CO / COW), 256, lds, st, x, gy, scratch, B, bps);
   const size_t n = (size_t)L::CI * L::CO * KK;
-  hipLaunchKernelGGL(k_sum_splits_t, (unsigned)((n + 255) / 256), 256, 0, st, scratch, nsplit, n, gw);
+  if (reduce_job(RedJob{scratch, gw, nsplit, (int)n, 0, 0, 0, 0}, st)) return 1;
   return check_launch("convT_wgrad_tiled");
 }
 
@@ -605,7 +605,7 @@ int dec10_bn_bwd_apply(const float* c, const float* gy, const float* w, const fl
   if (ipb == 4) rc = launch_dec10_bn<4, 1>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, nwg, count, gathered, wts, W, ggamma, gbeta, gc, part_gx);
   else rc = launch_dec10_bn<2, 1>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, nwg, count, gathered, wts, W, ggamma, gbeta, gc, part_gx);
   if (rc) return rc;
-  if (gc_chansum) hipLaunchKernelGGL(k_dec10_parts_reduce, 1, 512, 0, st, part_gx, nwg, gc_chansum, 0);
+  if (gc_chansum && reduce_job(RedJob{part_gx, gc_chansum, nwg, dec10::CI, 2, 0, 0, 0}, st)) return 1;
   return check_launch("dec10_bn_bwd_apply");
 }
 
@@ -625,7 +625,7 @@ int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch,
     const int ngroups = (B + IPB - 1) / IPB;
     const int nwg = ngroups < num_cus() ? ngroups : num_cus();
     hipLaunchKernelGGL(dec10::k_wgrad<IPB>, nwg, 512, sizeof(float) * fl, st, gy, x, scratch, B, in_bn);
-    hipLaunchKernelGGL(k_sum_splits4, (400 + 63) / 64, 1024, 0, st, scratch, nwg, (size_t)400, gw);
+    if (reduce_job(RedJob{scratch, gw, nwg, 400, 0, 0, 0, 0}, st)) return 1;
     return check_launch("dec10_wgrad_mfma");
   }
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) {
@@ -635,7 +635,7 @@ int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch,
     const size_t lds = sizeof(float) * (16 * 785 + 32 * 32);   // >= the [16][16][25] reduction buffer
     if (set_max_lds((const void*)k_dec10_wgrad, lds)) return 1;
     hipLaunchKernelGGL(k_dec10_wgrad, nsplit, 256, lds, st, gy, x, scratch, B, bps);
-    hipLaunchKernelGGL(k_sum_splits_t, 2, 256, 0, st, scratch, nsplit, (size_t)400, gw);
+    if (reduce_job(RedJob{scratch, gw, nsplit, 400, 0, 0, 0, 0}, st)) return 1;
     return check_launch("dec10_wgrad");
   }
   return -1;

@@ -11,6 +11,7 @@
 // channel), so the E[x^2] - E[x]^2 cancellation is relative to (mean - k)^2 / var = O(1), not mean^2 / var.
 // Reductions use fixed slabs and a fixed combine order: results are bitwise reproducible.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include "gp_launch.hpp"
 #include "wave_reduce.hpp"
 #include "bn_math.hpp"
@@ -404,7 +405,7 @@ int bn_bwd(const float* x, const float* gy, const float* gamma, const float* bet
   float* part_gx = gx_chansum ? scratch + (size_t)sp.ns * C * 2 + (size_t)C * 3 : nullptr;
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, save_mean, save_invstd, scratch, sp.used, (float)B * HW,
                      ggamma, gbeta, gx, part_gx, B, C, HW, sp.bps, relu, (const float*)nullptr, (const float*)nullptr, 0);
-  if (gx_chansum) hipLaunchKernelGGL(k_reduce_chan, C, 64, 0, st, part_gx, sp.used, C, gx_chansum);
+  if (gx_chansum && reduce_job(RedJob{part_gx, gx_chansum, sp.used, C, 2, 0, 0, 0}, st)) return 1;
   return check_launch("bn_bwd");
 }
 
@@ -454,7 +455,7 @@ int bn_bwd_apply(const float* x, const float* gy, const float* gamma, const floa
   float* part_gx = gx_chansum ? scratch + (size_t)sp.ns * C * 2 + (size_t)C * 3 : nullptr;
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, save_mean, save_invstd, scratch, sp.used, count,
                      ggamma, gbeta, gx, part_gx, B, C, HW, sp.bps, relu, gathered, wts, W);
-  if (gx_chansum) hipLaunchKernelGGL(k_reduce_chan, C, 64, 0, st, part_gx, sp.used, C, gx_chansum);
+  if (gx_chansum && reduce_job(RedJob{part_gx, gx_chansum, sp.used, C, 2, 0, 0, 0}, st)) return 1;
   return check_launch("bn_bwd_apply");
 }
 
@@ -468,11 +469,103 @@ int bn_eval(const float* x, const float* gy, const float* gamma, const float* be
 }
 
 // out[c] = sum over (b, hw) of v[b,c,hw]   (bias gradient of ConvTranspose2d / Conv2d)
+// ---------------------------------------------------------------------------------------------
+// Final reductions of per-workgroup partial sums, many tensors in ONE launch.
+// Every split-K weight gradient, bias gradient and BatchNorm channel sum of the backward pass ends in "sum the partials of nsplit
+// workgroups in a fixed order" -- a launch of a few microseconds of work that costs a graph node (~5 us on the queue) each, 10-15
+// per training step.  Between gpode_defer_reductions(1) and (0) those launches are recorded instead (their partials must stay alive),
+// and gpode_flush_reductions() runs them together: grid (blocks, jobs), 64 outputs x 16 split groups per workgroup, LDS combine.
+//   kind 0  out[e] = sum_s part[s n + e]
+//   kind 1  the accumulator layout of k_convT_wgrad_mfma: part[s][tap][mt][nt][r][lane] -> gw[ci][co][tap]   (a = MT, b = NT, c = KK)
+//   kind 2  out[e] = sum_s part[(s n + e) 2]      (channel sums kept as {sum, unused} pairs)
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int kMaxRedJobs = 24;
+struct RedJobs { RedJob j[kMaxRedJobs]; };
+std::mutex g_red_mu;
+RedJob g_red_jobs[kMaxRedJobs];
+int g_red_n = 0, g_red_defer = 0;
+
+__global__ __launch_bounds__(1024) void k_reduce_multi(RedJobs jobs) {
+  __shared__ float red[16][64];
+  const RedJob& jb = jobs.j[blockIdx.y];
+  const int n = jb.n;
+  if ((int)blockIdx.x * 64 >= n) return;
+  const int ex = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + ex;
+  float acc = 0.f;
+  if (e < n) {
+    const float* p = jb.part;
+    if (jb.kind == 2) {
+#pragma unroll 4
+      for (int s = sg; s < jb.nsplit; s += 16) acc += p[((size_t)s * n + e) * 2];
+    } else {
+#pragma unroll 8
+      for (int s = sg; s < jb.nsplit; s += 16) acc += p[(size_t)s * n + e];
+    }
+  }
+  red[sg][ex] = acc;
+  __syncthreads();
+  if (sg == 0 && e < n) {
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v += red[g][ex];
+    if (jb.kind == 1) {
+      const int MT = jb.a, NT = jb.b, KK = jb.c;
+      const int lane = e & 63, r = (e >> 6) & 3, tile = e >> 8;       // tile = (tap * MT + mt) * NT + nt
+      const int nt = tile % NT, mt = (tile / NT) % MT, t = tile / (NT * MT);
+      const int ci = mt * 16 + 4 * (lane >> 4) + r, co = nt * 16 + (lane & 15);
+      jb.out[((size_t)ci * (NT * 16) + co) * KK + t] = v;
+    } else {
+      jb.out[e] = v;
+    }
+  }
+}
+
+int launch_red(const RedJob* jobs, int nj, hipStream_t st) {
+  RedJobs all;
+  int maxn = 0;
+  for (int i = 0; i < nj; ++i) { all.j[i] = jobs[i]; maxn = jobs[i].n > maxn ? jobs[i].n : maxn; }
+  hipLaunchKernelGGL(k_reduce_multi, dim3((maxn + 63) / 64, nj), 1024, 0, st, all);
+  return check_launch("reduce_multi");
+}
+}  // namespace
+
+int reduce_job(const RedJob& job, hipStream_t st) {
+  if (job.n <= 0 || job.nsplit <= 0) return set_error("reduce_job: empty job");
+  {
+    std::lock_guard<std::mutex> lk(g_red_mu);
+    if (g_red_defer > 0 && g_red_n < kMaxRedJobs) {
+      g_red_jobs[g_red_n++] = job;
+      return 0;
+    }
+  }
+  return launch_red(&job, 1, st);
+}
+// mode 1: record from now on (nests); 0: one level back; 2: drop whatever an aborted backward pass left behind, then as 1
+void defer_reductions(int mode) {
+  std::lock_guard<std::mutex> lk(g_red_mu);
+  if (mode == 2) { g_red_n = 0; g_red_defer = 0; }
+  if (mode) ++g_red_defer;
+  else if (g_red_defer > 0) --g_red_defer;
+}
+int flush_reductions(hipStream_t st) {
+  RedJob local[kMaxRedJobs];
+  int nj;
+  {
+    std::lock_guard<std::mutex> lk(g_red_mu);
+    nj = g_red_n;
+    for (int i = 0; i < nj; ++i) local[i] = g_red_jobs[i];
+    g_red_n = 0;
+  }
+  return nj ? launch_red(local, nj, st) : 0;
+}
+
 int chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, hipStream_t st) {
   if ((HW & 3) == 0 && !aligned16(v)) return set_error("gpode_chan_sum: v must be 16-byte aligned");
   const Split sp = pick(B);
   hipLaunchKernelGGL(k_chan_sum, dim3(C, sp.used), 256, 0, st, v, B, C, HW, sp.bps, scratch);
-  hipLaunchKernelGGL(k_reduce_chan, C, 64, 0, st, scratch, sp.used, C, out);
+  if (reduce_job(RedJob{scratch, out, sp.used, C, 2, 0, 0, 0}, st)) return 1;
   return check_launch("chan_sum");
 }
 

@@ -234,7 +234,7 @@ def main(argv=None):
 
     meters = {k: RunningAverage(10) for k in ('elbo', 'nll', 'reg_kl', 'inducing_kl')}
     bn_sync = None
-    optimizer = HipAdam(model.parameters(), lr=args.lr, bucketed='gather' if dist is not None else True)
+    optimizer = HipAdam(model.parameters(), lr=args.lr, bucketed='gather' if dist is not None else False)
     sync = None
     if dist is not None:
         from .parallel import GradAllReduce, shard_batch

@@ -36,6 +36,7 @@ class HipAdam:
         self._gathered = False
         if self.gather:
             self.flat_grads.gather = self.gather_grads
+
         self._zero = {}
         offs, tot = [], 0
         for p in self.params:

@@ -25,6 +25,47 @@ def _bn_scratch(B, C, like):
     return _scratch(_lib.load().gpode_bn_scratch(B, C), like)
 
 
+# ---- deferred final reductions (include/gpode.h: gpode_defer_reductions / gpode_flush_reductions) --------------------------------
+# EXPERIMENTAL, off (set_deferred_reductions): the weight / bias gradients and BatchNorm channel sums produced by the backward
+# functions below then become valid at the END of the backward pass (one launch for all of them, from autograd's end-of-backward
+# callback) instead of when each function returns.  That is only sound when nothing reads them earlier, and autograd does read:
+# it clones an incoming gradient whenever it is not its sole owner, and adds it when ``p.grad`` exists.  Measured gain when it
+# works: configs[0] 0.927 -> 0.903 ms, configs[1] 3.10 -> 3.07 ms per step; tests/test_gpu_optim.py::
+# test_graph_replay_equals_eager_steps differs with it on (an early read somewhere in the pass), so no training loop enables it.
+_deferred = {'on': False, 'keep': [], 'queued': False}
+_DEFER_ALLOWED = os.environ.get('GPODE_EAGER_REDUCTIONS', '0') != '1'
+
+
+def set_deferred_reductions(on):
+    _deferred['on'] = bool(on) and _DEFER_ALLOWED
+
+
+def _flush_deferred():
+    _deferred['queued'] = False
+    try:
+        _lib.call('gpode_flush_reductions', _stream())
+    finally:
+        _deferred['keep'].clear()
+
+
+def _bwd_call(name, *args, keep=()):
+    """A backward-pass entry point whose last step is a reduction of workgroup partials (``keep``: its scratch buffers)."""
+    if not (_deferred['on'] and torch._C._current_graph_task_id() >= 0):
+        return _lib.call(name, *args)
+    lib = _lib.load()
+    if not _deferred['queued']:
+        lib.gpode_defer_reductions(2)                # drop leftovers of an aborted pass, then record
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
+        _deferred['queued'] = True
+    else:
+        lib.gpode_defer_reductions(1)
+    try:
+        _lib.call(name, *args)
+    finally:
+        lib.gpode_defer_reductions(0)
+    _deferred['keep'].extend(keep)
+
+
 _bn_sync = None        # parallel.BatchNormSync while data-parallel training normalises with global-minibatch statistics
 
 
@@ -60,9 +101,9 @@ def _bn_global_bwd(sync, x, gy, gamma, beta, mean, invstd, relu):
               _ptr(scratch), _stream())
     gathered = sync.gather(sums)
     gx, gg, gb, cs = _new(x.shape, x), _new((C,), x), _new((C,), x), _new((C,), x)
-    _lib.call('gpode_bn_bwd_apply', _ptr(x), _ptr(gy), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(gathered),
+    _bwd_call('gpode_bn_bwd_apply', _ptr(x), _ptr(gy), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(gathered),
               _ptr(sync.weights(x.device)), sync.world, ctypes.c_float(sync.count_all(B * HW)), _ptr(gx), _ptr(gg), _ptr(gb), _ptr(cs),
-              B, C, HW, int(relu), _ptr(scratch), _stream())
+              B, C, HW, int(relu), _ptr(scratch), _stream(), keep=(scratch,))
     return gx, gg, gb, cs
 
 
@@ -78,14 +119,14 @@ def _dec10_bn_bwd(sync, c, gy, w, gamma, beta, mean, invstd):
     head = (_ptr(c), _ptr(gy), _ptr(w), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd))
     if sync is None:
         _lib.call('gpode_dec10_bn_bwd_sums', *head, _ptr(None), B, _ptr(scratch), _stream())
-        _lib.call('gpode_dec10_bn_bwd_apply', *head, _ptr(None), _ptr(None), 0, ctypes.c_float(0.0), _ptr(gc), _ptr(gg), _ptr(gb), _ptr(cs),
-                  B, _ptr(scratch), _stream())
+        _bwd_call('gpode_dec10_bn_bwd_apply', *head, _ptr(None), _ptr(None), 0, ctypes.c_float(0.0), _ptr(gc), _ptr(gg), _ptr(gb), _ptr(cs),
+                  B, _ptr(scratch), _stream(), keep=(scratch,))
     else:
         sums = _new((32,), c)
         _lib.call('gpode_dec10_bn_bwd_sums', *head, _ptr(sums), B, _ptr(scratch), _stream())
         gathered = sync.gather(sums)
-        _lib.call('gpode_dec10_bn_bwd_apply', *head, _ptr(gathered), _ptr(sync.weights(c.device)), sync.world,
-                  ctypes.c_float(sync.count_all(B * 784)), _ptr(gc), _ptr(gg), _ptr(gb), _ptr(cs), B, _ptr(scratch), _stream())
+        _bwd_call('gpode_dec10_bn_bwd_apply', *head, _ptr(gathered), _ptr(sync.weights(c.device)), sync.world,
+                  ctypes.c_float(sync.count_all(B * 784)), _ptr(gc), _ptr(gg), _ptr(gb), _ptr(cs), B, _ptr(scratch), _stream(), keep=(scratch,))
     return gc, gg, gb, cs
 
 
@@ -97,6 +138,9 @@ def _fused_chansum(gy, C):
     cs = getattr(gy, '_gpode_chansum', None)
     if cs is None or tuple(cs.shape) != (C,):
         return None
+    # hand the tensor over with no second owner: autograd takes a gradient as it is only when nothing else refers to it, and clones
+    # it otherwise -- a read, which must not happen before the deferred reductions have run (set_deferred_reductions)
+    del gy._gpode_chansum
     fused_bias_grads += 1
     return cs
 
@@ -127,8 +171,9 @@ class _Conv2d(torch.autograd.Function):
             gw = _new(w.shape, x)
             pre = _fused_chansum(gy, Co) if has_b else None     # bias gradient already produced by the BatchNorm backward
             gb = _new((Co,), x) if (has_b and pre is None) else None
-            _lib.call('gpode_conv2d_bwd_weight', _ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), _ptr(_wgrad_scratch(B, Ci, Co, K, x)),
-                      B, Ci, H, W, Co, K, S, P, Ho, Wo, _stream())
+            ws = _wgrad_scratch(B, Ci, Co, K, x)
+            _bwd_call('gpode_conv2d_bwd_weight', _ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), _ptr(ws),
+                      B, Ci, H, W, Co, K, S, P, Ho, Wo, _stream(), keep=(ws, gy))
             if pre is not None:
                 gb = pre
         return gx, gw, gb, None, None
@@ -161,13 +206,14 @@ class _ConvT2d(torch.autograd.Function):
             _lib.call('gpode_conv2d_fwd', _ptr(gy), _ptr(w), _ptr(None), _ptr(gx), B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, _stream())
         if ctx.needs_input_grad[1]:
             gw = _new(w.shape, x)
-            _lib.call('gpode_conv2d_bwd_weight', _ptr(gy), _ptr(x), _ptr(gw), _ptr(None), _ptr(_wgrad_scratch(B, Cout, Cin, K, x)),
-                      B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, _stream())
+            ws = _wgrad_scratch(B, Cout, Cin, K, x)
+            _bwd_call('gpode_conv2d_bwd_weight', _ptr(gy), _ptr(x), _ptr(gw), _ptr(None), _ptr(ws),
+                      B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, _stream(), keep=(ws,))
             if has_b:
                 gb = _fused_chansum(gy, Cout)
                 if gb is None:
-                    gb = _new((Cout,), x)
-                    _lib.call('gpode_chan_sum', _ptr(gy), _ptr(gb), B, Cout, Ht * Wt, _ptr(_bn_scratch(B, Cout, x)), _stream())
+                    gb, bs = _new((Cout,), x), _bn_scratch(B, Cout, x)
+                    _bwd_call('gpode_chan_sum', _ptr(gy), _ptr(gb), B, Cout, Ht * Wt, _ptr(bs), _stream(), keep=(bs,))
         return gx, gw, gb, None, None, None
 
 
@@ -206,13 +252,14 @@ class _BnReluConvT(torch.autograd.Function):
         gw = gb = None
         if ctx.needs_input_grad[8]:
             gw = _new(w.shape, c)
-            _lib.call('gpode_conv2d_bwd_weight_bn', _ptr(gy), _ptr(c), _ptr(table), _ptr(gw), _ptr(None),
-                      _ptr(_wgrad_scratch(B, Cout, Cin, K, c)), B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, _stream())
+            ws = _wgrad_scratch(B, Cout, Cin, K, c)
+            _bwd_call('gpode_conv2d_bwd_weight_bn', _ptr(gy), _ptr(c), _ptr(table), _ptr(gw), _ptr(None),
+                      _ptr(ws), B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, _stream(), keep=(ws,))
             if has_b:
                 gb = _fused_chansum(gy, Cout)
                 if gb is None:
-                    gb = _new((Cout,), c)
-                    _lib.call('gpode_chan_sum', _ptr(gy), _ptr(gb), B, Cout, Ht * Wt, _ptr(_bn_scratch(B, Cout, c)), _stream())
+                    gb, bs = _new((Cout,), c), _bn_scratch(B, Cout, c)
+                    _bwd_call('gpode_chan_sum', _ptr(gy), _ptr(gb), B, Cout, Ht * Wt, _ptr(bs), _stream(), keep=(bs,))
         if _dec10_fused and (Cout, Cin, K, S, P, Hi, Wi, Ht, Wt) == (1, 16, 5, 1, 2, 28, 28, 28, 28):
             # the decoder's last stage: the gradient w.r.t. the normalised activation is recomputed inside both BatchNorm passes
             gc, gg, gbeta, cs = _dec10_bn_bwd(ctx.sync, c, gy, w, gamma, beta, mean, invstd)
@@ -225,8 +272,9 @@ class _BnReluConvT(torch.autograd.Function):
             gc, gg, gbeta, cs = _bn_global_bwd(ctx.sync, c, ga, gamma, beta, mean, invstd, 1)
         else:
             gc, gg, gbeta, cs = _new(c.shape, c), _new((Cin,), c), _new((Cin,), c), _new((Cin,), c)
-            _lib.call('gpode_bn_bwd', _ptr(c), _ptr(ga), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(gc), _ptr(gg), _ptr(gbeta),
-                      _ptr(cs), B, Cin, Hi * Wi, 1, _ptr(_bn_scratch(B, Cin, c)), _stream())
+            bs = _bn_scratch(B, Cin, c)
+            _bwd_call('gpode_bn_bwd', _ptr(c), _ptr(ga), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(gc), _ptr(gg), _ptr(gbeta),
+                      _ptr(cs), B, Cin, Hi * Wi, 1, _ptr(bs), _stream(), keep=(bs,))
         gc._gpode_chansum = cs
         return gc, gg, gbeta, None, None, None, None, None, gw, gb, None, None, None
 
@@ -262,8 +310,9 @@ class _BatchNormTrain(torch.autograd.Function):
             gx, gg, gb, cs = _bn_global_bwd(ctx.sync, x, gy, gamma, beta, mean, invstd, ctx.relu)
         else:
             gx, gg, gb, cs = _new(x.shape, x), _new((C,), x), _new((C,), x), _new((C,), x)
-            _lib.call('gpode_bn_bwd', _ptr(x), _ptr(gy.contiguous()), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(gx), _ptr(gg),
-                      _ptr(gb), _ptr(cs), B, C, HW, ctx.relu, _ptr(_bn_scratch(B, C, x)), _stream())
+            bs = _bn_scratch(B, C, x)
+            _bwd_call('gpode_bn_bwd', _ptr(x), _ptr(gy.contiguous()), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(gx), _ptr(gg),
+                      _ptr(gb), _ptr(cs), B, C, HW, ctx.relu, _ptr(bs), _stream(), keep=(bs,))
         # the channel sums of gx ride along with it: the convolution that produced x needs exactly these as its bias gradient
         gx._gpode_chansum = cs
         return gx, gg, gb, None, None, None, None, None, None
