@@ -23,6 +23,7 @@
 #include <type_traits>
 #include "conv_mfma.hpp"
 #include "conv_dec10_mfma.hpp"
+#include "conv_dec1_mfma.hpp"
 
 namespace gp {
 
@@ -491,7 +492,17 @@ int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx
   if (H != W || Ho != Wo) return -1;
   if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec7, 3, 2, 16>(gy, w, bias, gx, B, st, in_bn);
   if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec4, 3, 2, 16>(gy, w, bias, gx, B, st, in_bn);
-  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec1, 8, 8, 64>(gy, w, bias, gx, B, st, in_bn);
+  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) {
+    static const bool old = [] { const char* e = getenv("GPODE_DEC1_ENGINE"); return e && e[0] == '1'; }();
+    if (!in_bn && use_mfma() && !old) {              // taps folded into the GEMM's columns, weights resident in registers
+      const size_t lds = sizeof(float) * 2 * dec1::NPI * dec1::TLD;
+      if (set_max_lds((const void*)dec1::k_fwd, lds)) return 1;
+      const int cap = 2 * num_cus();                 // 74 KB of LDS per workgroup
+      hipLaunchKernelGGL(dec1::k_fwd, B < cap ? B : cap, 256, lds, st, gy, w, bias, gx, B);
+      return check_launch("dec1_fwd_mfma");
+    }
+    return launch_T1<Dec1, 8, 8, 64>(gy, w, bias, gx, B, st, in_bn);
+  }
   if (matches<Enc6>(Ci, Co, H, Ho, K, S, P) && use_mfma() && (reinterpret_cast<uintptr_t>(gy) & 15) == 0)   // d/d input of the encoder's cnn.6
     return launch_igemm<FwdPolicy<Enc6, 16>, 8, 4, 1>(gy, w, bias, gx, B, st, "enc_conv6_bwd_data_mfma", in_bn);
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) {
@@ -531,7 +542,16 @@ int tiled_fwd(const float* x, const float* w, const float* bias, float* y, int B
     if (alt) return launch_T2<Dec4, 3, 8, 3, 16, 1, 1>(x, w, y, B, st);
     return launch_T2<Dec4, 3, 8, 2, 32, 1, 1>(x, w, y, B, st);
   }
-  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T2<Dec1, 8, 32, 6, 32, 1, 1>(x, w, y, B, st);
+  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) {
+    static const bool old = [] { const char* e = getenv("GPODE_DEC1_ENGINE"); return e && e[0] == '1'; }();
+    if (use_mfma() && !old && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+      const size_t lds = sizeof(float) * (2 * dec1::GYF + 4 * dec1::NPI * 33);
+      const int cap = 2 * num_cus();
+      hipLaunchKernelGGL(dec1::k_bwd_data, B < cap ? B : cap, 256, lds, st, x, w, y, B);
+      return check_launch("dec1_bwd_data_mfma");
+    }
+    return launch_T2<Dec1, 8, 32, 6, 32, 1, 1>(x, w, y, B, st);
+  }
 
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) {
     if (use_mfma() && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
@@ -615,7 +635,19 @@ int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch,
   if (H != W || Ho != Wo) return -1;
   if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec7, 16, 2, 1, 1, 8, true>(gy, x, gw, scratch, B, st, in_bn);
   if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec4, 16, 2, 4, 2, 1, false>(gy, x, gw, scratch, B, st, in_bn);
-  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec1, 32, 8, 2, 4, 1, true>(gy, x, gw, scratch, B, st, in_bn);
+  if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) {
+    static const bool old = [] { const char* e = getenv("GPODE_DEC1_ENGINE"); return e && e[0] == '1'; }();
+    if (!in_bn && use_mfma() && !old && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {   // gy: the layer's input, x: grad_output
+      const size_t lds = sizeof(float) * 2 * dec1::GYF;
+      static const int wcap = [] { const char* e = getenv("GPODE_DEC1_WGRAD_WGS"); return e ? atoi(e) : 256; }();   // 256: 33.8 + 7.8 us (kernel + reduction of the partials) at 4096 images; 512: 33.1 + 10.8; 128: 56 + 6
+      const int cap = 2 * num_cus() < wcap ? 2 * num_cus() : wcap;
+      const int nwg = B < cap ? B : cap;
+      hipLaunchKernelGGL(dec1::k_wgrad, nwg, 256, lds, st, gy, x, scratch, B);
+      if (reduce_job(RedJob{scratch, gw, nwg, dec1::CI * dec1::NN, 0, 0, 0, 0}, st)) return 1;
+      return check_launch("dec1_wgrad_mfma");
+    }
+    return launch_T3<Dec1, 32, 8, 2, 4, 1, true>(gy, x, gw, scratch, B, st, in_bn);
+  }
   if (matches<Enc6>(Ci, Co, H, Ho, K, S, P) && use_mfma() && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0)
     return launch_wgrad_mfma<Enc6, 8, 2, 1, 4, true>(gy, x, gw, scratch, B, st, in_bn);   // d/d weight of the encoder's cnn.6
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P) && use_mfma() &&
