@@ -231,10 +231,12 @@ int gpode_chan_sum(const float* v, float* out, int B, int C, int HW, float* scra
 /* mode 0: ReLU, 1: sigmoid (vae.py:60,121).  Backward takes the forward OUTPUT y. */
 int gpode_act_fwd(const float* x, float* y, size_t n, int mode, void* stream);
 int gpode_act_bwd(const float* y, const float* gy, float* gx, size_t n, int mode, void* stream);
-/* nn.Linear (vae.py:64,107): x (B,In), w (Out,In). */
+/* nn.Linear (vae.py:64,107): x (B,In), w (Out,In).  scratch: gpode_linear_bwd_scratch(B, In, Out) floats, or NULL (the weight
+ * gradient of a narrow, tall layer -- the decoder's fc at thousands of rows -- is then summed without row slabs, ~3x slower). */
 int gpode_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, void* stream);
+size_t gpode_linear_bwd_scratch(int B, int In, int Out);
 int gpode_linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out,
-                     void* stream);
+                     float* scratch, void* stream);
 /* Decoder.log_prob (vae.py:136-153): ll = log(z) X + log(1-z)(1-X), X broadcast over the leading L copies
  * (nX = numel(X)).  rowsum: the sum([2,3,4,5]) of create_model.py:52-53 fused, rows = L*N, inner = T*C*H*W. */
 int gpode_loglik_fwd(const float* X, const float* z, float* ll, size_t n, size_t nX, void* stream);

@@ -68,7 +68,8 @@ SIGNATURES.update({
     'gpode_act_fwd': (_i, [_c_float_p, _c_float_p, _sz, _i, _vp]),
     'gpode_act_bwd': (_i, [_c_float_p, _c_float_p, _c_float_p, _sz, _i, _vp]),
     'gpode_linear_fwd': (_i, [_c_float_p] * 4 + [_i, _i, _i, _vp]),
-    'gpode_linear_bwd': (_i, [_c_float_p] * 6 + [_i, _i, _i, _vp]),
+    'gpode_linear_bwd_scratch': (_sz, [_i, _i, _i]),
+    'gpode_linear_bwd': (_i, [_c_float_p] * 6 + [_i, _i, _i, _c_float_p, _vp]),
     'gpode_loglik_fwd': (_i, [_c_float_p] * 3 + [_sz, _sz, _vp]),
     'gpode_loglik_bwd': (_i, [_c_float_p] * 4 + [_sz, _sz, _vp]),
     'gpode_loglik_rowsum_fwd': (_i, [_c_float_p] * 3 + [_sz, _sz, _sz, _vp]),

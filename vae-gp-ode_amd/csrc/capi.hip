@@ -253,10 +253,11 @@ int gpode_linear_fwd(const float* x, const float* w, const float* bias, float* y
   if (!x || !w || !y) return gp::set_error("gpode_linear_fwd: null pointer");
   return gp::linear_fwd(x, w, bias, y, B, In, Out, GP_ST);
 }
+size_t gpode_linear_bwd_scratch(int B, int In, int Out) { return gp::linear_bwd_scratch(B, In, Out); }
 int gpode_linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out,
-                     void* stream) {
+                     float* scratch, void* stream) {
   if (!x || !w || !gy) return gp::set_error("gpode_linear_bwd: null pointer");
-  return gp::linear_bwd(x, w, gy, gx, gw, gb, B, In, Out, GP_ST);
+  return gp::linear_bwd(x, w, gy, gx, gw, gb, B, In, Out, scratch, GP_ST);
 }
 int gpode_loglik_fwd(const float* X, const float* z, float* ll, size_t n, size_t nX, void* stream) { return gp::loglik_fwd(X, z, ll, n, nX, GP_ST); }
 int gpode_loglik_bwd(const float* X, const float* z, const float* g, float* gz, size_t n, size_t nX, void* stream) {

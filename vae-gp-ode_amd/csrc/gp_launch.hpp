@@ -120,6 +120,7 @@ int dec10_bn_bwd_apply(const float* c, const float* gy, const float* w, const fl
 // (vae_norm.hip); outside such a bracket reduce_job launches at once
 struct RedJob { const float* part; float* out; int nsplit, n, kind, a, b, c; };
 int reduce_job(const RedJob& job, hipStream_t st);
+int reduce_jobs(const RedJob* jobs, int nj, hipStream_t st);
 void defer_reductions(int mode);
 int flush_reductions(hipStream_t st);
 int bn_bwd_sums(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
@@ -133,7 +134,8 @@ int chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, h
 int act_fwd(const float* x, float* y, size_t n, int mode, hipStream_t st);
 int act_bwd(const float* y, const float* gy, float* gx, size_t n, int mode, hipStream_t st);
 int linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, hipStream_t st);
-int linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out, hipStream_t st);
+int linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out, float* scratch, hipStream_t st);
+size_t linear_bwd_scratch(int B, int In, int Out);
 int loglik_fwd(const float* X, const float* z, float* ll, size_t n, size_t nX, hipStream_t st);
 int loglik_bwd(const float* X, const float* z, const float* g, float* gz, size_t n, size_t nX, hipStream_t st);
 int loglik_rowsum_fwd(const float* X, const float* z, float* out, size_t rows, size_t inner, size_t nX, hipStream_t st);

@@ -184,6 +184,39 @@ __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ 
   if (lane == 0) { if (i < In) gw[(size_t)o * In + i] = out1[0]; else if (gb) gb[o] = out1[0]; }
 }
 
+// The same sums for the decoder's fc layer at thousands of rows (q -> 512 on batch x T latent states, vae.py:101): a workgroup owns 64
+// consecutive outputs and a slab of rows -- gy is read in 256-byte rows (one wavefront per (o, i) pair re-read every cache line of gy
+// 16 times through 2 KB strides: 36 us at 4096 rows), x[b][i] is wave-uniform.  partW[slab][o][i], partB[slab][o] are summed in a
+// fixed order by reduce_jobs.  grid (Out / 64, nslab), block 256 = 64 outputs x 4 row groups.
+constexpr int LINW_SLABS = 32;
+__global__ __launch_bounds__(256) void k_linear_bwd_w_cols(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ partW,
+                                                            float* __restrict__ partB, int B, int In, int Out, int rps) {
+  __shared__ float red[4][9][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, o = blockIdx.x * 64 + lane;
+  const int b0 = blockIdx.y * rps, b1 = min(B, b0 + rps);
+  float acc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+#pragma unroll 4
+  for (int b = b0 + g; b < b1; b += 4) {
+    const float gv = gy[(size_t)b * Out + o];
+    const float* xr = x + (size_t)b * In;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < In) acc[i] = fmaf(gv, xr[i], acc[i]);
+    acc[8] += gv;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) red[g][i][lane] = acc[i];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 9 * 64; e += 256) {
+    const int i = e >> 6, l = e & 63, oo = blockIdx.x * 64 + l;
+    const float v = (red[0][i][l] + red[1][i][l]) + (red[2][i][l] + red[3][i][l]);
+    if (i < In) partW[((size_t)blockIdx.y * Out + oo) * In + i] = v;
+    else if (i == 8) partB[(size_t)blockIdx.y * Out + oo] = v;
+  }
+}
+
 // ---- wide fan-in, few outputs (the encoder's fc layer, 512 -> 2q on the minibatch, vae.py:62): one wavefront per output
 //      element, lanes along the reduction
 __global__ __launch_bounds__(256) void k_linear_fwd_fanin(const float* __restrict__ x, const float* __restrict__ w,
@@ -400,7 +433,10 @@ int linear_fwd(const float* x, const float* w, const float* bias, float* y, int 
   hipLaunchKernelGGL(k_linear_fwd, (unsigned)(((size_t)B * Out + 255) / 256), 256, 0, st, x, w, bias, y, B, In, Out);
   return check_launch("linear_fwd");
 }
-int linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out, hipStream_t st) {
+size_t linear_bwd_scratch(int B, int In, int Out) { (void)B; return (size_t)LINW_SLABS * Out * (In + 1); }
+
+int linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out, float* scratch,
+               hipStream_t st) {
   if (In <= LIN_MAXIN && Out % 64 == 0 && Out <= 512 && B >= 256) {
     const int nb = B / 4 < 256 ? (B + 3) / 4 : 256;
     if (gx) {
@@ -410,7 +446,18 @@ int linear_bwd(const float* x, const float* w, const float* gy, float* gx, float
 #undef X
       }
     }
-    if (gw) hipLaunchKernelGGL(k_linear_bwd_w, (unsigned)(((size_t)Out * (In + 1) * 64 + 255) / 256), 256, 0, st, x, gy, gw, gb, B, In, Out);
+    if (gw) {
+      if (scratch && In <= 8 && B >= 1024) {
+        const int rps = (B + LINW_SLABS - 1) / LINW_SLABS, used = (B + rps - 1) / rps;
+        float* partW = scratch;
+        float* partB = scratch + (size_t)LINW_SLABS * Out * In;
+        hipLaunchKernelGGL(k_linear_bwd_w_cols, dim3(Out / 64, used), 256, 0, st, x, gy, partW, partB, B, In, Out, rps);
+        const RedJob jobs[2] = {RedJob{partW, gw, used, Out * In, 0, 0, 0, 0}, RedJob{partB, gb, used, Out, 0, 0, 0, 0}};
+        if (reduce_jobs(jobs, gb ? 2 : 1, st)) return 1;
+      } else {
+        hipLaunchKernelGGL(k_linear_bwd_w, (unsigned)(((size_t)Out * (In + 1) * 64 + 255) / 256), 256, 0, st, x, gy, gw, gb, B, In, Out);
+      }
+    }
     return check_launch("linear_bwd_fanout");
   }
   if (gx) hipLaunchKernelGGL(k_linear_bwd_x, (unsigned)(((size_t)B * In + 255) / 256), 256, 0, st, gy, w, gx, B, In, Out);

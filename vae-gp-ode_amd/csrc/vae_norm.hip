@@ -531,6 +531,19 @@ int launch_red(const RedJob* jobs, int nj, hipStream_t st) {
 }
 }  // namespace
 
+// several jobs of one producer in one launch, never deferred apart
+int reduce_jobs(const RedJob* jobs, int nj, hipStream_t st) {
+  if (nj < 1 || nj > kMaxRedJobs) return set_error("reduce_jobs: 1 .. %d jobs", kMaxRedJobs);
+  {
+    std::lock_guard<std::mutex> lk(g_red_mu);
+    if (g_red_defer > 0 && g_red_n + nj <= kMaxRedJobs) {
+      for (int i = 0; i < nj; ++i) g_red_jobs[g_red_n++] = jobs[i];
+      return 0;
+    }
+  }
+  return launch_red(jobs, nj, st);
+}
+
 int reduce_job(const RedJob& job, hipStream_t st) {
   if (job.n <= 0 || job.nsplit <= 0) return set_error("reduce_job: empty job");
   {

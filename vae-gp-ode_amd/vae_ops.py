@@ -384,7 +384,9 @@ class _Linear(torch.autograd.Function):
         gx = _new(x.shape, x) if ctx.needs_input_grad[0] else None
         gw = _new(w.shape, x) if ctx.needs_input_grad[1] else None
         gb = _new((Out,), x) if (ctx.has_b and gw is not None) else None
-        _lib.call('gpode_linear_bwd', _ptr(x), _ptr(w), _ptr(gy.contiguous()), _ptr(gx), _ptr(gw), _ptr(gb), B, In, Out, _stream())
+        ws = _scratch(_lib.load().gpode_linear_bwd_scratch(B, In, Out), x) if (gw is not None and B >= 1024 and In <= 8) else None
+        _bwd_call('gpode_linear_bwd', _ptr(x), _ptr(w), _ptr(gy.contiguous()), _ptr(gx), _ptr(gw), _ptr(gb), B, In, Out, _ptr(ws), _stream(),
+                  keep=(ws,) if ws is not None else ())
         return gx, gw, gb
 
 
