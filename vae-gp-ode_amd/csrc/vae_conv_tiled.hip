@@ -24,6 +24,7 @@
 #include "conv_mfma.hpp"
 #include "conv_dec10_mfma.hpp"
 #include "conv_dec1_mfma.hpp"
+#include "conv_dec4_mfma.hpp"
 
 namespace gp {
 
@@ -491,7 +492,20 @@ int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx
                    int P, int Ho, int Wo, const float* in_bn, hipStream_t st) {
   if (H != W || Ho != Wo) return -1;
   if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec7, 3, 2, 16>(gy, w, bias, gx, B, st, in_bn);
-  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec4, 3, 2, 16>(gy, w, bias, gx, B, st, in_bn);
+  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) {
+    // taps-as-columns form (conv_dec4_mfma.hpp): 48.5 vs 59.7 us for the stage at 512 images (no weight slabs to stage before the first
+    // image), 276 vs 267 us at 4096 -- so it takes the small batches (configs[0]: 512 images); GPODE_DEC4_TAPCOLS=0 / 1 forces one
+    static const int tapcols = [] { const char* e = getenv("GPODE_DEC4_TAPCOLS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    if ((tapcols == 1 || (tapcols < 0 && B <= 4 * num_cus())) && use_mfma()) {
+      const size_t lds = sizeof(float) * (dec4::NPI * dec4::TLD + 4 * dec4::CI);
+      if (set_max_lds((const void*)dec4::k_fwd<true>, lds) || set_max_lds((const void*)dec4::k_fwd<false>, lds)) return 1;
+      const int nwg = B < num_cus() ? B : num_cus();
+      if (in_bn) hipLaunchKernelGGL(dec4::k_fwd<true>, nwg, 512, lds, st, gy, w, bias, gx, B, in_bn);
+      else hipLaunchKernelGGL(dec4::k_fwd<false>, nwg, 512, lds, st, gy, w, bias, gx, B, in_bn);
+      return check_launch("dec4_fwd_tapcols");
+    }
+    return launch_T1<Dec4, 3, 2, 16>(gy, w, bias, gx, B, st, in_bn);
+  }
   if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) {
     static const bool old = [] { const char* e = getenv("GPODE_DEC1_ENGINE"); return e && e[0] == '1'; }();
     if (!in_bn && use_mfma() && !old) {              // taps folded into the GEMM's columns, weights resident in registers
