@@ -349,3 +349,32 @@ def test_training_trajectory_matches_the_oracle_over_several_steps():
         worst = max(worst, err / tol)
         assert err < tol, (k, err, tol)
     print('worst err/tol over parameters after 4 steps: %.2f' % worst)
+
+
+def test_single_process_graph_runs_repeat_exactly(tmp_path):
+    """Two identical single-process runs of main.py with --hip_graph (side-stream overlap, device noise) and one eager run: the
+    logged loss sequences (12 iterations, ragged last batch, L 1 -> 5) must be the same to the printed digit -- run-to-run
+    differences are how a race between the side stream and the main stream shows (profiles/r02b_notes.txt)."""
+    import glob
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+
+    def run(tag, extra):
+        cmd = [sys.executable, '-m', 'vae_gp_ode_amd.main', '--task', 'synthetic', '--Ndata', '10', '--Ntest', '4', '--batch', '4', '--T', '6',
+               '--solver', 'rk4', '--num_inducing', '16', '--num_features', '32', '--lr', '1e-3', '--log_freq', '1', '--Nepoch', '4',
+               '--kernel', 'DF', '--save', 'results/' + tag] + extra
+        r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        log = glob.glob(str(tmp_path / 'results' / (tag + '_*') / 'logs'))
+        assert len(log) == 1
+        return [m.group(1) for m in re.finditer(r'elbo\s+(-?[\d.]+)\(', open(log[0]).read())]
+    g1 = run('g1', ['--hip_graph', 'True'])
+    g2 = run('g2', ['--hip_graph', 'True'])
+    e = run('e', ['--device_noise', 'True'])
+    assert len(g1) == 12 and g1 == g2, (g1, g2)
+    worst = max(abs(float(a) - float(b)) / max(abs(float(b)), 1.0) for a, b in zip(g1, e))
+    assert worst < 2e-5, (g1, e)
