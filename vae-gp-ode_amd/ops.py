@@ -244,7 +244,7 @@ def rhs_vjp(cache, x, a):
     return gx
 
 
-_PGRAD_CHUNKS = int(os.environ.get('GPODE_PGRAD_CHUNKS', '256'))
+_PGRAD_CHUNKS = int(os.environ.get('GPODE_PGRAD_CHUNKS', '0'))     # 0: by the number of rows (below)
 
 
 def param_grad(cache, x, a, gpack=None, nchunk=None, keep=None):
@@ -253,7 +253,11 @@ def param_grad(cache, x, a, gpack=None, nchunk=None, keep=None):
     stream has been joined (the caching allocator only knows the stream the block was allocated on)."""
     x = _chk(x, 'x'); a = _chk(a, 'a')
     R = x.shape[0]
-    nchunk = max(1, min(_PGRAD_CHUNKS if nchunk is None else nchunk, R))
+    if nchunk is None:
+        # one workgroup per chunk of rows, every chunk a full pack-sized slab for the reduction to read: ~32 rows per chunk, between
+        # 64 and 256 chunks (configs[0], 1920 rows: 64 chunks 0.855 ms / 256 chunks 0.867 ms per step; configs[1], 15360 rows: 256)
+        nchunk = _PGRAD_CHUNKS if _PGRAD_CHUNKS > 0 else min(256, max(64, R // 32))
+    nchunk = max(1, min(nchunk, R))
     pf = cache.pack.numel()
     slab = torch.empty(nchunk * pf, dtype=torch.float32, device=x.device)
     acc = 1 if gpack is not None else 0
