@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512) void k_bwd_data(const float* __restrict__ gy, 
 //   MODE 1  gc = gamma invstd (g - mean(g) - xhat mean(g xhat)),  part_gx[wg][c] = sum gc   (reads c, gy; writes gc)
 // Same tile loop as k_bwd_data; c is fetched NT tiles ahead (4 NT loads in flight per lane).  2 workgroups per CU.
 // ---------------------------------------------------------------------------------------------
-constexpr int BN_NT = 4;
+constexpr int BN_NT = 8;
 
 // sA[c], sB[c] <- sums over the workgroups' partials part[wg][c][0..1], identical in every workgroup (fixed order)
 __device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int nsplit, float* sA, float* sB) {
@@ -211,30 +211,27 @@ __global__ __launch_bounds__(512, 4) void k_bwd_data_bn(const float* __restrict_
                                                         const float* __restrict__ wts, int W, float* __restrict__ ggamma,
                                                         float* __restrict__ gbeta, float* __restrict__ gx, float* __restrict__ part_gx) {
   float* s_g = igemm_smem;                           // [IPB][32][32], index = o + 2, zero borders
-  float* s_red = s_g + IPB * PLANE;                  // [8][CI][2]
-  float* s_A = s_red + 8 * CI * 2;                   // [CI] sum g  (MODE 1)
+  float* s_red = s_g + IPB * PLANE;                  // [8][4][CI][2]
+  float* s_A = s_red + 8 * 4 * CI * 2;               // [CI] sum g  (MODE 1)
   float* s_B = s_A + CI;                             // [CI] sum g xhat
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
   constexpr int NKS = (KK + 3) / 4;
   constexpr int NLD = (IPB * NP / 4 + 511) / 512;
   for (int e = tid; e < IPB * PLANE; e += 512) s_g[e] = 0.f;
-  float wa[NKS];
+  // The tile product is taken transposed with respect to k_bwd_data -- D[m = pixel][n = ci] = sum_tap G[pixel][tap] w[ci][tap] --
+  // with the SAME operand registers swapped (A[m = lr][k = lk] and B[k = lk][n = lr] index a lane alike): a lane then holds 4
+  // consecutive pixels of ONE channel, so c and gc move as 16-byte accesses and the channel's constants are 7 registers, not 28.
+  float wb[NKS];                                     // B[k = tap][n = ci = lr]
   int toff[NKS];
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
     const int tap = 4 * ks + lk;
-    wa[ks] = tap < KK ? w[(size_t)lr * KK + tap] : 0.f;
+    wb[ks] = tap < KK ? w[(size_t)lr * KK + tap] : 0.f;
     toff[ks] = tap < KK ? (tap / 5) * WP + tap % 5 : 0;
   }
-  // the lane's channels 4 lk + r
-  float cm[4], cis[4], cg[4], cb[4], ca_[4], cb_[4], sc[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int c = 4 * lk + r;
-    cm[r] = mean[c]; cis[r] = invstd[c]; cg[r] = gamma[c]; cb[r] = beta[c];
-    ca_[r] = 0.f; cb_[r] = 0.f; sc[r] = cg[r] * cis[r];
-  }
+  const float cm = mean[lr], cis = invstd[lr], cg = gamma[lr], cbt = beta[lr], sc = cg * cis;
+  float ca = 0.f, cb = 0.f;
   if (MODE == 1) {
     reduce_parts(part, nsplit, s_A, s_B);
     __syncthreads();
@@ -249,10 +246,10 @@ __global__ __launch_bounds__(512, 4) void k_bwd_data_bn(const float* __restrict_
       __syncthreads();
     }
     const float ic = 1.f / count;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { ca_[r] = s_A[4 * lk + r] * ic; cb_[r] = s_B[4 * lk + r] * ic; }
+    ca = s_A[lr] * ic;
+    cb = s_B[lr] * ic;
   }
-  float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+  float a0 = 0.f, a1 = 0.f;
   const int ngroups = (B + IPB - 1) / IPB;
   float4 pre[NLD];
   auto prefetch = [&](int grp) {
@@ -284,59 +281,54 @@ __global__ __launch_bounds__(512, 4) void k_bwd_data_bn(const float* __restrict_
     if (grp + (int)gridDim.x < ngroups) prefetch(grp + gridDim.x);
     const int ntiles = nimg * NTILE;
     for (int t0 = wave; t0 < ntiles; t0 += 8 * BN_NT) {
-      float xv[BN_NT][4];
+      float4 xv[BN_NT];
 #pragma unroll
       for (int u = 0; u < BN_NT; ++u) {
         const int t = t0 + 8 * u;
         if (t < ntiles) {                            // wave-uniform
-          const int im = t / NTILE, p = (t % NTILE) * 16 + lr;
-          const float* xp = x + ((size_t)(b0 + im) * CI + 4 * lk) * NP + p;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) xv[u][r] = xp[(size_t)r * NP];
+          const int im = t / NTILE, p0 = (t % NTILE) * 16 + 4 * lk;
+          xv[u] = *reinterpret_cast<const float4*>(x + ((size_t)(b0 + im) * CI + lr) * NP + p0);
         }
       }
 #pragma unroll
       for (int u = 0; u < BN_NT; ++u) {
         const int t = t0 + 8 * u;
         if (t < ntiles) {
-          const int im = t / NTILE, p = (t % NTILE) * 16 + lr;
-          const float* gp = s_g + im * PLANE + (p / H) * WP + p % H;
-          float bf[NKS];
-#pragma unroll
-          for (int ks = 0; ks < NKS; ++ks) bf[ks] = gp[toff[ks]];
+          const int im = t / NTILE, pa = (t % NTILE) * 16 + lr;       // A: the window of pixel lr of the tile
+          const float* gp = s_g + im * PLANE + (pa / H) * WP + pa % H;
           f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ks], bf[ks], acc, 0, 0, 0);
-          float* op = gx + ((size_t)(b0 + im) * CI + 4 * lk) * NP + p;
+          for (int ks = 0; ks < NKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gp[toff[ks]], wb[ks], acc, 0, 0, 0);
+          // D[m = pixel 4 lk + r of the tile][n = ci = lr]
+          const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+          float o[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float xh = bn_xhat(xv[u][r], cm[r], cis[r]);
-            const float g = (__fmaf_rn(xh, cg[r], cb[r]) > 0.f) ? acc[r] : 0.f;
+            const float xh = bn_xhat(xs[r], cm, cis);
+            const float g = (__fmaf_rn(xh, cg, cbt) > 0.f) ? acc[r] : 0.f;
             if (MODE == 0) {
-              a0[r] += g;
-              a1[r] = fmaf(g, xh, a1[r]);
+              a0 += g;
+              a1 = fmaf(g, xh, a1);
             } else {
-              const float o = sc[r] * (g - ca_[r] - xh * cb_[r]);
-              op[(size_t)r * NP] = o;
-              a0[r] += o;
+              o[r] = sc * (g - ca - xh * cb);
+              a0 += o[r];
             }
           }
+          if (MODE == 1)
+            *reinterpret_cast<float4*>(gx + ((size_t)(b0 + im) * CI + lr) * NP + (t % NTILE) * 16 + 4 * lk) = float4{o[0], o[1], o[2], o[3]};
         }
       }
     }
   }
-  // the lane's 16-lane row shares its channels: row sums, then the 8 wavefronts in a fixed order
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float r0 = row_allreduce16(a0[r]), r1 = row_allreduce16(a1[r]);
-    if (lr == 0) { s_red[(wave * CI + 4 * lk + r) * 2] = r0; s_red[(wave * CI + 4 * lk + r) * 2 + 1] = r1; }
-  }
+  // channel lr of this lane: the four row groups and the 8 wavefronts in a fixed order
+  s_red[((wave * 4 + lk) * CI + lr) * 2] = a0;
+  s_red[((wave * 4 + lk) * CI + lr) * 2 + 1] = a1;
   __syncthreads();
   float* outp = MODE == 0 ? part : part_gx;
   if (tid < 2 * CI && outp) {
     float v = 0.f;
 #pragma unroll
-    for (int wv = 0; wv < 8; ++wv) v += s_red[wv * CI * 2 + tid];
+    for (int q = 0; q < 32; ++q) v += s_red[q * CI * 2 + tid];
     outp[(size_t)blockIdx.x * CI * 2 + tid] = v;
   }
 }

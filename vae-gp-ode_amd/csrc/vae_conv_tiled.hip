@@ -597,7 +597,7 @@ __global__ __launch_bounds__(512) void k_dec10_parts_reduce(const float* __restr
 
 template <int IPB, int MODE, typename... A>
 static int launch_dec10_bn(int B, hipStream_t st, A... args) {
-  const size_t lds = sizeof(float) * ((size_t)IPB * dec10::PLANE + 8 * dec10::CI * 2 + 2 * dec10::CI);
+  const size_t lds = sizeof(float) * ((size_t)IPB * dec10::PLANE + 8 * 4 * dec10::CI * 2 + 2 * dec10::CI);
   auto kern = dec10::k_bwd_data_bn<IPB, MODE>;
   if (set_max_lds((const void*)kern, lds)) return 1;
   const int ngroups = (B + IPB - 1) / IPB, cap = 2 * num_cus() < kDec10BnMaxWg ? 2 * num_cus() : kDec10BnMaxWg;
