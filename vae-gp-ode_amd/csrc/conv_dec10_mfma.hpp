@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512) void k_bwd_data(const float* __restrict__ gy, 
 //   MODE 1  gc = gamma invstd (g - mean(g) - xhat mean(g xhat)),  part_gx[wg][c] = sum gc   (reads c, gy; writes gc)
 // Same tile loop as k_bwd_data; c is fetched NT tiles ahead (4 NT loads in flight per lane).  2 workgroups per CU.
 // ---------------------------------------------------------------------------------------------
-constexpr int BN_NT = 8;
+constexpr int BN_NT = 4;                           // (8 measured: no change -- the passes are not latency-bound)
 
 // sA[c], sB[c] <- sums over the workgroups' partials part[wg][c][0..1], identical in every workgroup (fixed order)
 __device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int nsplit, float* sA, float* sB) {
