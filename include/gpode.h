@@ -100,6 +100,43 @@ int gpode_cache_build_bwd(int kernel, int Di, int Do, int M, int S,
  * after gpode_cache_build_fwd -- e.g. on a side stream while the decoder runs -- and pass prepared = 1 with the same bws. */
 int gpode_cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, const float* ws, float* bws, void* stream);
 
+/* ---- Monte-Carlo draws batched into one call ------------------------------------------------------------------------------
+ * ODEGPVAE.sample_trajectories (odegpvae.py:37-45) loops `for l in range(L)` over whole flow calls -- L cache builds, L solver
+ * loops, L autograd graphs -- and the training loop runs half of all epochs at L = 5 (main.py:200).  K_uu + jitter I and its
+ * Cholesky factor depend on the parameters only (kernels.py:163 / :384), so the `_n` forms below build ONE factor for all
+ * `ndraws` function draws (their right-hand sides f_prior_l(Z) are solved as a block), integrate the L * N trajectories in ONE
+ * launch (the launch's second grid dimension is the draw: its own pack, the shared initial states) and run ONE Cholesky
+ * backward on the summed adjoint (that VJP is linear).  Layouts: every per-draw operand gains a LEADING draw axis --
+ *   eps_u (L,M,Do), rff_w (L,S|2S,Do), rff_eps (L,Di,S,Do), rff_u (L,1,S,Do); pack (L, pack_floats); omega / phase / u / nu /
+ *   u_prior (L, ...); zt (L,N,T,D), xstage (L,N,T-1,NS,D), gzt, gz0 (L,N,D), astage; x / a of gpode_param_grad_n (L,R,.),
+ *   slab (L, nchunk, pack_floats), gpack (L, pack_floats) --
+ * while z0 (N,D), ts, the raw parameters, ell, var, Lu and the factor inside `ws` are shared.  gpode_cache_build_bwd_n returns the
+ * parameter gradients SUMMED over the draws (what autograd accumulates over the reference's loop).  ws / bws sizes depend on
+ * ndraws (gpode_cache_sizes_n, gpode_cache_bwd_sizes_n); pack_floats does not.  ndraws = 1 is the un-suffixed entry point. */
+int gpode_cache_sizes_n(int kernel, int Di, int Do, int M, int S, int ndraws, size_t* pack_floats, size_t* ws_floats);
+int gpode_cache_build_fwd_n(int kernel, int Di, int Do, int M, int S, int ndraws,
+                            const float* raw_ell, const float* raw_var, const float* Z,
+                            const float* Um, const float* Us_packed,
+                            const float* eps_u, const float* rff_w, const float* rff_eps, const float* rff_u,
+                            float* pack, float* ws,
+                            float* ell, float* var, float* omega, float* phase, float* u,
+                            float* Lu, float* nu, float* u_prior, void* stream);
+int gpode_rollout_fwd_n(int kernel, int order, int method, int Di, int Do, int M, int S, int ndraws,
+                        const float* pack, const float* z0, const float* ts, int N, int T,
+                        float* zt, float* xstage, void* stream);
+int gpode_rollout_bwd_n(int kernel, int order, int method, int Di, int Do, int M, int S, int ndraws,
+                        const float* pack, const float* xstage, const float* gzt, const float* ts, int N, int T,
+                        float* gz0, float* astage, void* stream);
+int gpode_param_grad_n(int kernel, int Di, int Do, int M, int S, int ndraws, const float* pack,
+                       const float* x, const float* a, int R, float* slab, int nchunk, float* gpack, int accumulate,
+                       void* stream);
+int gpode_cache_bwd_sizes_n(int kernel, int Di, int Do, int M, int S, int ndraws, size_t* bws_floats);
+int gpode_cache_build_bwd_n(int kernel, int Di, int Do, int M, int S, int ndraws,
+                            const float* raw_ell, const float* raw_var, const float* Z, const float* eps_u,
+                            const float* pack, const float* ws, float* gpack, float* bws,
+                            float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, int prepared, void* stream);
+int gpode_cache_bwd_prepare_n(int kernel, int Di, int Do, int M, int S, int ndraws, const float* ws, float* bws, void* stream);
+
 /* Factorisation status of the last gpode_cache_build_fwd on `ws` (bit 0: K_uu + jitter I not positive
  * definite -- torch.linalg.cholesky raises there, kernels.py:163/:384).  Copies one int to the host and
  * synchronises `stream`. */

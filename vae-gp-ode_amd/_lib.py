@@ -37,6 +37,15 @@ SIGNATURES = {
     'gpode_rollout_bwd': (_i, [_i] * 7 + [_c_float_p] * 4 + [_i, _i, _c_float_p, _c_float_p, ctypes.c_void_p]),
     'gpode_rhs_vjp': (_i, [_i] * 5 + [_c_float_p, _c_float_p, _c_float_p, _i, _c_float_p, ctypes.c_void_p]),
     'gpode_param_grad': (_i, [_i] * 5 + [_c_float_p, _c_float_p, _c_float_p, _i, _c_float_p, _i, _c_float_p, _i, ctypes.c_void_p]),
+    # Monte-Carlo draws batched into one call (a leading draw axis on every per-draw operand; `ndraws` follows S)
+    'gpode_cache_sizes_n': (_i, [_i] * 6 + [_sz_p, _sz_p]),
+    'gpode_cache_build_fwd_n': (_i, [_i] * 6 + [_c_float_p] * 20),
+    'gpode_rollout_fwd_n': (_i, [_i] * 8 + [_c_float_p, _c_float_p, _c_float_p, _i, _i, _c_float_p, _c_float_p, ctypes.c_void_p]),
+    'gpode_rollout_bwd_n': (_i, [_i] * 8 + [_c_float_p] * 4 + [_i, _i, _c_float_p, _c_float_p, ctypes.c_void_p]),
+    'gpode_param_grad_n': (_i, [_i] * 6 + [_c_float_p, _c_float_p, _c_float_p, _i, _c_float_p, _i, _c_float_p, _i, ctypes.c_void_p]),
+    'gpode_cache_bwd_sizes_n': (_i, [_i] * 6 + [_sz_p]),
+    'gpode_cache_build_bwd_n': (_i, [_i] * 6 + [_c_float_p] * 13 + [_i, ctypes.c_void_p]),
+    'gpode_cache_bwd_prepare_n': (_i, [_i] * 6 + [_c_float_p] * 2 + [ctypes.c_void_p]),
 }
 
 _sz = ctypes.c_size_t

@@ -16,9 +16,24 @@ const char* gpode_last_error(void) { return gp::error_slot(); }
 int gpode_supported(int kernel, int Di, int Do) { return gp::dims_supported(kernel, Di, Do); }
 
 int gpode_cache_sizes(int kernel, int Di, int Do, int M, int S, size_t* pack_floats, size_t* ws_floats) {
-  return gp::cache_sizes(kernel, Di, Do, M, S, pack_floats, ws_floats);
+  return gp::cache_sizes(kernel, Di, Do, M, S, pack_floats, ws_floats, 1);
+}
+int gpode_cache_sizes_n(int kernel, int Di, int Do, int M, int S, int ndraws, size_t* pack_floats, size_t* ws_floats) {
+  return gp::cache_sizes(kernel, Di, Do, M, S, pack_floats, ws_floats, ndraws);
 }
 
+int gpode_cache_build_fwd_n(int kernel, int Di, int Do, int M, int S, int ndraws,
+                            const float* raw_ell, const float* raw_var, const float* Z,
+                            const float* Um, const float* Us_packed,
+                            const float* eps_u, const float* rff_w, const float* rff_eps, const float* rff_u,
+                            float* pack, float* ws,
+                            float* ell, float* var, float* omega, float* phase, float* u,
+                            float* Lu, float* nu, float* u_prior, void* stream) {
+  if (!raw_ell || !raw_var || !Z || !Um || !Us_packed || !eps_u || !rff_w || !rff_eps || !rff_u || !pack || !ws)
+    return gp::set_error("gpode_cache_build_fwd: null required pointer");
+  return gp::cache_build_fwd(kernel, Di, Do, M, S, ndraws, raw_ell, raw_var, Z, Um, Us_packed, eps_u, rff_w, rff_eps, rff_u,
+                             pack, ws, ell, var, omega, phase, u, Lu, nu, u_prior, (hipStream_t)stream);
+}
 int gpode_cache_build_fwd(int kernel, int Di, int Do, int M, int S,
                           const float* raw_ell, const float* raw_var, const float* Z,
                           const float* Um, const float* Us_packed,
@@ -26,10 +41,8 @@ int gpode_cache_build_fwd(int kernel, int Di, int Do, int M, int S,
                           float* pack, float* ws,
                           float* ell, float* var, float* omega, float* phase, float* u,
                           float* Lu, float* nu, float* u_prior, void* stream) {
-  if (!raw_ell || !raw_var || !Z || !Um || !Us_packed || !eps_u || !rff_w || !rff_eps || !rff_u || !pack || !ws)
-    return gp::set_error("gpode_cache_build_fwd: null required pointer");
-  return gp::cache_build_fwd(kernel, Di, Do, M, S, raw_ell, raw_var, Z, Um, Us_packed, eps_u, rff_w, rff_eps, rff_u,
-                             pack, ws, ell, var, omega, phase, u, Lu, nu, u_prior, (hipStream_t)stream);
+  return gpode_cache_build_fwd_n(kernel, Di, Do, M, S, 1, raw_ell, raw_var, Z, Um, Us_packed, eps_u, rff_w, rff_eps, rff_u, pack, ws, ell, var,
+                                 omega, phase, u, Lu, nu, u_prior, stream);
 }
 
 int gpode_cache_info(const float* ws, int* host_info, void* stream) {
@@ -63,22 +76,46 @@ int gpode_rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack,
   return gp::rhs_fwd(kernel, Di, Do, M, S, pack, x, N, f, mode, (hipStream_t)stream);
 }
 
+static gp::Draws draws_of(int nd, size_t pack, size_t in, size_t out, size_t in2, size_t out2) {
+  gp::Draws d;
+  d.nd = nd; d.pack = pack; d.in = in; d.out = out; d.in2 = in2; d.out2 = out2;
+  return d;
+}
+static int stage_count(int method) { return method == 0 ? 1 : (method == 1 ? 4 : 2); }
+
+int gpode_rollout_fwd_n(int kernel, int order, int method, int Di, int Do, int M, int S, int ndraws,
+                        const float* pack, const float* z0, const float* ts, int N, int T,
+                        float* zt, float* xstage, void* stream) {
+  if (N < 0 || T < 1 || ndraws < 1 || ndraws > 65535) return gp::set_error("gpode_rollout_fwd: N=%d T=%d draws=%d", N, T, ndraws);
+  if (N == 0) return 0;
+  if (!pack || !z0 || !ts || !zt) return gp::set_error("gpode_rollout_fwd: null pointer");
+  size_t pf = 0;
+  if (gp::cache_sizes(kernel, Di, Do, M, S, &pf, nullptr)) return 1;
+  return gp::rollout_fwd(kernel, order, method, Di, Do, M, S, pack, z0, ts, N, T, zt, xstage, (hipStream_t)stream,
+                         draws_of(ndraws, pf, 0, (size_t)N * T * Di, 0, (size_t)N * (T - 1) * stage_count(method) * Di));
+}
 int gpode_rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, int S,
                       const float* pack, const float* z0, const float* ts, int N, int T,
                       float* zt, float* xstage, void* stream) {
-  if (N < 0 || T < 1) return gp::set_error("gpode_rollout_fwd: N=%d T=%d", N, T);
-  if (N == 0) return 0;
-  if (!pack || !z0 || !ts || !zt) return gp::set_error("gpode_rollout_fwd: null pointer");
-  return gp::rollout_fwd(kernel, order, method, Di, Do, M, S, pack, z0, ts, N, T, zt, xstage, (hipStream_t)stream);
+  return gpode_rollout_fwd_n(kernel, order, method, Di, Do, M, S, 1, pack, z0, ts, N, T, zt, xstage, stream);
 }
 
+int gpode_rollout_bwd_n(int kernel, int order, int method, int Di, int Do, int M, int S, int ndraws,
+                        const float* pack, const float* xstage, const float* gzt, const float* ts, int N, int T,
+                        float* gz0, float* astage, void* stream) {
+  if (N < 0 || T < 1 || ndraws < 1 || ndraws > 65535) return gp::set_error("gpode_rollout_bwd: N=%d T=%d draws=%d", N, T, ndraws);
+  if (N == 0) return 0;
+  if (!pack || !gzt || !ts || !gz0 || (T > 1 && (!xstage || !astage))) return gp::set_error("gpode_rollout_bwd: null pointer");
+  size_t pf = 0;
+  if (gp::cache_sizes(kernel, Di, Do, M, S, &pf, nullptr)) return 1;
+  const size_t rows = (size_t)N * (T - 1) * stage_count(method);
+  return gp::rollout_bwd(kernel, order, method, Di, Do, M, S, pack, xstage, gzt, ts, N, T, gz0, astage, (hipStream_t)stream,
+                         draws_of(ndraws, pf, rows * Di, (size_t)N * Di, (size_t)N * T * Di, rows * Do));
+}
 int gpode_rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S,
                       const float* pack, const float* xstage, const float* gzt, const float* ts, int N, int T,
                       float* gz0, float* astage, void* stream) {
-  if (N < 0 || T < 1) return gp::set_error("gpode_rollout_bwd: N=%d T=%d", N, T);
-  if (N == 0) return 0;
-  if (!pack || !gzt || !ts || !gz0 || (T > 1 && (!xstage || !astage))) return gp::set_error("gpode_rollout_bwd: null pointer");
-  return gp::rollout_bwd(kernel, order, method, Di, Do, M, S, pack, xstage, gzt, ts, N, T, gz0, astage, (hipStream_t)stream);
+  return gpode_rollout_bwd_n(kernel, order, method, Di, Do, M, S, 1, pack, xstage, gzt, ts, N, T, gz0, astage, stream);
 }
 
 int gpode_rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack,
@@ -87,11 +124,20 @@ int gpode_rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack,
   return gp::rhs_vjp(kernel, Di, Do, M, S, pack, x, a, R, gx, 0, (hipStream_t)stream);
 }
 
+int gpode_param_grad_n(int kernel, int Di, int Do, int M, int S, int ndraws, const float* pack,
+                       const float* x, const float* a, int R, float* slab, int nchunk, float* gpack, int accumulate,
+                       void* stream) {
+  if (!pack || !x || !a || !slab || !gpack) return gp::set_error("gpode_param_grad: null pointer");
+  if (ndraws < 1 || ndraws > 65535) return gp::set_error("gpode_param_grad: %d draws", ndraws);
+  size_t pf = 0;
+  if (gp::cache_sizes(kernel, Di, Do, M, S, &pf, nullptr)) return 1;
+  return gp::param_grad(kernel, Di, Do, M, S, pack, x, a, R, slab, nchunk, gpack, accumulate, 0, (hipStream_t)stream,
+                        draws_of(ndraws, pf, (size_t)R * Di, pf, (size_t)R * Do, 0));
+}
 int gpode_param_grad(int kernel, int Di, int Do, int M, int S, const float* pack,
                      const float* x, const float* a, int R, float* slab, int nchunk, float* gpack, int accumulate,
                      void* stream) {
-  if (!pack || !x || !a || !slab || !gpack) return gp::set_error("gpode_param_grad: null pointer");
-  return gp::param_grad(kernel, Di, Do, M, S, pack, x, a, R, slab, nchunk, gpack, accumulate, 0, (hipStream_t)stream);
+  return gpode_param_grad_n(kernel, Di, Do, M, S, 1, pack, x, a, R, slab, nchunk, gpack, accumulate, stream);
 }
 
 int gpode_kernel_matrix(int kernel, int Di, int Do, const float* raw_ell, const float* raw_var,
@@ -122,23 +168,39 @@ int gpode_svgp_kl_bwd(int M, int Do, const float* Um, const float* Us_packed, co
   return gp::svgp_kl_bwd(M, Do, Um, Us_packed, g, dUm, dUs, (hipStream_t)stream);
 }
 
-int gpode_cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, size_t* bws_floats) {
+int gpode_cache_bwd_sizes_n(int kernel, int Di, int Do, int M, int S, int ndraws, size_t* bws_floats) {
   if (!bws_floats) return gp::set_error("gpode_cache_bwd_sizes: null pointer");
-  return gp::cache_bwd_sizes(kernel, Di, Do, M, S, bws_floats);
+  if (ndraws < 1) return gp::set_error("gpode_cache_bwd_sizes: %d draws", ndraws);
+  return gp::cache_bwd_sizes(kernel, Di, Do, M, S, ndraws, bws_floats);
+}
+int gpode_cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, size_t* bws_floats) {
+  return gpode_cache_bwd_sizes_n(kernel, Di, Do, M, S, 1, bws_floats);
 }
 
+int gpode_cache_build_bwd_n(int kernel, int Di, int Do, int M, int S, int ndraws,
+                            const float* raw_ell, const float* raw_var, const float* Z, const float* eps_u,
+                            const float* pack, const float* ws, float* gpack, float* bws,
+                            float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, int prepared, void* stream) {
+  if (!raw_ell || !raw_var || !Z || !eps_u || !pack || !ws || !gpack || !bws || !g_raw_ell || !g_raw_var || !g_Z || !g_Um || !g_Us)
+    return gp::set_error("gpode_cache_build_bwd: null pointer");
+  if (ndraws < 1 || ndraws > 65535) return gp::set_error("gpode_cache_build_bwd: %d draws", ndraws);
+  return gp::cache_build_bwd(kernel, Di, Do, M, S, ndraws, raw_ell, raw_var, Z, eps_u, pack, ws, gpack, bws,
+                             g_raw_ell, g_raw_var, g_Z, g_Um, g_Us, prepared, (hipStream_t)stream);
+}
 int gpode_cache_build_bwd(int kernel, int Di, int Do, int M, int S,
                           const float* raw_ell, const float* raw_var, const float* Z, const float* eps_u,
                           const float* pack, const float* ws, float* gpack, float* bws,
                           float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, int prepared, void* stream) {
-  if (!raw_ell || !raw_var || !Z || !eps_u || !pack || !ws || !gpack || !bws || !g_raw_ell || !g_raw_var || !g_Z || !g_Um || !g_Us)
-    return gp::set_error("gpode_cache_build_bwd: null pointer");
-  return gp::cache_build_bwd(kernel, Di, Do, M, S, raw_ell, raw_var, Z, eps_u, pack, ws, gpack, bws,
-                             g_raw_ell, g_raw_var, g_Z, g_Um, g_Us, prepared, (hipStream_t)stream);
+  return gpode_cache_build_bwd_n(kernel, Di, Do, M, S, 1, raw_ell, raw_var, Z, eps_u, pack, ws, gpack, bws, g_raw_ell, g_raw_var, g_Z, g_Um,
+                                 g_Us, prepared, stream);
+}
+int gpode_cache_bwd_prepare_n(int kernel, int Di, int Do, int M, int S, int ndraws, const float* ws, float* bws, void* stream) {
+  if (!ws || !bws) return gp::set_error("gpode_cache_bwd_prepare: null pointer");
+  if (ndraws < 1) return gp::set_error("gpode_cache_bwd_prepare: %d draws", ndraws);
+  return gp::cache_bwd_prepare(kernel, Di, Do, M, S, ndraws, ws, bws, (hipStream_t)stream);
 }
 int gpode_cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, const float* ws, float* bws, void* stream) {
-  if (!ws || !bws) return gp::set_error("gpode_cache_bwd_prepare: null pointer");
-  return gp::cache_bwd_prepare(kernel, Di, Do, M, S, ws, bws, (hipStream_t)stream);
+  return gpode_cache_bwd_prepare_n(kernel, Di, Do, M, S, 1, ws, bws, stream);
 }
 
 // ---- conv VAE blocks -----------------------------------------------------------------------

@@ -51,9 +51,11 @@ template <class EV, int DI, int DO, int ORDER, int METHOD>
 __global__ __launch_bounds__(64 * EV::kTeam) void rollout_bwd_team_kernel(const float* __restrict__ pack, int M, int S,
                                                                 const float* __restrict__ xstage, const float* __restrict__ gzt,
                                                                 const float* __restrict__ ts, int N, int T,
-                                                                float* __restrict__ gz0, float* __restrict__ astage) {
+                                                                float* __restrict__ gz0, float* __restrict__ astage, Draws dw) {
   constexpr int NS = METHOD == 0 ? 1 : (METHOD == 1 ? 4 : 2);
   __shared__ float slots[2 * EV::kTeam * TeamCombine::DP];
+  // blockIdx.y = Monte-Carlo draw
+  pack += blockIdx.y * dw.pack; xstage += blockIdx.y * dw.in; gzt += blockIdx.y * dw.in2; gz0 += blockIdx.y * dw.out; astage += blockIdx.y * dw.out2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   EV ev;
   ev.init(pack, M, S, slots, wave, lane);
@@ -135,8 +137,9 @@ __global__ __launch_bounds__(64 * EV::kTeam) void rollout_bwd_team_kernel(const 
 template <class EV, int DI, int DO>
 __global__ __launch_bounds__(64 * EV::kTeam) void rhs_vjp_team_kernel(const float* __restrict__ pack, int M, int S,
                                                             const float* __restrict__ x, const float* __restrict__ a, int R,
-                                                            float* __restrict__ gx, int prior_only) {
+                                                            float* __restrict__ gx, int prior_only, Draws dw) {
   __shared__ float slots[2 * EV::kTeam * TeamCombine::DP];
+  pack += blockIdx.y * dw.pack; x += blockIdx.y * dw.in; a += blockIdx.y * dw.in2; gx += blockIdx.y * dw.out;   // blockIdx.y = Monte-Carlo draw
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   EV ev;
   ev.init(pack, M, S, slots, wave, lane);
@@ -162,7 +165,9 @@ template <int DI, int DO, int NJ>
 __global__ __launch_bounds__(256) void param_grad_rbf_kernel(const float* __restrict__ pack, int M, int S,
                                                               const float* __restrict__ xr, const float* __restrict__ ar,
                                                               int R, int rows_per_chunk, float* __restrict__ slab,
-                                                              size_t pack_floats, int prior_only) {
+                                                              size_t pack_floats, int prior_only, Draws dw, int slab_chunks) {
+  // blockIdx.y = Monte-Carlo draw: its pack, its rows, its chunk slabs
+  pack += blockIdx.y * dw.pack; xr += blockIdx.y * dw.in; ar += blockIdx.y * dw.in2; slab += (size_t)blockIdx.y * slab_chunks * pack_floats;
   using EV = RbfTeamEval<DI, DO, NJ>;
   using L = RbfLayout<DI, DO>;
   constexpr int DH = (DO + 1) / 2;
@@ -234,7 +239,9 @@ template <int D, int NJ>
 __global__ __launch_bounds__(256) void param_grad_df_kernel(const float* __restrict__ pack, int M, int S,
                                                              const float* __restrict__ xr, const float* __restrict__ ar,
                                                              int R, int rows_per_chunk, float* __restrict__ slab,
-                                                             size_t pack_floats, int prior_only) {
+                                                             size_t pack_floats, int prior_only, Draws dw, int slab_chunks) {
+  // blockIdx.y = Monte-Carlo draw: its pack, its rows, its chunk slabs
+  pack += blockIdx.y * dw.pack; xr += blockIdx.y * dw.in; ar += blockIdx.y * dw.in2; slab += (size_t)blockIdx.y * slab_chunks * pack_floats;
   using EV = DfTeamEval<D, NJ>;
   using L = DfLayout<D>;
   constexpr int DH = (D + 1) / 2;
@@ -323,7 +330,9 @@ template <int DI, int DO>
 __global__ __launch_bounds__(256) void param_grad_rbf_stream_kernel(const float* __restrict__ pack, int M, int S,
                                                                      const float* __restrict__ xr, const float* __restrict__ ar,
                                                                      int R, int rows_per_chunk, float* __restrict__ slab,
-                                                                     size_t pack_floats, int prior_only) {
+                                                                     size_t pack_floats, int prior_only, Draws dw, int slab_chunks) {
+  // blockIdx.y = Monte-Carlo draw: its pack, its rows, its chunk slabs
+  pack += blockIdx.y * dw.pack; xr += blockIdx.y * dw.in; ar += blockIdx.y * dw.in2; slab += (size_t)blockIdx.y * slab_chunks * pack_floats;
   using L = RbfLayout<DI, DO>;
   constexpr int DH = (DO + 1) / 2;
   __shared__ __attribute__((aligned(16))) float sInd[2][64][4 * L::RQ2];
@@ -418,7 +427,9 @@ template <int D, int NP>
 __global__ __launch_bounds__(256) void param_grad_df_stream_kernel(const float* __restrict__ pack, int M, int S,
                                                                     const float* __restrict__ xr, const float* __restrict__ ar,
                                                                     int R, int rows_per_chunk, float* __restrict__ slab,
-                                                                    size_t pack_floats, int prior_only) {
+                                                                    size_t pack_floats, int prior_only, Draws dw, int slab_chunks) {
+  // blockIdx.y = Monte-Carlo draw: its pack, its rows, its chunk slabs
+  pack += blockIdx.y * dw.pack; xr += blockIdx.y * dw.in; ar += blockIdx.y * dw.in2; slab += (size_t)blockIdx.y * slab_chunks * pack_floats;
   using L = DfLayout<D>;
   constexpr int DQ = (D + NP - 1) / NP;
   constexpr int NU = 2 * D * DQ + DQ;
@@ -532,8 +543,9 @@ __global__ __launch_bounds__(256) void param_grad_df_stream_kernel(const float* 
 // gpack[e] = sum_c slab[c][e] in a fixed order: 16 interleaved partial sums per element (independent load streams),
 // combined through LDS.  grid = ceil(pack_floats / 64), block = 1024 (64 elements x 16 chunk groups).
 __global__ __launch_bounds__(1024) void reduce_slab_kernel(const float* __restrict__ slab, int nchunk, size_t pack_floats,
-                                                            float* __restrict__ gpack, int accumulate) {
+                                                            float* __restrict__ gpack, int accumulate, size_t gpack_dstride, int slab_chunks) {
   __shared__ float red[16][64];
+  slab += (size_t)blockIdx.y * slab_chunks * pack_floats; gpack += blockIdx.y * gpack_dstride;   // blockIdx.y = Monte-Carlo draw
   const int ex = threadIdx.x & 63, cg = threadIdx.x >> 6;
   const size_t e = (size_t)blockIdx.x * 64 + ex;
   float acc = 0.f;
@@ -570,47 +582,47 @@ template <int D> static bool df_team_ok(int M, int S) {
 
 template <int DI, int DO, int ORDER, int METHOD>
 static int launch_bwd_rbf(const float* pack, int M, int S, const float* xstage, const float* gzt, const float* ts, int N, int T,
-                          float* gz0, float* astage, hipStream_t st) {
+                          float* gz0, float* astage, hipStream_t st, Draws dw) {
   if constexpr (wide_ts_b<DO>() > 0 && DI <= 8) {   // few trajectories: 12 wavefronts each (gp_wide.hpp)
     constexpr int TS = wide_ts_b<DO>();
     if (wide_team_enabled() && N <= kWideMaxRows && RbfWideTeam<DI, DO, TS>::fits(M, S)) {
-      hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfWideTeam<DI, DO, TS>, DI, DO, ORDER, METHOD>), N, 64 * TS, 0, st,
-                         pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+      hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfWideTeam<DI, DO, TS>, DI, DO, ORDER, METHOD>), dim3(N, dw.nd), 64 * TS, 0, st,
+                         pack, M, S, xstage, gzt, ts, N, T, gz0, astage, dw);
       return check_launch("rollout_bwd_rbf_wide");
     }
   }
   if constexpr (DO <= 8) {
     if (rbf_team_ok<DI, DO>(M, S)) {
-      hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO, ORDER, METHOD>), team_grid_b(N), 256, 0, st,
-                         pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+      hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO, ORDER, METHOD>), dim3(team_grid_b(N), dw.nd), 256, 0, st,
+                         pack, M, S, xstage, gzt, ts, N, T, gz0, astage, dw);
       return check_launch("rollout_bwd_rbf");
     }
   }
-  hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfStreamTeam<DI, DO>, DI, DO, ORDER, METHOD>), team_grid_b(N), 256, 0, st,
-                     pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+  hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfStreamTeam<DI, DO>, DI, DO, ORDER, METHOD>), dim3(team_grid_b(N), dw.nd), 256, 0, st,
+                     pack, M, S, xstage, gzt, ts, N, T, gz0, astage, dw);
   return check_launch("rollout_bwd_rbf_stream");
 }
 
 template <int D, int METHOD>
 static int launch_bwd_df(const float* pack, int M, int S, const float* xstage, const float* gzt, const float* ts, int N, int T,
-                         float* gz0, float* astage, hipStream_t st) {
+                         float* gz0, float* astage, hipStream_t st, Draws dw) {
   if constexpr (wide_ts_b<D>() > 0) {
     constexpr int TS = wide_ts_b<D>();
     if (wide_team_enabled() && N <= kWideMaxRows && DfWideTeam<D, TS>::fits(M, S)) {
-      hipLaunchKernelGGL((rollout_bwd_team_kernel<DfWideTeam<D, TS>, D, D, 1, METHOD>), N, 64 * TS, 0, st,
-                         pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+      hipLaunchKernelGGL((rollout_bwd_team_kernel<DfWideTeam<D, TS>, D, D, 1, METHOD>), dim3(N, dw.nd), 64 * TS, 0, st,
+                         pack, M, S, xstage, gzt, ts, N, T, gz0, astage, dw);
       return check_launch("rollout_bwd_df_wide");
     }
   }
   if constexpr (D <= 8) {
     if (df_team_ok<D>(M, S)) {
-      hipLaunchKernelGGL((rollout_bwd_team_kernel<DfTeamEval<D, 1>, D, D, 1, METHOD>), team_grid_b(N), 256, 0, st,
-                         pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+      hipLaunchKernelGGL((rollout_bwd_team_kernel<DfTeamEval<D, 1>, D, D, 1, METHOD>), dim3(team_grid_b(N), dw.nd), 256, 0, st,
+                         pack, M, S, xstage, gzt, ts, N, T, gz0, astage, dw);
       return check_launch("rollout_bwd_df");
     }
   }
-  hipLaunchKernelGGL((rollout_bwd_team_kernel<DfStreamTeam<D>, D, D, 1, METHOD>), team_grid_b(N), 256, 0, st,
-                     pack, M, S, xstage, gzt, ts, N, T, gz0, astage);
+  hipLaunchKernelGGL((rollout_bwd_team_kernel<DfStreamTeam<D>, D, D, 1, METHOD>), dim3(team_grid_b(N), dw.nd), 256, 0, st,
+                     pack, M, S, xstage, gzt, ts, N, T, gz0, astage, dw);
   return check_launch("rollout_bwd_df_stream");
 }
 
@@ -619,32 +631,32 @@ static int launch_bwd_df(const float* pack, int M, int S, const float* xstage, c
 
 template <int DI, int DO>
 static int bwd_rbf_dispatch(int order, int method, const float* pack, int M, int S, const float* xstage, const float* gzt,
-                            const float* ts, int N, int T, float* gz0, float* astage, hipStream_t st) {
+                            const float* ts, int N, int T, float* gz0, float* astage, hipStream_t st, Draws dw) {
   if constexpr (DI == DO) {
-    if (order == 1 && method == 0) return launch_bwd_rbf<DI, DO, 1, 0>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
-    if (order == 1 && method == 1) return launch_bwd_rbf<DI, DO, 1, 1>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
-    if (order == 1 && method == 2) return launch_bwd_rbf<DI, DO, 1, 2>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
+    if (order == 1 && method == 0) return launch_bwd_rbf<DI, DO, 1, 0>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st, dw);
+    if (order == 1 && method == 1) return launch_bwd_rbf<DI, DO, 1, 1>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st, dw);
+    if (order == 1 && method == 2) return launch_bwd_rbf<DI, DO, 1, 2>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st, dw);
   }
   if constexpr (DI == 2 * DO) {
-    if (order == 2 && method == 0) return launch_bwd_rbf<DI, DO, 2, 0>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
-    if (order == 2 && method == 1) return launch_bwd_rbf<DI, DO, 2, 1>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
-    if (order == 2 && method == 2) return launch_bwd_rbf<DI, DO, 2, 2>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
+    if (order == 2 && method == 0) return launch_bwd_rbf<DI, DO, 2, 0>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st, dw);
+    if (order == 2 && method == 1) return launch_bwd_rbf<DI, DO, 2, 1>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st, dw);
+    if (order == 2 && method == 2) return launch_bwd_rbf<DI, DO, 2, 2>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st, dw);
   }
   return set_error("gpode_rollout_bwd: order=%d needs Di == order*Do (Di=%d Do=%d)", order, DI, DO);
 }
 
 int rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S, const float* pack, const float* xstage,
-                const float* gzt, const float* ts, int N, int T, float* gz0, float* astage, hipStream_t st) {
+                const float* gzt, const float* ts, int N, int T, float* gz0, float* astage, hipStream_t st, Draws dw) {
   if (method < 0 || method > 2) return set_error("gpode_rollout_bwd: method %d", method);
   if (kernel == 0) {
-#define X(a, b) if (Di == a && Do == b) return bwd_rbf_dispatch<a, b>(order, method, pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
+#define X(a, b) if (Di == a && Do == b) return bwd_rbf_dispatch<a, b>(order, method, pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st, dw);
     GP_BWD_RBF_DIMS(X)
 #undef X
   } else {
     if (order != 1) return set_error("gpode_rollout_bwd: DF kernel is first-order only");
-#define X(a) if (Di == a && Do == a) return method == 0 ? launch_bwd_df<a, 0>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st) \
-                                            : method == 1 ? launch_bwd_df<a, 1>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st) \
-                                                          : launch_bwd_df<a, 2>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st);
+#define X(a) if (Di == a && Do == a) return method == 0 ? launch_bwd_df<a, 0>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st, dw) \
+                                            : method == 1 ? launch_bwd_df<a, 1>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st, dw) \
+                                                          : launch_bwd_df<a, 2>(pack, M, S, xstage, gzt, ts, N, T, gz0, astage, st, dw);
     GP_BWD_DF_DIMS(X)
 #undef X
   }
@@ -652,38 +664,38 @@ int rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S,
 }
 
 template <int DI, int DO>
-static int launch_vjp_rbf(const float* pack, int M, int S, const float* x, const float* a, int R, float* gx, int prior_only, hipStream_t st) {
+static int launch_vjp_rbf(const float* pack, int M, int S, const float* x, const float* a, int R, float* gx, int prior_only, hipStream_t st, Draws dw) {
   if constexpr (DO <= 8) {
     if (rbf_team_ok<DI, DO>(M, S)) {
-      hipLaunchKernelGGL((rhs_vjp_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);
+      hipLaunchKernelGGL((rhs_vjp_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO>), dim3(team_grid_b(R), dw.nd), 256, 0, st, pack, M, S, x, a, R, gx, prior_only, dw);
       return check_launch("rhs_vjp_rbf");
     }
   }
-  hipLaunchKernelGGL((rhs_vjp_team_kernel<RbfStreamTeam<DI, DO>, DI, DO>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);
+  hipLaunchKernelGGL((rhs_vjp_team_kernel<RbfStreamTeam<DI, DO>, DI, DO>), dim3(team_grid_b(R), dw.nd), 256, 0, st, pack, M, S, x, a, R, gx, prior_only, dw);
   return check_launch("rhs_vjp_rbf_stream");
 }
 
 template <int D>
-static int launch_vjp_df(const float* pack, int M, int S, const float* x, const float* a, int R, float* gx, int prior_only, hipStream_t st) {
+static int launch_vjp_df(const float* pack, int M, int S, const float* x, const float* a, int R, float* gx, int prior_only, hipStream_t st, Draws dw) {
   if constexpr (D <= 8) {
     if (df_team_ok<D>(M, S)) {
-      hipLaunchKernelGGL((rhs_vjp_team_kernel<DfTeamEval<D, 1>, D, D>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);
+      hipLaunchKernelGGL((rhs_vjp_team_kernel<DfTeamEval<D, 1>, D, D>), dim3(team_grid_b(R), dw.nd), 256, 0, st, pack, M, S, x, a, R, gx, prior_only, dw);
       return check_launch("rhs_vjp_df");
     }
   }
-  hipLaunchKernelGGL((rhs_vjp_team_kernel<DfStreamTeam<D>, D, D>), team_grid_b(R), 256, 0, st, pack, M, S, x, a, R, gx, prior_only);
+  hipLaunchKernelGGL((rhs_vjp_team_kernel<DfStreamTeam<D>, D, D>), dim3(team_grid_b(R), dw.nd), 256, 0, st, pack, M, S, x, a, R, gx, prior_only, dw);
   return check_launch("rhs_vjp_df_stream");
 }
 
 int rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, const float* a, int R, float* gx,
-            int prior_only, hipStream_t st) {
+            int prior_only, hipStream_t st, Draws dw) {
   if (R <= 0) return 0;
   if (kernel == 0) {
-#define X(p, q) if (Di == p && Do == q) return launch_vjp_rbf<p, q>(pack, M, S, x, a, R, gx, prior_only, st);
+#define X(p, q) if (Di == p && Do == q) return launch_vjp_rbf<p, q>(pack, M, S, x, a, R, gx, prior_only, st, dw);
     GP_BWD_RBF_DIMS(X)
 #undef X
   } else {
-#define X(p) if (Di == p && Do == p) return launch_vjp_df<p>(pack, M, S, x, a, R, gx, prior_only, st);
+#define X(p) if (Di == p && Do == p) return launch_vjp_df<p>(pack, M, S, x, a, R, gx, prior_only, st, dw);
     GP_BWD_DF_DIMS(X)
 #undef X
   }
@@ -693,32 +705,32 @@ int rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack, const f
 // rows (R,Di) x adjoints (R,Do) -> gpack (pack layout).  slab: nchunk * pack_floats floats of scratch.
 template <int DI, int DO>
 static int launch_pgrad_rbf(const float* pack, int M, int S, const float* xr, const float* ar, int R, int rpc, int used, float* slab,
-                            size_t pf, int prior_only, hipStream_t st) {
+                            size_t pf, int prior_only, hipStream_t st, Draws dw, int nchunk) {
   if constexpr (DO <= 8) {
     if (rbf_team_ok<DI, DO>(M, S)) {
-      hipLaunchKernelGGL((param_grad_rbf_kernel<DI, DO, 1>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only);
+      hipLaunchKernelGGL((param_grad_rbf_kernel<DI, DO, 1>), dim3(used, dw.nd), 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only, dw, nchunk);
       return check_launch("param_grad_rbf");
     }
   }
-  hipLaunchKernelGGL((param_grad_rbf_stream_kernel<DI, DO>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only);
+  hipLaunchKernelGGL((param_grad_rbf_stream_kernel<DI, DO>), dim3(used, dw.nd), 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only, dw, nchunk);
   return check_launch("param_grad_rbf_stream");
 }
 
 template <int D>
 static int launch_pgrad_df(const float* pack, int M, int S, const float* xr, const float* ar, int R, int rpc, int used, float* slab,
-                           size_t pf, int prior_only, hipStream_t st) {
+                           size_t pf, int prior_only, hipStream_t st, Draws dw, int nchunk) {
   if constexpr (D <= 8) {
     if (df_team_ok<D>(M, S)) {
-      hipLaunchKernelGGL((param_grad_df_kernel<D, 1>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only);
+      hipLaunchKernelGGL((param_grad_df_kernel<D, 1>), dim3(used, dw.nd), 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only, dw, nchunk);
       return check_launch("param_grad_df");
     }
   }
-  hipLaunchKernelGGL((param_grad_df_stream_kernel<D, (D > 8 ? 4 : 2)>), used, 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only);
+  hipLaunchKernelGGL((param_grad_df_stream_kernel<D, (D > 8 ? 4 : 2)>), dim3(used, dw.nd), 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only, dw, nchunk);
   return check_launch("param_grad_df_stream");
 }
 
 int param_grad(int kernel, int Di, int Do, int M, int S, const float* pack, const float* xr, const float* ar, int R,
-               float* slab, int nchunk, float* gpack, int accumulate, int prior_only, hipStream_t st) {
+               float* slab, int nchunk, float* gpack, int accumulate, int prior_only, hipStream_t st, Draws dw) {
   size_t pf = 0;
   if (cache_sizes(kernel, Di, Do, M, S, &pf, nullptr)) return 1;
   if (R <= 0 || nchunk <= 0) return set_error("gpode_param_grad: R=%d nchunk=%d", R, nchunk);
@@ -726,17 +738,17 @@ int param_grad(int kernel, int Di, int Do, int M, int S, const float* pack, cons
   const int used = cdiv(R, rpc);
   int rc = -1;
   if (kernel == 0) {
-#define X(p, q) if (Di == p && Do == q) rc = launch_pgrad_rbf<p, q>(pack, M, S, xr, ar, R, rpc, used, slab, pf, prior_only, st);
+#define X(p, q) if (Di == p && Do == q) rc = launch_pgrad_rbf<p, q>(pack, M, S, xr, ar, R, rpc, used, slab, pf, prior_only, st, dw, nchunk);
     GP_BWD_RBF_DIMS(X)
 #undef X
   } else {
-#define X(p) if (Di == p && Do == p) rc = launch_pgrad_df<p>(pack, M, S, xr, ar, R, rpc, used, slab, pf, prior_only, st);
+#define X(p) if (Di == p && Do == p) rc = launch_pgrad_df<p>(pack, M, S, xr, ar, R, rpc, used, slab, pf, prior_only, st, dw, nchunk);
     GP_BWD_DF_DIMS(X)
 #undef X
   }
   if (rc < 0) return set_error("gpode_param_grad: no specialisation for kernel=%d Di=%d Do=%d", kernel, Di, Do);
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_slab_kernel, (unsigned)((pf + 63) / 64), 1024, 0, st, slab, used, pf, gpack, accumulate);
+  hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((pf + 63) / 64), dw.nd), 1024, 0, st, slab, used, pf, gpack, accumulate, dw.out, nchunk);
   return check_launch("reduce_slab");
 }
 

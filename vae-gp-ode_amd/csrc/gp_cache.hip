@@ -48,6 +48,8 @@ struct PrepArgs {
   float *ell_out, *var_out, *omega_out, *phase_out, *u_out;
   int* info;                                         // status word of the factorisation, cleared here (no memset node)
   int nb_rff, nb_u, nb_ind, nb_hyp, nb_om;
+  // blockIdx.y = Monte-Carlo draw: per-draw strides (floats) of the noise, of the pack and of the per-draw outputs
+  size_t s_eps_u, s_rff_w, s_rff_eps, s_rff_u, s_pack;
 };
 
 __device__ __forceinline__ void put_rec(float* __restrict__ pack, size_t rec_f4_base, int lane, int field, float v) {
@@ -57,6 +59,15 @@ __device__ __forceinline__ void put_rec(float* __restrict__ pack, size_t rec_f4_
 
 __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
   const int Di = a.Di, Do = a.Do, S = a.S, M = a.M;
+  {
+    const size_t dr = blockIdx.y;                    // this draw's noise, pack and outputs (ell / var / info: same values from every draw)
+    a.eps_u += dr * a.s_eps_u; a.rff_w += dr * a.s_rff_w; a.rff_eps += dr * a.s_rff_eps; a.rff_u += dr * a.s_rff_u;
+    a.pack += dr * a.s_pack; a.pack_ind += dr * a.s_pack; a.uni += dr * a.s_pack;
+    a.u_ws += dr * a.s_eps_u;
+    if (a.u_out) a.u_out += dr * a.s_eps_u;
+    if (a.omega_out) a.omega_out += dr * a.s_rff_eps;
+    if (a.phase_out) a.phase_out += dr * a.s_rff_u;
+  }
   int blk = blockIdx.x;
   const int tid = threadIdx.x;
   __shared__ float sEll[256], sVar[16];  // Do*Di <= 256, Do <= 16 for every compiled specialisation
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
 //   A: (batch, np, np) row-major.  RBF: batch = Do, n = M.  DF: batch = 1, n = M D.
 // ---------------------------------------------------------------------------------------------
 __global__ void k_Kzz_rbf(int Di, int Do, int M, int np, const float* __restrict__ Z, const float* __restrict__ ell,
-                          const float* __restrict__ var, const float* __restrict__ u_prior, float* __restrict__ A) {
+                          const float* __restrict__ var, const float* __restrict__ u_prior, float* __restrict__ A, int nd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = blockIdx.y, d = blockIdx.z;
   if (c >= np) return;
@@ -187,8 +198,8 @@ __global__ void k_Kzz_rbf(int Di, int Do, int M, int np, const float* __restrict
       q = fmaf(t, t, q);
     }
     v = var[d] * expf(-0.5f * q) + (r == c ? kJitter : 0.f);
-  } else if (r == M) {
-    v = c < M ? u_prior[c * Do + d] : (c == M ? 1e30f : 0.f);
+  } else if (r < M + nd) {                           // rhs row of draw r - M (huge diagonal: eliminating its column touches nothing)
+    v = c < M ? u_prior[(size_t)(r - M) * M * Do + c * Do + d] : (c == r ? 1e30f : 0.f);
   } else {
     v = (r == c) ? 1.f : 0.f;
   }
@@ -196,7 +207,7 @@ __global__ void k_Kzz_rbf(int Di, int Do, int M, int np, const float* __restrict
 }
 
 __global__ void k_Kzz_df(int D, int M, int np, const float* __restrict__ Z, const float* __restrict__ ell,
-                         const float* __restrict__ var, const float* __restrict__ u_prior, float* __restrict__ A) {
+                         const float* __restrict__ var, const float* __restrict__ u_prior, float* __restrict__ A, int nd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int r = blockIdx.y;
   const int n = M * D;
@@ -212,8 +223,8 @@ __global__ void k_Kzz_df(int D, int M, int np, const float* __restrict__ Z, cons
     float da = Z[mm * D + a] - Z[nn * D + a], db = Z[mm * D + b] - Z[nn * D + b];
     float term = da * db * il2 + ((a == b) ? ((float)(D - 1) - r2 * il2) : 0.f);
     v = var[b] * expf(-0.5f * r2 * il2) * term * il2 + (r == c ? kJitter : 0.f);
-  } else if (r == n) {
-    v = c < n ? u_prior[c] : (c == n ? 1e30f : 0.f);
+  } else if (r < n + nd) {
+    v = c < n ? u_prior[(size_t)(r - n) * n + c] : (c == r ? 1e30f : 0.f);
   } else {
     v = (r == c) ? 1.f : 0.f;
   }
@@ -647,17 +658,22 @@ __global__ __launch_bounds__(256) void k_solve_back(const float* __restrict__ Aa
                                                      const float* __restrict__ u, int u_stride, int u_bstride,
                                                      float* __restrict__ nu, float* __restrict__ nu_out,
                                                      int kernel, int Di, int Do, int M, const float* __restrict__ var,
-                                                     float* __restrict__ pack_ind) {
+                                                     float* __restrict__ pack_ind, size_t u_dstride, size_t nu_dstride,
+                                                     size_t pack_dstride) {
   extern __shared__ __attribute__((aligned(16))) float sv[];  // np floats: residual, overwritten by the solution
   __shared__ float sx[NB];
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, dr = blockIdx.y;          // system, Monte-Carlo draw (its rhs is row n + dr of the factor)
   const float* A = Aall + (size_t)b * batch_stride;
   const float* Dfac = Dfac_all + (size_t)b * dfac_stride;
+  u += (size_t)dr * u_dstride;
+  nu += (size_t)dr * nu_dstride;
+  if (nu_out) nu_out += (size_t)dr * nu_dstride;
+  pack_ind += (size_t)dr * pack_dstride;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int kl = n / NB, cl = kl * NB;  // block holding the rhs row n
+  const int rr = n + dr, kl = rr / NB, cl = kl * NB;  // block holding the rhs row
   for (int j = tid; j < np; j += 256) {
     float y = 0.f;
-    if (j < n) y = (j < cl) ? A[(size_t)n * np + j] : Dfac[(size_t)kl * NB * NB + (n - cl) * NB + (j - cl)];
+    if (j < n) y = (j < cl) ? A[(size_t)rr * np + j] : Dfac[(size_t)kl * NB * NB + (rr - cl) * NB + (j - cl)];
     sv[j] = j < n ? u[(size_t)j * u_stride + (size_t)b * u_bstride] - y : 0.f;
   }
   const int nblk = cdiv(n, NB);
@@ -777,12 +793,14 @@ __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, 
                                                    const float* __restrict__ u_prior, const float* __restrict__ u,
                                                    float* __restrict__ Lall, size_t batch_stride, float* __restrict__ Dfac_all,
                                                    size_t dfac_stride, float* __restrict__ nu_ws, float* __restrict__ nu_out,
-                                                   float* __restrict__ pack_ind, int* __restrict__ info) {
+                                                   float* __restrict__ pack_ind, int* __restrict__ info, int nd, size_t u_dstride,
+                                                   size_t nu_dstride, size_t pack_dstride) {
+  // nd Monte-Carlo draws share the factor: their right-hand sides f_prior_l(Z) are rows n .. n + nd - 1, u / nu / pack are per draw
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   const int LD = np + 2;
   float* sA = dsm;                                   // [np][LD]
-  float* sv = dsm + (size_t)np * LD;                 // [np] residual / solution
-  float* sx = sv + np;                               // [NB]
+  float* sv = dsm + (size_t)np * LD;                 // [nd][np] solutions
+  float* sx = sv + (size_t)nd * np;                  // [NB]
   float* sZ = sx + NB;                               // [M][Di]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef DRAW_PROBE
@@ -866,8 +884,9 @@ __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, 
             const float term = da * db * il2 + ((a == bb) ? ((float)(D - 1) - r2 * il2) : 0.f);
             v = vq[q] * expf(-0.5f * r2 * il2) * term * il2 + (r == c ? kJitter : 0.f);
           }
-        } else if (r == n) {
-          v = c < n ? (KERNEL == 0 ? u_prior[c * Do + b] : u_prior[c]) : (c == n ? 1e30f : 0.f);
+        } else if (r < n + nd) {
+          const float* up = u_prior + (size_t)(r - n) * u_dstride;
+          v = c < n ? (KERNEL == 0 ? up[c * Do + b] : up[c]) : (c == r ? 1e30f : 0.f);
         } else {
           v = (r == c) ? 1.f : 0.f;
         }
@@ -950,13 +969,15 @@ __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, 
   }
   // ---- nu = L^-T (u - y), y = row n of the factor: block back-substitution by wavefront 0 alone -- the residual lives in its
   // registers (lane l holds entries l, l + 64, l + 128), the 32 solved unknowns of a block travel as wave-uniform values
-  // (v_readlane), so the 2 x nblk workgroup barriers of a shared-residual formulation disappear from the chain
-  if (wave == 0) {
+  // (v_readlane), so the 2 x nblk workgroup barriers of a shared-residual formulation disappear from the chain.
+  // One wavefront per draw (draws wave, wave + 8, ...): the substitutions of the draws are independent and run side by side.
+  for (int dr = wave; dr < nd; dr += 8) {
+    const float* ud = u + (size_t)dr * u_dstride;
     float res[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const int j = lane + 64 * q;
-      res[q] = j < n ? (KERNEL == 0 ? u[(size_t)j * Do + b] : u[j]) - sA[n * LD + j] : 0.f;
+      res[q] = j < n ? (KERNEL == 0 ? ud[(size_t)j * Do + b] : ud[j]) - sA[(n + dr) * LD + j] : 0.f;
     }
     for (int k = cdiv(n, NB) - 1; k >= 0; --k) {
       const int c0 = k * NB, q0 = c0 >> 6, l0 = c0 & 63;     // the block sits in chunk q0, lanes l0 .. l0 + 31
@@ -998,7 +1019,7 @@ __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, 
     }
 #pragma unroll
     for (int q = 0; q < 3; ++q)
-      if (lane + 64 * q < np) sv[lane + 64 * q] = res[q];
+      if (lane + 64 * q < np) sv[(size_t)dr * np + lane + 64 * q] = res[q];
   }
   __syncthreads();
   DPROBE(3);
@@ -1013,16 +1034,17 @@ __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, 
       else Dfac[(size_t)tr * NB * NB + (r & 31) * NB + (c & 31)] = v;
     }
   }
-  for (int j = tid; j < n; j += 512) {
-    const float v = sv[j];
-    nu_ws[(size_t)b * n + j] = v;
-    if (nu_out) nu_out[(size_t)b * n + j] = v;
+  for (int e = tid; e < nd * n; e += 512) {
+    const int dr = e / n, j = e - dr * n;
+    const float v = sv[(size_t)dr * np + j];
+    nu_ws[(size_t)dr * nu_dstride + (size_t)b * n + j] = v;
+    if (nu_out) nu_out[(size_t)dr * nu_dstride + (size_t)b * n + j] = v;
     const int RQ2 = cdiv(Di + Do, 4);
     int m, d;
     float coef;
     if (KERNEL == 0) { m = j; d = b; coef = var[d] * v; } else { m = j / Do; d = j % Do; coef = v; }
     const int field = Di + d;
-    pack_ind[(((size_t)(m >> 6) * RQ2 + (field >> 2)) * 64 + (m & 63)) * 4 + (field & 3)] = coef;
+    pack_ind[(size_t)dr * pack_dstride + (((size_t)(m >> 6) * RQ2 + (field >> 2)) * 64 + (m & 63)) * 4 + (field & 3)] = coef;
   }
 #ifdef DRAW_PROBE
   __syncthreads();
@@ -1034,12 +1056,12 @@ __global__ __launch_bounds__(512) void k_draw_lds(int Di, int Do, int M, int n, 
 }
 
 // LDS bytes of k_draw_lds; it takes systems up to np = 192 (GPODE_DRAW_CHAIN=1 keeps the launch chain for every size: A/B switch)
-static inline size_t draw_lds_bytes(int np, int M, int Di) {   // sA, sv, sx, Z transposed, constants (<= Di * Di + Di)
-  return sizeof(float) * ((size_t)np * (np + 2) + np + NB + (size_t)Di * (M | 1) + (size_t)Di * Di + Di);
+static inline size_t draw_lds_bytes(int np, int M, int Di, int nd) {   // sA, sv, sx, Z transposed, constants (<= Di * Di + Di)
+  return sizeof(float) * ((size_t)np * (np + 2) + (size_t)nd * np + NB + (size_t)Di * (M | 1) + (size_t)Di * Di + Di);
 }
-static inline bool draw_in_lds(int np, int M, int Di) {
+static inline bool draw_in_lds(int np, int M, int Di, int nd) {
   static const bool off = [] { const char* e = getenv("GPODE_DRAW_CHAIN"); return e && e[0] == '1'; }();
-  return !off && np <= 192 && draw_lds_bytes(np, M, Di) <= 160 * 1024;
+  return !off && np <= 192 && draw_lds_bytes(np, M, Di, nd) <= 160 * 1024;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1056,18 +1078,20 @@ __device__ __forceinline__ float factor_elem(const float* __restrict__ Lm, const
 __global__ __launch_bounds__(256) void k_solve_back_panel(const float* __restrict__ Lall, int n, int np, size_t batch_stride,
                                                            const float* __restrict__ Dfac_all, size_t dfac_stride,
                                                            const float* __restrict__ u, int u_stride, int u_bstride,
-                                                           float* __restrict__ yall, float* __restrict__ nu, int P, int first) {
+                                                           float* __restrict__ yall, float* __restrict__ nu, int P, int first,
+                                                           size_t u_dstride, size_t nu_dstride) {
   constexpr int PW = 128;
   __shared__ float sx[PW], spart[PW];
-  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int c = blockIdx.x, b = blockIdx.y, dr = blockIdx.z, tid = threadIdx.x;   // dr: Monte-Carlo draw, rhs = row n + dr of the factor
   const float* Lm = Lall + (size_t)b * batch_stride;
   const float* Dfac = Dfac_all + (size_t)b * dfac_stride;
-  float* y = yall + (size_t)b * batch_stride;
-  float* nub = nu + (size_t)b * n;
+  float* y = yall + (size_t)b * batch_stride + (size_t)dr * np;      // residuals: rows of the consumed A buffer, one per draw
+  float* nub = nu + (size_t)dr * nu_dstride + (size_t)b * n;
+  u += (size_t)dr * u_dstride;
   const int col = c * PW + (tid & (PW - 1)), half = tid >> 7;
   float res = 0.f;
   if (first) {
-    if (half == 0 && col < n) res = u[(size_t)col * u_stride + (size_t)b * u_bstride] - factor_elem(Lm, Dfac, np, n, col);
+    if (half == 0 && col < n) res = u[(size_t)col * u_stride + (size_t)b * u_bstride] - factor_elem(Lm, Dfac, np, n + dr, col);
   } else {
     const int r0 = (P + 1) * PW;
     if (tid < PW) sx[tid] = r0 + tid < n ? nub[r0 + tid] : 0.f;
@@ -1106,9 +1130,12 @@ __global__ __launch_bounds__(256) void k_solve_back_panel(const float* __restric
 
 // nu -> optional dense output and the coefficient fields of the pack's inducing records (as the tail of k_solve_back)
 __global__ void k_nu_publish(int n, const float* __restrict__ nu, float* __restrict__ nu_out, int kernel, int Di, int Do,
-                             const float* __restrict__ var, float* __restrict__ pack_ind) {
+                             const float* __restrict__ var, float* __restrict__ pack_ind, size_t nu_dstride, size_t pack_dstride) {
   const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
+  nu += (size_t)blockIdx.z * nu_dstride;
+  if (nu_out) nu_out += (size_t)blockIdx.z * nu_dstride;
+  pack_ind += (size_t)blockIdx.z * pack_dstride;
   const float v = nu[(size_t)b * n + j];
   if (nu_out) nu_out[(size_t)b * n + j] = v;
   const int RQ2 = cdiv(Di + Do, 4);
@@ -1140,11 +1167,11 @@ static size_t pack_floats_for(int kernel, int Di, int Do, int M, int S) {
   return 256 * (SJ * Do * cdiv(2 * Do + 3, 4) + MJ * cdiv(2 * Do, 4)) + (size_t)cdiv(2 * Do * Do + Do, 4) * 4;
 }
 
-int cache_sizes(int kernel, int Di, int Do, int M, int S, size_t* pack_floats, size_t* ws_floats) {
+int cache_sizes(int kernel, int Di, int Do, int M, int S, size_t* pack_floats, size_t* ws_floats, int nd) {
   if (!dims_supported(kernel, Di, Do)) return set_error("gpode_cache_sizes: no specialisation for kernel=%d Di=%d Do=%d", kernel, Di, Do);
-  if (M < 1 || S < 1) return set_error("gpode_cache_sizes: M=%d S=%d", M, S);
+  if (M < 1 || S < 1 || nd < 1) return set_error("gpode_cache_sizes: M=%d S=%d draws=%d", M, S, nd);
   if (pack_floats) *pack_floats = pack_floats_for(kernel, Di, Do, M, S);
-  if (ws_floats) *ws_floats = ws_layout(kernel, Di, Do, M, S).total;
+  if (ws_floats) *ws_floats = ws_layout(kernel, Di, Do, M, S, nd).total;
   return 0;
 }
 
@@ -1183,17 +1210,22 @@ static void cholesky_blocked(float* A, float* Lmat, float* Dfac, int np, int nbl
   }
 }
 
-int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
+// nd Monte-Carlo draws in one build (nd = 1: SVGP_Layer.build_cache as the reference calls it).  Noise, pack and the per-draw
+// outputs (omega, phase, u, nu, u_prior) are stacked along a leading draw axis; ell, var, Lu and the factor in ws are shared.
+int cache_build_fwd(int kernel, int Di, int Do, int M, int S, int nd,
                     const float* raw_ell, const float* raw_var, const float* Z, const float* Um, const float* Us_packed,
                     const float* eps_u, const float* rff_w, const float* rff_eps, const float* rff_u,
                     float* pack, float* ws, float* ell, float* var, float* omega, float* phase, float* u,
                     float* Lu, float* nu, float* u_prior, hipStream_t st) {
   if (!dims_supported(kernel, Di, Do)) return set_error("gpode_cache_build_fwd: no specialisation for kernel=%d Di=%d Do=%d", kernel, Di, Do);
   if (kernel == 1 && Di != Do) return set_error("gpode_cache_build_fwd: DF needs D_in == D_out (kernels.py:259-262)");
-  const WsLayout w = ws_layout(kernel, Di, Do, M, S);
+  if (nd < 1 || nd > 65535) return set_error("gpode_cache_build_fwd: %d draws", nd);
+  const WsLayout w = ws_layout(kernel, Di, Do, M, S, nd);
   const size_t SJ = cdiv(S, 64), MJ = cdiv(M, 64);
   const size_t rff_f4 = (kernel == 0 ? SJ * Do * cdiv(Di + 2, 4) : SJ * Do * cdiv(2 * Do + 3, 4)) * 64;
   const size_t ind_f4 = (kernel == 0 ? MJ * cdiv(Di + Do, 4) : MJ * cdiv(2 * Do, 4)) * 64;
+  const size_t pf = pack_floats_for(kernel, Di, Do, M, S);
+  const size_t MD = (size_t)M * Do;                    // per-draw stride of u, u_prior (and of nu: batch * n = M Do for both kernels)
   float* pack_ind = pack + 4 * rff_f4;
   float* uni = pack + 4 * (rff_f4 + ind_f4);
   int* info = reinterpret_cast<int*>(ws + w.info);
@@ -1211,57 +1243,60 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
     a.nb_ind = cdiv((int)(MJ * 64), 256);
     a.nb_hyp = 1;
     a.nb_om = (omega || phase) ? cdiv(Di * S * Do, 256) : 0;
-    hipLaunchKernelGGL(k_prep, a.nb_rff + a.nb_u + a.nb_ind + a.nb_hyp + a.nb_om, 256, 0, st, a);
+    a.s_eps_u = MD; a.s_rff_w = (size_t)(kernel == 0 ? S : 2 * S) * Do; a.s_rff_eps = (size_t)Di * S * Do; a.s_rff_u = (size_t)S * Do;
+    a.s_pack = pf;
+    hipLaunchKernelGGL(k_prep, dim3(a.nb_rff + a.nb_u + a.nb_ind + a.nb_hyp + a.nb_om, nd), 256, 0, st, a);
     if (check_launch("cache prep")) return 1;
   }
 
-  // u_prior = f_prior(Z): the rhs kernel in prior-only mode on the M inducing locations (straight into the caller's
-  // buffer when one is given: no copy node on the critical path of the step)
+  // u_prior = f_prior(Z): the rhs kernel in prior-only mode on the M inducing locations, every draw with its own pack (straight
+  // into the caller's buffer when one is given: no copy node on the critical path of the step)
   float* up = u_prior ? u_prior : ws + w.u_prior;
-  if (rhs_fwd(kernel, Di, Do, M, S, pack, Z, M, up, 1, st)) return 1;
+  if (rhs_fwd(kernel, Di, Do, M, S, pack, Z, M, up, 1, st, Draws{nd, pf, 0, MD})) return 1;
 
   float* A = ws + w.A;
   float* Lmat = ws + w.Lmat;
   float* Dfac = ws + w.Dfac;
   const size_t bstride = (size_t)w.np * w.np, dstride = (size_t)w.nblk * NB * NB;
-  if (draw_in_lds(w.np, M, Di)) {
+  if (draw_in_lds(w.np, M, Di, nd)) {
     // small systems: kernel matrix, factorisation and both solves in one launch, LDS-resident
-    const size_t lds = draw_lds_bytes(w.np, M, Di);
+    const size_t lds = draw_lds_bytes(w.np, M, Di, nd);
     if (kernel == 0) {
       if (set_max_lds((const void*)k_draw_lds<0>, lds)) return 1;
       hipLaunchKernelGGL(k_draw_lds<0>, w.batch, 512, lds, st, Di, Do, M, w.n, w.np, w.nblk, Z, ws + w.ell, ws + w.var, up, ws + w.u, Lmat,
-                         bstride, Dfac, dstride, ws + w.nu, nu, pack_ind, info);
+                         bstride, Dfac, dstride, ws + w.nu, nu, pack_ind, info, nd, MD, MD, pf);
     } else {
       if (set_max_lds((const void*)k_draw_lds<1>, lds)) return 1;
       hipLaunchKernelGGL(k_draw_lds<1>, w.batch, 512, lds, st, Di, Do, M, w.n, w.np, w.nblk, Z, ws + w.ell, ws + w.var, up, ws + w.u, Lmat,
-                         bstride, Dfac, dstride, ws + w.nu, nu, pack_ind, info);
+                         bstride, Dfac, dstride, ws + w.nu, nu, pack_ind, info, nd, MD, MD, pf);
     }
     if (Lu) hipLaunchKernelGGL(k_copy_L, dim3(cdiv(w.n, 128), w.n, w.batch), 128, 0, st, Lmat, Dfac, dstride, w.n, w.np, bstride, Lu);
     return check_launch("cache build (LDS-resident draw)");
   }
   if (kernel == 0)
-    hipLaunchKernelGGL(k_Kzz_rbf, dim3(cdiv(w.np, 128), w.np, Do), 128, 0, st, Di, Do, M, w.np, Z, ws + w.ell, ws + w.var, up, A);
+    hipLaunchKernelGGL(k_Kzz_rbf, dim3(cdiv(w.np, 128), w.np, Do), 128, 0, st, Di, Do, M, w.np, Z, ws + w.ell, ws + w.var, up, A, nd);
   else
-    hipLaunchKernelGGL(k_Kzz_df, dim3(cdiv(w.np, 128), w.np, 1), 128, 0, st, Do, M, w.np, Z, ws + w.ell, ws + w.var, up, A);
+    hipLaunchKernelGGL(k_Kzz_df, dim3(cdiv(w.np, 128), w.np, 1), 128, 0, st, Do, M, w.np, Z, ws + w.ell, ws + w.var, up, A, nd);
   cholesky_blocked(A, Lmat, Dfac, w.np, w.nblk, w.batch, info, st, w.n);
   if (check_launch("cholesky")) return 1;
 
-  // nu = L^-T (u - L^-1 u_prior), written to ws, to the optional output and into the pack
+  // nu_l = L^-T (u_l - L^-1 u_prior_l), written to ws, to the optional output and into draw l's pack
   const int u_stride = kernel == 0 ? Do : 1, u_bstride = kernel == 0 ? 1 : 0;
   if (big_factor(w.np)) {
     const int npanel = cdiv(w.n, ST);
     for (int P = npanel - 1; P >= 0; --P)
-      hipLaunchKernelGGL(k_solve_back_panel, dim3(P + 1, w.batch), 256, 0, st, Lmat, w.n, w.np, bstride, Dfac, dstride, ws + w.u,
-                         u_stride, u_bstride, A, ws + w.nu, P, P == npanel - 1 ? 1 : 0);
-    hipLaunchKernelGGL(k_nu_publish, dim3(cdiv(w.n, 256), w.batch), 256, 0, st, w.n, ws + w.nu, nu, kernel, Di, Do, ws + w.var, pack_ind);
+      hipLaunchKernelGGL(k_solve_back_panel, dim3(P + 1, w.batch, nd), 256, 0, st, Lmat, w.n, w.np, bstride, Dfac, dstride, ws + w.u,
+                         u_stride, u_bstride, A, ws + w.nu, P, P == npanel - 1 ? 1 : 0, MD, MD);
+    hipLaunchKernelGGL(k_nu_publish, dim3(cdiv(w.n, 256), w.batch, nd), 256, 0, st, w.n, ws + w.nu, nu, kernel, Di, Do, ws + w.var, pack_ind,
+                       MD, pf);
   } else {
     const size_t lds = sizeof(float) * w.np;
     const int cpt = cdiv(w.n, 1024);  // 4 columns per thread per unit
 #define GP_SOLVE(CPT)                                                                                              \
   do {                                                                                                             \
     if (set_max_lds((const void*)k_solve_back<CPT>, lds)) return 1;                                                \
-    hipLaunchKernelGGL(k_solve_back<CPT>, w.batch, 256, lds, st, Lmat, w.n, w.np, bstride, Dfac, dstride, ws + w.u,   \
-                       u_stride, u_bstride, ws + w.nu, nu, kernel, Di, Do, M, ws + w.var, pack_ind);               \
+    hipLaunchKernelGGL(k_solve_back<CPT>, dim3(w.batch, nd), 256, lds, st, Lmat, w.n, w.np, bstride, Dfac, dstride, ws + w.u,   \
+                       u_stride, u_bstride, ws + w.nu, nu, kernel, Di, Do, M, ws + w.var, pack_ind, MD, MD, pf);   \
   } while (0)
     if (cpt == 1) GP_SOLVE(1);
     else if (cpt == 2) GP_SOLVE(2);

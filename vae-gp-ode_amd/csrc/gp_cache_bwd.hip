@@ -27,13 +27,16 @@ __device__ __forceinline__ float sigmoid_raw(float x) { return x > 20.f ? 1.f : 
 __device__ __forceinline__ float softplus_l(float x) { return (x > 20.f ? x : log1pf(expf(x))) + 1e-12f; }
 
 struct BwsLayout {
-  size_t Dinv, Linv, X, S, vec, gp_rows, vjpZ, slab, gZpart, kpart, gom, total;
-  int n, np, nbn, batch, nchunkZ, kpart_stride;
+  size_t Dinv, Linv, X, S, vec, gp_rows, gu_rows, vjpZ, slab, gZpart, kpart, gom, total;
+  int n, np, nbn, batch, nchunkZ, kpart_stride, nd;
 };
 
-static BwsLayout bws_layout(int kernel, int Di, int Do, int M, int S, size_t pack_floats) {
+// nd Monte-Carlo draws share the factor (ws_layout): the vectors, the f_prior(Z) path and the pack chains are per draw, the
+// triangular inverse / solves, Phi (summed over the draws: the Cholesky backward is linear in it) and the K(Z) backward are not.
+static BwsLayout bws_layout(int kernel, int Di, int Do, int M, int S, size_t pack_floats, int nd) {
   BwsLayout b;
-  const WsLayout w = ws_layout(kernel, Di, Do, M, S);
+  const WsLayout w = ws_layout(kernel, Di, Do, M, S, nd);
+  b.nd = nd;
   b.n = w.n; b.np = w.np; b.batch = w.batch; b.nbn = cdiv(w.n, NB);
   b.nchunkZ = M < 16 ? M : 16;
   size_t o = 0;
@@ -42,26 +45,32 @@ static BwsLayout bws_layout(int kernel, int Di, int Do, int M, int S, size_t pac
   b.Linv = take((size_t)b.batch * b.np * b.np);
   b.X = take((size_t)b.batch * b.np * b.np);
   b.S = take((size_t)b.batch * b.np * b.np);
-  b.vec = take((size_t)6 * b.batch * b.np);
-  b.gp_rows = take((size_t)M * Do);
-  b.vjpZ = take((size_t)M * Di);
-  b.slab = take((size_t)b.nchunkZ * pack_floats);
+  b.vec = take((size_t)6 * nd * b.batch * b.np);
+  b.gp_rows = take((size_t)nd * M * Do);
+  b.gu_rows = take((size_t)nd * M * Do);
+  b.vjpZ = take((size_t)nd * M * Di);
+  b.slab = take((size_t)nd * b.nchunkZ * pack_floats);
   b.gZpart = take((size_t)(kernel == 0 ? Do : 1) * M * Di);
   b.kpart_stride = kernel == 0 ? (1 + Di) : (Do + Do * Do);
   b.kpart = take((size_t)(kernel == 0 ? Do * M : M) * b.kpart_stride);
-  b.gom = take(kernel == 1 ? (size_t)S * Do * Do : 4);
+  b.gom = take(kernel == 1 ? (size_t)nd * S * Do * Do : 4);
   b.total = o;
   return b;
 }
+
+// vector k (0 g_nu, 1 q, 2 a, 3 r, 4 v) of draw l, system b:  [k][draw][system][np]
+#define GP_VEC(base, k, l) ((base) + ((size_t)((k) * nd + (l)) * nb + b) * np)
 
 // ---------------------------------------------------------------------------------------------
 // g_nu from the coefficient fields of the pack gradient
 // ---------------------------------------------------------------------------------------------
 __global__ void k_gnu(int kernel, int Di, int Do, int M, int n, int np, const float* __restrict__ gpack_ind,
-                      const float* __restrict__ var, float* __restrict__ gnu) {
-  const int b = blockIdx.y;
+                      const float* __restrict__ var, float* __restrict__ vec_all, size_t pack_dstride) {
+  const int b = blockIdx.y, nb = gridDim.y, l = blockIdx.z, nd = gridDim.z;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= np) return;
+  gpack_ind += (size_t)l * pack_dstride;
+  float* gnu = GP_VEC(vec_all, 0, l);
   float v = 0.f;
   if (j < n) {
     const int RQ2 = cdiv(Di + Do, 4);
@@ -71,7 +80,7 @@ __global__ void k_gnu(int kernel, int Di, int Do, int M, int n, int np, const fl
     const float gc = gpack_ind[(((size_t)(m >> 6) * RQ2 + (field >> 2)) * 64 + (m & 63)) * 4 + (field & 3)];
     v = kernel == 0 ? gc * var[d] : gc;
   }
-  gnu[(size_t)b * np + j] = v;
+  gnu[j] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -177,31 +186,32 @@ __global__ __launch_bounds__(256) void k_linv_dc(int step, int sb, int npairs, i
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_vec_q(int n, int np, const float* __restrict__ Linv_all, size_t batch_stride,
                                                float* __restrict__ vec_all) {
-  const int b = blockIdx.y, nb = gridDim.y, lane = threadIdx.x & 63;
+  const int b = blockIdx.y, nb = gridDim.y, l = blockIdx.z, nd = gridDim.z, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= np) return;
   const float* Li = Linv_all + (size_t)b * batch_stride + (size_t)i * np;
-  const float* vg = vec_all + (size_t)(0 * nb + b) * np;
+  const float* vg = GP_VEC(vec_all, 0, l);
   float acc = 0.f;
   if (i < n)
     for (int j = lane; j <= i; j += 64) acc = fmaf(Li[j], vg[j], acc);
   const float in1[1] = {acc};
   float out1[1];
   wave_sum_multi<1>(in1, out1);
-  if (lane == 0) vec_all[(size_t)(1 * nb + b) * np + i] = out1[0];
+  if (lane == 0) GP_VEC(vec_all, 1, l)[i] = out1[0];
 }
 
 __global__ __launch_bounds__(256) void k_vec_a(int kernel, int Do, int n, int np, const float* __restrict__ Lall, size_t batch_stride,
                                                const float* __restrict__ Dfac_all, size_t dfac_stride, const float* __restrict__ Linv_all,
-                                               const float* __restrict__ u, float* __restrict__ vec_all, float* __restrict__ g_Um,
-                                               float* __restrict__ gp_rows) {
-  const int b = blockIdx.y, nb = gridDim.y, lane = threadIdx.x & 63;
+                                               const float* __restrict__ u, float* __restrict__ vec_all, float* __restrict__ gu_rows,
+                                               float* __restrict__ gp_rows, size_t u_dstride) {
+  const int b = blockIdx.y, nb = gridDim.y, l = blockIdx.z, nd = gridDim.z, lane = threadIdx.x & 63;
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (j >= np) return;
   const float* Lm = Lall + (size_t)b * batch_stride;
   const float* Li = Linv_all + (size_t)b * batch_stride;
   const float* Dfac = Dfac_all + (size_t)b * dfac_stride;
-  const float* vq = vec_all + (size_t)(1 * nb + b) * np;
+  const float* vq = GP_VEC(vec_all, 1, l);
+  u += (size_t)l * u_dstride; gu_rows += (size_t)l * u_dstride; gp_rows += (size_t)l * u_dstride;
   float acc = 0.f;
   if (j < n)
     for (int i = j + lane; i < n; i += 64) acc = fmaf(Li[(size_t)i * np + j], vq[i], acc);
@@ -212,23 +222,29 @@ __global__ __launch_bounds__(256) void k_vec_a(int kernel, int Do, int n, int np
   const float a = out1[0];
   float y = 0.f, rr = 0.f;
   if (j < n) {
-    const int kl = n / NB, cl = kl * NB;
+    const int rn = n + l, kl = rn / NB, cl = kl * NB;           // draw l's forward-solved rhs is row n + l of the factor
     const int u_stride = kernel == 0 ? Do : 1, u_b = kernel == 0 ? b : 0;
-    y = (j < cl) ? Lm[(size_t)n * np + j] : Dfac[(size_t)kl * NB * NB + (n - cl) * NB + (j - cl)];
+    y = (j < cl) ? Lm[(size_t)rn * np + j] : Dfac[(size_t)kl * NB * NB + (rn - cl) * NB + (j - cl)];
     rr = u[(size_t)j * u_stride + u_b] - y;
     // g_u = q (u element j of batch b lives at u[j*u_stride + u_b]); g_p = -a in the same (M,Do) layout
-    g_Um[(size_t)j * u_stride + u_b] = vq[j];
+    gu_rows[(size_t)j * u_stride + u_b] = vq[j];
     gp_rows[(size_t)j * u_stride + u_b] = -a;
   }
-  vec_all[(size_t)(2 * nb + b) * np + j] = a;
-  vec_all[(size_t)(3 * nb + b) * np + j] = rr;
-  vec_all[(size_t)(4 * nb + b) * np + j] = y;
+  GP_VEC(vec_all, 2, l)[j] = a;
+  GP_VEC(vec_all, 3, l)[j] = rr;
+  GP_VEC(vec_all, 4, l)[j] = y;
 }
 
-// g_Us[d, n(n+1)/2 + m] = g_u[n,d] eps_u[m,d]   (svpy.py:94-100 backward)
-__global__ void k_gUs(int M, int Do, const float* __restrict__ g_u, const float* __restrict__ eps_u, float* __restrict__ g_Us) {
-  const size_t P = (size_t)M * (M + 1) / 2;
+// g_Us[d, n(n+1)/2 + m] = sum_l g_u_l[n,d] eps_u_l[m,d]   (svpy.py:94-100 backward);  g_Um = sum_l g_u_l.  Draws in a fixed order.
+__global__ void k_gUs(int M, int Do, int nd, const float* __restrict__ g_u, const float* __restrict__ eps_u, float* __restrict__ g_Us,
+                      float* __restrict__ g_Um) {
+  const size_t P = (size_t)M * (M + 1) / 2, MD = (size_t)M * Do;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < MD) {
+    float acc = 0.f;
+    for (int l = 0; l < nd; ++l) acc += g_u[l * MD + e];
+    g_Um[e] = acc;
+  }
   if (e >= P * Do) return;
   const int d = (int)(e / P);
   const size_t k = e % P;
@@ -236,7 +252,20 @@ __global__ void k_gUs(int M, int Do, const float* __restrict__ g_u, const float*
   while ((size_t)(nn + 1) * (nn + 2) / 2 <= k) ++nn;
   while ((size_t)nn * (nn + 1) / 2 > k) --nn;
   const int m = (int)(k - (size_t)nn * (nn + 1) / 2);
-  g_Us[e] = g_u[(size_t)nn * Do + d] * eps_u[(size_t)m * Do + d];
+  float acc = 0.f;
+  for (int l = 0; l < nd; ++l) acc = fmaf(g_u[l * MD + (size_t)nn * Do + d], eps_u[l * MD + (size_t)m * Do + d], acc);
+  g_Us[e] = acc;
+}
+
+// Phi[i][j] = sum_l (-r_l[i] q_l[j] + q_l[i] v_l[j]): the Cholesky backward is linear in Phi, so the draws that share the factor are
+// summed HERE, in front of the two triangular products (vectors laid out GP_VEC: [k][draw][system][np])
+__device__ __forceinline__ float phi_sum(const float* __restrict__ vec_all, int nd, int nb, int b, int np, size_t i, size_t j) {
+  float ph = 0.f;
+  for (int l = 0; l < nd; ++l) {
+    const float* vq = GP_VEC(vec_all, 1, l);
+    ph += -GP_VEC(vec_all, 3, l)[i] * vq[j] + vq[i] * GP_VEC(vec_all, 4, l)[j];
+  }
+  return ph;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -247,16 +276,12 @@ __global__ void k_gUs(int M, int Do, const float* __restrict__ g_u, const float*
 // ---------------------------------------------------------------------------------------------
 typedef float tf32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_gemm_phiX(const float* __restrict__ Linv_all, size_t batch_stride, int np, int nbn,
-                                                    const float* __restrict__ vec_all, float* __restrict__ X_all) {
+                                                    const float* __restrict__ vec_all, float* __restrict__ X_all, int nd) {
   __shared__ float sA[NB][NB + 1], sP[NB][NB + 1];
   const int ab = blockIdx.x, jb = blockIdx.y, b = blockIdx.z, nb = gridDim.z;
   const float* Li = Linv_all + (size_t)b * batch_stride;
   float* X = X_all + (size_t)b * batch_stride;
-  const float* vq = vec_all + (size_t)(1 * nb + b) * np;
-  const float* vr = vec_all + (size_t)(3 * nb + b) * np;
-  const float* vv = vec_all + (size_t)(4 * nb + b) * np;
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-  const float qj = vq[jb * NB + tx], vj = vv[jb * NB + tx];         // column quantities of this thread
   const int lane = tid & 63, lr = lane & 15, lk = lane >> 4, mq = (tid >> 6) & 1, nq = tid >> 7;
   tf32x4 macc = tf32x4{0.f, 0.f, 0.f, 0.f};
   float ra[4], rp[4];                                                // next block: Linv tile and the Phi tile generated on the fly
@@ -265,7 +290,7 @@ __global__ __launch_bounds__(256) void k_gemm_phiX(const float* __restrict__ Lin
     for (int q = 0; q < 4; ++q) {
       const int p = ty + 8 * q, gi = ib * NB + p, gj = jb * NB + tx;
       ra[q] = Li[(size_t)gi * np + ab * NB + tx];                    // Linv[i][a]
-      const float ph = -vr[gi] * qj + vq[gi] * vj;
+      const float ph = gi >= gj ? phi_sum(vec_all, nd, nb, b, np, gi, gj) : 0.f;
       rp[q] = gi > gj ? ph : (gi == gj ? 0.5f * ph : 0.f);
     }
   };
@@ -336,15 +361,12 @@ constexpr int GT = 128, GK = 16, GLD = GT + 16;
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const float* __restrict__ A_all, const float* __restrict__ B_all,
                                                        size_t batch_stride, int np, int klim,
-                                                       const float* __restrict__ vec_all, float* __restrict__ C_all) {
+                                                       const float* __restrict__ vec_all, float* __restrict__ C_all, int nd) {
   __shared__ __attribute__((aligned(16))) float sA[GK][GLD], sB[GK][GLD];
   const int tm = blockIdx.x, tn = blockIdx.y, b = blockIdx.z, nb = gridDim.z;
   const float* A = A_all + (size_t)b * batch_stride;
   const float* B = B_all + (size_t)b * batch_stride;
   float* C = C_all + (size_t)b * batch_stride;
-  const float* vq = vec_all + (size_t)(1 * nb + b) * np;
-  const float* vr = vec_all + (size_t)(3 * nb + b) * np;
-  const float* vv = vec_all + (size_t)(4 * nb + b) * np;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4;
   const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
   gf32x4 acc[4][4];
@@ -367,13 +389,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mfma(const float* __restrict__ 
         rb[q] = *reinterpret_cast<const float4*>(&B[gk * np + (size_t)tn * GT + c4]);
       } else {
         ra[q] = *reinterpret_cast<const float4*>(&A[gk * np + (size_t)tm * GT + c4]);   // Linv[i][a]: a contiguous
-        const float ri = vr[gk], qi = vq[gk];
-        float ph[4];
+        float ph[4] = {0.f, 0.f, 0.f, 0.f};
+        const size_t gj0 = (size_t)tn * GT + c4;
+        if (gk >= gj0) {                                              // a quad wholly above the diagonal stays zero
+          for (int l = 0; l < nd; ++l) {
+            const float* vq = GP_VEC(vec_all, 1, l);
+            const float* vv = GP_VEC(vec_all, 4, l);
+            const float ri = GP_VEC(vec_all, 3, l)[gk], qi = vq[gk];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const size_t gj = (size_t)tn * GT + c4 + c;
-          const float v = -ri * vq[gj] + qi * vv[gj];
-          ph[c] = gk > gj ? v : (gk == gj ? 0.5f * v : 0.f);
+            for (int c = 0; c < 4; ++c) ph[c] += -ri * vq[gj0 + c] + qi * vv[gj0 + c];
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ph[c] = gk > gj0 + c ? ph[c] : (gk == gj0 + c ? 0.5f * ph[c] : 0.f);
         }
         rb[q] = make_float4(ph[0], ph[1], ph[2], ph[3]);
       }
@@ -514,7 +541,7 @@ __global__ __launch_bounds__(64 * TNW) void k_trsm_slab(int n, int np, int nbn, 
                                                          const float* __restrict__ Dfac_all, size_t dfac_stride,
                                                          const float* __restrict__ Dinv_all, size_t dinv_stride,
                                                          float* __restrict__ vec_all, const float* __restrict__ Xin_all,
-                                                         float* __restrict__ Out_all) {
+                                                         float* __restrict__ Out_all, int nd) {
   extern __shared__ __attribute__((aligned(16))) float sY[];        // [32 nbn][TSL] slab, then two [32][TSL] scratch tiles
   constexpr bool TRANS = MODE != 0;
   constexpr int NT = 64 * TNW;
@@ -522,12 +549,10 @@ __global__ __launch_bounds__(64 * TNW) void k_trsm_slab(int n, int np, int nbn, 
   const float* Lm = Lall + (size_t)b * batch_stride;
   const float* Dfac = Dfac_all + (size_t)b * dfac_stride;
   const float* Dinv = Dinv_all + (size_t)b * dinv_stride;
-  const float* vg = vec_all + (size_t)(0 * nb + b) * np;
-  const float* vq = vec_all + (size_t)(1 * nb + b) * np;
-  const float* vr = vec_all + (size_t)(3 * nb + b) * np;
-  const float* vv = vec_all + (size_t)(4 * nb + b) * np;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lk = lane >> 4;
-  const int nrow = nbn * NB, c0 = slab * TSW, nslab = (nrow + TSW - 1) / TSW;   // MODE 1: slab nslab carries q
+  // MODE 0: slab s carries g_nu of the draws 16 s .. 16 s + 15 (one column each); MODE 1: slabs >= nslab carry their q likewise
+  const int nrow = nbn * NB, c0 = slab * TSW, nslab = (nrow + TSW - 1) / TSW;
+  const int l0 = (MODE == 0 ? slab : slab - nslab) * TSW;            // first draw of a vector slab
   float* sT0 = sY + (size_t)nrow * TSL;              // first solution y0 of the diagonal step
   float* sT1 = sT0 + NB * TSL;                       // its residual
   // ---- right-hand sides -------------------------------------------------------------------
@@ -535,14 +560,14 @@ __global__ __launch_bounds__(64 * TNW) void k_trsm_slab(int n, int np, int nbn, 
     float v = 0.f;
     if (MODE == 0) {
       const int i = e / TSW, c = e % TSW;
-      if (c == 0 && i < n) v = vg[i];
+      if (l0 + c < nd && i < n) v = GP_VEC(vec_all, 0, l0 + c)[i];
       sY[i * TSL + c] = v;
     } else if (MODE == 1) {
       const int i = e / TSW, c = e % TSW, gj = c0 + c;
-      if (slab == nslab) { if (c == 0 && i < n) v = vq[i]; }
-      else if (i < n && gj < n) {
-        const float ph = -vr[i] * vq[gj] + vq[i] * vv[gj];
-        v = i > gj ? ph : (i == gj ? 0.5f * ph : 0.f);
+      if (slab >= nslab) { if (l0 + c < nd && i < n) v = GP_VEC(vec_all, 1, l0 + c)[i]; }
+      else if (i < n && gj < n && i >= gj) {
+        const float ph = phi_sum(vec_all, nd, nb, b, np, i, gj);
+        v = i > gj ? ph : 0.5f * ph;
       }
       sY[i * TSL + c] = v;
     } else {                                         // B[i][c] = X[c0 + c][i]: walk X's rows (i contiguous)
@@ -662,10 +687,12 @@ __global__ __launch_bounds__(64 * TNW) void k_trsm_slab(int n, int np, int nbn, 
   }
   // ---- results -------------------------------------------------------------------------------
   if (MODE == 0) {
-    for (int i = tid; i < np; i += NT) vec_all[(size_t)(1 * nb + b) * np + i] = i < n ? sY[i * TSL] : 0.f;
+    for (int c = 0; c < TSW && l0 + c < nd; ++c)
+      for (int i = tid; i < np; i += NT) GP_VEC(vec_all, 1, l0 + c)[i] = i < n ? sY[i * TSL + c] : 0.f;
   } else if (MODE == 1) {
-    if (slab == nslab) {
-      for (int i = tid; i < np; i += NT) vec_all[(size_t)(2 * nb + b) * np + i] = i < n ? sY[i * TSL] : 0.f;
+    if (slab >= nslab) {
+      for (int c = 0; c < TSW && l0 + c < nd; ++c)
+        for (int i = tid; i < np; i += NT) GP_VEC(vec_all, 2, l0 + c)[i] = i < n ? sY[i * TSL + c] : 0.f;
     } else {
       float* X = Out_all + (size_t)b * batch_stride;
       for (int e = tid; e < nrow * TSW; e += NT) {
@@ -686,24 +713,26 @@ __global__ __launch_bounds__(64 * TNW) void k_trsm_slab(int n, int np, int nbn, 
 // its product with the explicit inverse); one thread per element
 __global__ void k_vec_rv(int kernel, int Do, int n, int np, const float* __restrict__ Lall, size_t batch_stride,
                          const float* __restrict__ Dfac_all, size_t dfac_stride, const float* __restrict__ u,
-                         float* __restrict__ vec_all, int with_a, float* __restrict__ g_Um, float* __restrict__ gp_rows) {
-  const int b = blockIdx.y, nb = gridDim.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+                         float* __restrict__ vec_all, int with_a, float* __restrict__ gu_rows, float* __restrict__ gp_rows,
+                         size_t u_dstride) {
+  const int b = blockIdx.y, nb = gridDim.y, l = blockIdx.z, nd = gridDim.z, j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= np) return;
   const float* Lm = Lall + (size_t)b * batch_stride;
   const float* Dfac = Dfac_all + (size_t)b * dfac_stride;
   const int u_stride = kernel == 0 ? Do : 1, u_b = kernel == 0 ? b : 0;
+  u += (size_t)l * u_dstride; gu_rows += (size_t)l * u_dstride; gp_rows += (size_t)l * u_dstride;
   if (!with_a) {
     float y = 0.f, rr = 0.f;
     if (j < n) {
-      const int kl = n / NB, cl = kl * NB;
-      y = (j < cl) ? Lm[(size_t)n * np + j] : Dfac[(size_t)kl * NB * NB + (n - cl) * NB + (j - cl)];
+      const int rn = n + l, kl = rn / NB, cl = kl * NB;        // draw l's forward-solved rhs is row n + l of the factor
+      y = (j < cl) ? Lm[(size_t)rn * np + j] : Dfac[(size_t)kl * NB * NB + (rn - cl) * NB + (j - cl)];
       rr = u[(size_t)j * u_stride + u_b] - y;
     }
-    vec_all[(size_t)(3 * nb + b) * np + j] = rr;
-    vec_all[(size_t)(4 * nb + b) * np + j] = y;
+    GP_VEC(vec_all, 3, l)[j] = rr;
+    GP_VEC(vec_all, 4, l)[j] = y;
   } else if (j < n) {
-    g_Um[(size_t)j * u_stride + u_b] = vec_all[(size_t)(1 * nb + b) * np + j];
-    gp_rows[(size_t)j * u_stride + u_b] = -vec_all[(size_t)(2 * nb + b) * np + j];
+    gu_rows[(size_t)j * u_stride + u_b] = GP_VEC(vec_all, 1, l)[j];
+    gp_rows[(size_t)j * u_stride + u_b] = -GP_VEC(vec_all, 2, l)[j];
   }
 }
 
@@ -845,17 +874,16 @@ __device__ __forceinline__ float rec_field(const float* __restrict__ base, size_
 
 // RBF: one workgroup per output scalar (Do * Di lengthscales, Do variances), threads over the summation index, fixed-order
 // reduction; the remaining workgroups assemble g_Z.  g_ell[d,i], g_var[d] -> raw.
-__global__ __launch_bounds__(256) void k_chain_rbf(int Di, int Do, int M, int S, const float* __restrict__ pack,
-                                                    const float* __restrict__ gpack, const float* __restrict__ raw_ell,
-                                                    const float* __restrict__ raw_var, const float* __restrict__ nu,
-                                                    const float* __restrict__ vjpZ, const float* __restrict__ gZpart,
+__global__ __launch_bounds__(256) void k_chain_rbf(int Di, int Do, int M, int S, const float* __restrict__ pack_all,
+                                                    const float* __restrict__ gpack_all, const float* __restrict__ raw_ell,
+                                                    const float* __restrict__ raw_var, const float* __restrict__ nu_all,
+                                                    const float* __restrict__ vjpZ_all, const float* __restrict__ gZpart,
                                                     const float* __restrict__ kpart,
                                                     float* __restrict__ g_raw_ell, float* __restrict__ g_raw_var,
-                                                    float* __restrict__ g_Z) {
+                                                    float* __restrict__ g_Z, int nd, size_t pack_dstride) {
+  // the pack chains of the nd draws (each with its own frequencies, weights and nu) are summed draw by draw in a fixed order
   const int RQ = cdiv(Di + 2, 4), RQ2 = cdiv(Di + Do, 4), SJ = cdiv(S, 64), MJ = cdiv(M, 64);
   const size_t rff_f4 = (size_t)SJ * Do * RQ * 64, ind_f4 = (size_t)MJ * RQ2 * 64;
-  const float* gind = gpack + 4 * rff_f4;
-  const float* guni = gpack + 4 * (rff_f4 + ind_f4);
   const int tid = threadIdx.x, blk = blockIdx.x;
   __shared__ float red[4];
   auto block_sum = [&](float v) {                    // every thread gets the total
@@ -868,32 +896,41 @@ __global__ __launch_bounds__(256) void k_chain_rbf(int Di, int Do, int M, int S,
   if (blk < Do * Di) {
     const int e = blk, d = e / Di, i = e % Di;
     const float l = softplus_l(raw_ell[e]);
-    float g = 0.f;
-    for (int s = tid; s < S; s += 256) {
-      const size_t base = (size_t)((s >> 6) * Do + d) * RQ;
-      g = fmaf(rec_field(gpack, base, s & 63, i), -rec_field(pack, base, s & 63, i) / l, g);  // om = eps/(2 pi l)
+    float g = 0.f, gu = 0.f;
+    for (int dr = 0; dr < nd; ++dr) {
+      const float* pack = pack_all + (size_t)dr * pack_dstride;
+      const float* gpack = gpack_all + (size_t)dr * pack_dstride;
+      for (int s = tid; s < S; s += 256) {
+        const size_t base = (size_t)((s >> 6) * Do + d) * RQ;
+        g = fmaf(rec_field(gpack, base, s & 63, i), -rec_field(pack, base, s & 63, i) / l, g);  // om = eps/(2 pi l)
+      }
+      gu += gpack[4 * (rff_f4 + ind_f4) + e];
     }
     float k = 0.f;
     for (int n = tid; n < M; n += 256) k += kpart[((size_t)d * M + n) * (1 + Di) + 1 + i];
     g = block_sum(g);
     k = block_sum(k);
     if (tid == 0) {
-      g = fmaf(guni[e], GP_LOG2E / (l * l * l), g);                                           // wl = -log2e/(2 l^2)
+      g = fmaf(gu, GP_LOG2E / (l * l * l), g);                                                // wl = -log2e/(2 l^2)
       g_raw_ell[e] = (g + k) * sigmoid_raw(raw_ell[e]);
     }
   } else if (blk < Do * Di + Do) {
     const int d = blk - Do * Di;
     const float v = softplus_l(raw_var[d]);
-    float g = 0.f;
-    for (int s = tid; s < S; s += 256) {
-      const size_t base = (size_t)((s >> 6) * Do + d) * RQ;
-      g = fmaf(rec_field(gpack, base, s & 63, Di + 1), rec_field(pack, base, s & 63, Di + 1) / (2.f * v), g);  // aw = sqrt(v/S) w
+    float g = 0.f, c = 0.f, k = 0.f;
+    for (int dr = 0; dr < nd; ++dr) {
+      const float* pack = pack_all + (size_t)dr * pack_dstride;
+      const float* gpack = gpack_all + (size_t)dr * pack_dstride;
+      const float* gind = gpack + 4 * rff_f4;
+      const float* nu = nu_all + (size_t)dr * Do * M;
+      for (int s = tid; s < S; s += 256) {
+        const size_t base = (size_t)((s >> 6) * Do + d) * RQ;
+        g = fmaf(rec_field(gpack, base, s & 63, Di + 1), rec_field(pack, base, s & 63, Di + 1) / (2.f * v), g);  // aw = sqrt(v/S) w
+      }
+      for (int m = tid; m < M; m += 256)
+        c = fmaf(rec_field(gind, (size_t)(m >> 6) * RQ2, m & 63, Di + d), nu[(size_t)d * M + m], c);             // cc = v nu
     }
-    float c = 0.f, k = 0.f;
-    for (int m = tid; m < M; m += 256) {
-      c = fmaf(rec_field(gind, (size_t)(m >> 6) * RQ2, m & 63, Di + d), nu[(size_t)d * M + m], c);             // cc = v nu
-      k += kpart[((size_t)d * M + m) * (1 + Di)];
-    }
+    for (int m = tid; m < M; m += 256) k += kpart[((size_t)d * M + m) * (1 + Di)];
     g = block_sum(g);
     c = block_sum(c);
     k = block_sum(k);
@@ -902,7 +939,9 @@ __global__ __launch_bounds__(256) void k_chain_rbf(int Di, int Do, int M, int S,
     const int e = (blk - Do * Di - Do) * 256 + tid;
     if (e < M * Di) {
       const int m = e / Di, i = e % Di;
-      float g = rec_field(gind, (size_t)(m >> 6) * RQ2, m & 63, i) + vjpZ[e];
+      float g = 0.f;
+      for (int dr = 0; dr < nd; ++dr)
+        g += rec_field(gpack_all + (size_t)dr * pack_dstride + 4 * rff_f4, (size_t)(m >> 6) * RQ2, m & 63, i) + vjpZ_all[(size_t)dr * M * Di + e];
       for (int d = 0; d < Do; ++d) g += gZpart[((size_t)d * M + m) * Di + i];
       g_Z[e] = g;
     }
@@ -915,9 +954,11 @@ __global__ __launch_bounds__(256) void k_chain_rbf(int Di, int Do, int M, int S,
 // was 0.87 ms at D = 16 -- four 64-thread workgroups, spilling -- and 13 us on the critical tail of the step at D = 6).
 template <int D>
 __global__ __launch_bounds__(((D * D + 63) / 64) * 64) void k_df_gomega(int S, const float* __restrict__ pack, const float* __restrict__ gpack,
-                                                                         const float* __restrict__ var, float* __restrict__ gom) {
+                                                                         const float* __restrict__ var, float* __restrict__ gom,
+                                                                         size_t pack_dstride) {
   constexpr int RQ = cdiv(2 * D + 3, 4);
   __shared__ float om[D][D + 1], gB[D][D + 1], G[D][D + 1], nrm[D];   // om[p][q] = omega[p,s,q]
+  pack += blockIdx.y * pack_dstride; gpack += blockIdx.y * pack_dstride; gom += (size_t)blockIdx.y * S * D * D;   // blockIdx.y = draw
   const int s = blockIdx.x, t = threadIdx.x;
   const int lane = s & 63, j0 = s >> 6;
   const bool on = t < D * D;
@@ -962,17 +1003,15 @@ __global__ __launch_bounds__(((D * D + 63) / 64) * 64) void k_df_gomega(int S, c
 // DF step 2: chain rule to the raw parameters.  One workgroup per output scalar (D*D lengthscales, D variances),
 // threads over the summation index, fixed-order reduction; the remaining workgroups assemble g_Z.
 template <int D>
-__global__ __launch_bounds__(256) void k_chain_df(int M, int S, const float* __restrict__ pack, const float* __restrict__ gpack,
+__global__ __launch_bounds__(256) void k_chain_df(int M, int S, const float* __restrict__ pack_all, const float* __restrict__ gpack_all,
                                                    const float* __restrict__ raw_ell, const float* __restrict__ raw_var,
-                                                   const float* __restrict__ gom, const float* __restrict__ vjpZ,
+                                                   const float* __restrict__ gom_all, const float* __restrict__ vjpZ_all,
                                                    const float* __restrict__ gZpart, const float* __restrict__ kpart,
                                                    float* __restrict__ g_raw_ell, float* __restrict__ g_raw_var,
-                                                   float* __restrict__ g_Z) {
+                                                   float* __restrict__ g_Z, int nd, size_t pack_dstride) {
   constexpr int RQ = cdiv(2 * D + 3, 4), RQ2 = cdiv(2 * D, 4);
   const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
   const size_t rff_f4 = (size_t)SJ * D * RQ * 64, ind_f4 = (size_t)MJ * RQ2 * 64;
-  const float* gind = gpack + 4 * rff_f4;
-  const float* guni = gpack + 4 * (rff_f4 + ind_f4);
   const int tid = threadIdx.x, blk = blockIdx.x;
   __shared__ float red[4];
   auto block_sum = [&](float v) {                    // every thread gets the total
@@ -987,11 +1026,18 @@ __global__ __launch_bounds__(256) void k_chain_df(int M, int S, const float* __r
   if (blk < D * D) {
     const int e = blk, a = e / D, b = e % D;         // ell[a][b]; omega[k,s,i] = eps/ell[i][k] -> entry (a,b) <- omega[b,s,a]
     const float l = softplus_l(raw_ell[e]);
-    float g = 0.f;
-    for (int s = tid; s < S; s += 256) {
-      const size_t base = (size_t)((s >> 6) * D + a) * RQ;                // record (s, i=a), field k=b
-      const float om = rec_field(pack, base, s & 63, b) * GP_2PI;         // omega[b,s,a]
-      g = fmaf(gom[(size_t)s * D * D + b * D + a], -om / l, g);
+    float g = 0.f, gu0 = 0.f, gu1 = 0.f;
+    for (int dr = 0; dr < nd; ++dr) {                // the draws (own frequencies each) in a fixed order
+      const float* pack = pack_all + (size_t)dr * pack_dstride;
+      const float* guni = gpack_all + (size_t)dr * pack_dstride + 4 * (rff_f4 + ind_f4);
+      const float* gom = gom_all + (size_t)dr * S * D * D;
+      for (int s = tid; s < S; s += 256) {
+        const size_t base = (size_t)((s >> 6) * D + a) * RQ;                // record (s, i=a), field k=b
+        const float om = rec_field(pack, base, s & 63, b) * GP_2PI;         // omega[b,s,a]
+        g = fmaf(gom[(size_t)s * D * D + b * D + a], -om / l, g);
+      }
+      gu0 += guni[e];
+      gu1 += guni[D * D + e];
     }
     float k = 0.f;
     for (int n = tid; n < M; n += 256) k += kpart[(size_t)n * (D + D * D) + D + e];
@@ -999,28 +1045,36 @@ __global__ __launch_bounds__(256) void k_chain_df(int M, int S, const float* __r
     k = block_sum(k);
     if (tid == 0) {
       const float l3 = l * l * l;
-      g = fmaf(guni[e], GP_LOG2E / l3, g);           // wab = -log2e/(2 l^2)
-      g = fmaf(guni[D * D + e], -2.f / l3, g);       // il2 = 1/l^2
+      g = fmaf(gu0, GP_LOG2E / l3, g);               // wab = -log2e/(2 l^2)
+      g = fmaf(gu1, -2.f / l3, g);                   // il2 = 1/l^2
       g_raw_ell[e] = (g + k) * sigmoid_raw(raw_ell[e]);
     }
   } else if (blk < D * D + D) {
     const int j = blk - D * D;
     const float v = softplus_l(raw_var[j]);
-    float g = 0.f;
-    for (int q = tid; q < S * D; q += 256) {
-      const int s = q / D, i = q % D;
-      const size_t base = (size_t)((s >> 6) * D + i) * RQ;
-      g = fmaf(rec_field(gpack, base, s & 63, D + 3 + j), rec_field(pack, base, s & 63, D + 3 + j) / (2.f * v), g);  // bs = B sqrt(v/S)
+    float g = 0.f, gu = 0.f;
+    for (int dr = 0; dr < nd; ++dr) {
+      const float* pack = pack_all + (size_t)dr * pack_dstride;
+      const float* gpack = gpack_all + (size_t)dr * pack_dstride;
+      for (int q = tid; q < S * D; q += 256) {
+        const int s = q / D, i = q % D;
+        const size_t base = (size_t)((s >> 6) * D + i) * RQ;
+        g = fmaf(rec_field(gpack, base, s & 63, D + 3 + j), rec_field(pack, base, s & 63, D + 3 + j) / (2.f * v), g);  // bs = B sqrt(v/S)
+      }
+      gu += gpack[4 * (rff_f4 + ind_f4) + 2 * D * D + j];
     }
     float k = 0.f;
     for (int n = tid; n < M; n += 256) k += kpart[(size_t)n * (D + D * D) + j];
     g = block_sum(g);
     k = block_sum(k);
-    if (tid == 0) g_raw_var[j] = (guni[2 * D * D + j] + g + k) * sigmoid_raw(raw_var[j]);
+    if (tid == 0) g_raw_var[j] = (gu + g + k) * sigmoid_raw(raw_var[j]);
   } else {
     for (int e = (blk - D * D - D) * 256 + tid; e < M * D; e += (gridDim.x - D * D - D) * 256) {
       const int m = e / D, i = e % D;
-      g_Z[e] = rec_field(gind, (size_t)(m >> 6) * RQ2, m & 63, i) + vjpZ[e] + gZpart[e];
+      float g = 0.f;
+      for (int dr = 0; dr < nd; ++dr)
+        g += rec_field(gpack_all + (size_t)dr * pack_dstride + 4 * rff_f4, (size_t)(m >> 6) * RQ2, m & 63, i) + vjpZ_all[(size_t)dr * M * D + e];
+      g_Z[e] = g + gZpart[e];
     }
   }
 }
@@ -1046,21 +1100,21 @@ static inline bool use_trsm(int np) {
   return g_solves_mode == 1 ? np <= kTrsmMaxNp : np <= 192;
 }
 
-int cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, size_t* bws_floats) {
+int cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, int nd, size_t* bws_floats) {
   size_t pf = 0;
   if (cache_sizes(kernel, Di, Do, M, S, &pf, nullptr)) return 1;
-  *bws_floats = bws_layout(kernel, Di, Do, M, S, pf).total;
+  *bws_floats = bws_layout(kernel, Di, Do, M, S, pf, nd).total;
   return 0;
 }
 
 // The gradient-independent part of the cache backward: L^-1 from the factor the forward left in ws.  It needs nothing
 // from the backward pass, so a caller may run it any time after the forward (e.g. on a side stream under the decoder)
-// and pass prepared = 1 to cache_build_bwd with the same bws.
-int cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, const float* ws, float* bws, hipStream_t st) {
+// and pass prepared = 1 to cache_build_bwd with the same bws.  (nd only locates the factor in ws: it is shared by the draws.)
+int cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, int nd, const float* ws, float* bws, hipStream_t st) {
   size_t pf = 0;
   if (cache_sizes(kernel, Di, Do, M, S, &pf, nullptr)) return 1;
-  const WsLayout w = ws_layout(kernel, Di, Do, M, S);
-  const BwsLayout b = bws_layout(kernel, Di, Do, M, S, pf);
+  const WsLayout w = ws_layout(kernel, Di, Do, M, S, nd);
+  const BwsLayout b = bws_layout(kernel, Di, Do, M, S, pf, nd);
   const float* Lmat = ws + w.Lmat;
   const float* Dfac = ws + w.Dfac;
   const size_t bstride = (size_t)w.np * w.np, dstride = (size_t)w.nblk * NB * NB, dinv_stride = (size_t)b.nbn * NB * NB;
@@ -1081,64 +1135,69 @@ int cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, const float* ws,
   return check_launch("cache bwd: L^-1");
 }
 
-int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_ell, const float* raw_var, const float* Z,
+// nd draws that shared one cache build: gpack, pack, eps_u are stacked along a leading draw axis; the parameter gradients
+// come out summed over the draws (what autograd accumulates over the `for l in range(L)` loop of odegpvae.py:41-43).
+int cache_build_bwd(int kernel, int Di, int Do, int M, int S, int nd, const float* raw_ell, const float* raw_var, const float* Z,
                     const float* eps_u, const float* pack, const float* ws, float* gpack, float* bws,
                     float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, int prepared, hipStream_t st) {
   size_t pf = 0;
   if (cache_sizes(kernel, Di, Do, M, S, &pf, nullptr)) return 1;
   if (Di > 16 || Do > 16) return set_error("gpode_cache_build_bwd: D <= 16");
-  const WsLayout w = ws_layout(kernel, Di, Do, M, S);
-  const BwsLayout b = bws_layout(kernel, Di, Do, M, S, pf);
+  const WsLayout w = ws_layout(kernel, Di, Do, M, S, nd);
+  const BwsLayout b = bws_layout(kernel, Di, Do, M, S, pf, nd);
   const size_t SJ = cdiv(S, 64), MJ = cdiv(M, 64);
   const size_t rff_f4 = (kernel == 0 ? SJ * Do * cdiv(Di + 2, 4) : SJ * Do * cdiv(2 * Do + 3, 4)) * 64;
   const float* gpack_ind = gpack + 4 * rff_f4;
   const float* Lmat = ws + w.Lmat;
   const float* Dfac = ws + w.Dfac;
   const size_t bstride = (size_t)w.np * w.np, dstride = (size_t)w.nblk * NB * NB, dinv_stride = (size_t)b.nbn * NB * NB;
+  const size_t MD = (size_t)M * Do;                  // per-draw stride of u / g_u / g_p rows
   float* vec = bws + b.vec;
   (void)MJ;
 
-  hipLaunchKernelGGL(k_gnu, dim3(cdiv(b.np, 128), b.batch), 128, 0, st, kernel, Di, Do, M, b.n, b.np, gpack_ind, ws + w.var, vec);
-  if (!prepared && cache_bwd_prepare(kernel, Di, Do, M, S, ws, bws, st)) return 1;
+  hipLaunchKernelGGL(k_gnu, dim3(cdiv(b.np, 128), b.batch, nd), 128, 0, st, kernel, Di, Do, M, b.n, b.np, gpack_ind, ws + w.var, vec, pf);
+  if (!prepared && cache_bwd_prepare(kernel, Di, Do, M, S, nd, ws, bws, st)) return 1;
   const bool solves = use_trsm(b.np);
   const size_t trsm_lds = sizeof(float) * (size_t)(b.nbn + 2) * NB * TSL;
-  const int nslab = (b.nbn * NB + TSW - 1) / TSW;
+  const int nslab = (b.nbn * NB + TSW - 1) / TSW, vslab = cdiv(nd, TSW);     // slabs of Phi columns; slabs of per-draw vectors
   if (solves) {
     // triangular solves with the factor (torch's route); L^-1 is never formed
     if (set_max_lds((const void*)k_trsm_slab<0>, trsm_lds) || set_max_lds((const void*)k_trsm_slab<1>, trsm_lds) ||
         set_max_lds((const void*)k_trsm_slab<2>, trsm_lds)) return 1;
-    hipLaunchKernelGGL(k_vec_rv, dim3(cdiv(b.np, 128), b.batch), 128, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, ws + w.u, vec,
-                       0, g_Um, bws + b.gp_rows);
-    hipLaunchKernelGGL(k_trsm_slab<0>, dim3(1, b.batch), 64 * TNW, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, Dfac, dstride, bws + b.Dinv, dinv_stride, vec,
-                       (const float*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL(k_trsm_slab<1>, dim3(nslab + 1, b.batch), 64 * TNW, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, Dfac, dstride, bws + b.Dinv, dinv_stride,
-                       vec, (const float*)nullptr, bws + b.X);
-    hipLaunchKernelGGL(k_vec_rv, dim3(cdiv(b.np, 128), b.batch), 128, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, ws + w.u, vec,
-                       1, g_Um, bws + b.gp_rows);
+    hipLaunchKernelGGL(k_vec_rv, dim3(cdiv(b.np, 128), b.batch, nd), 128, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, ws + w.u, vec,
+                       0, bws + b.gu_rows, bws + b.gp_rows, MD);
+    hipLaunchKernelGGL(k_trsm_slab<0>, dim3(vslab, b.batch), 64 * TNW, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, Dfac, dstride, bws + b.Dinv, dinv_stride, vec,
+                       (const float*)nullptr, (float*)nullptr, nd);
+    hipLaunchKernelGGL(k_trsm_slab<1>, dim3(nslab + vslab, b.batch), 64 * TNW, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, Dfac, dstride, bws + b.Dinv, dinv_stride,
+                       vec, (const float*)nullptr, bws + b.X, nd);
+    hipLaunchKernelGGL(k_vec_rv, dim3(cdiv(b.np, 128), b.batch, nd), 128, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, ws + w.u, vec,
+                       1, bws + b.gu_rows, bws + b.gp_rows, MD);
   } else {
-    hipLaunchKernelGGL(k_vec_q, dim3(cdiv(b.np, 4), b.batch), 256, 0, st, b.n, b.np, bws + b.Linv, bstride, vec);
-    hipLaunchKernelGGL(k_vec_a, dim3(cdiv(b.np, 4), b.batch), 256, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, bws + b.Linv,
-                       ws + w.u, vec, g_Um, bws + b.gp_rows);
+    hipLaunchKernelGGL(k_vec_q, dim3(cdiv(b.np, 4), b.batch, nd), 256, 0, st, b.n, b.np, bws + b.Linv, bstride, vec);
+    hipLaunchKernelGGL(k_vec_a, dim3(cdiv(b.np, 4), b.batch, nd), 256, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, bws + b.Linv,
+                       ws + w.u, vec, bws + b.gu_rows, bws + b.gp_rows, MD);
   }
   if (check_launch("cache bwd: solves")) return 1;
   {
-    const size_t P = (size_t)M * (M + 1) / 2 * Do;
-    hipLaunchKernelGGL(k_gUs, (unsigned)((P + 255) / 256), 256, 0, st, M, Do, g_Um, eps_u, g_Us);
+    const size_t P = (size_t)M * (M + 1) / 2 * Do;   // >= M * Do: the same launch sums g_Um
+    hipLaunchKernelGGL(k_gUs, (unsigned)((P + 255) / 256), 256, 0, st, M, Do, nd, bws + b.gu_rows, eps_u, g_Us, g_Um);
   }
-  // f_prior(Z) path: d/dZ and parameter gradients (prior only), added to the pack gradient
-  if (rhs_vjp(kernel, Di, Do, M, S, pack, Z, bws + b.gp_rows, M, bws + b.vjpZ, 1, st)) return 1;
-  if (param_grad(kernel, Di, Do, M, S, pack, Z, bws + b.gp_rows, M, bws + b.slab, b.nchunkZ, gpack, 1, 1, st)) return 1;
-  // g_K = sym(L^-T Phi L^-1)
+  // f_prior(Z) path, every draw through its own pack: d/dZ and parameter gradients (prior only), added to the pack gradient
+  Draws dv; dv.nd = nd; dv.pack = pf; dv.in = 0; dv.in2 = MD; dv.out = (size_t)M * Di;
+  if (rhs_vjp(kernel, Di, Do, M, S, pack, Z, bws + b.gp_rows, M, bws + b.vjpZ, 1, st, dv)) return 1;
+  Draws dp; dp.nd = nd; dp.pack = pf; dp.in = 0; dp.in2 = MD; dp.out = pf;
+  if (param_grad(kernel, Di, Do, M, S, pack, Z, bws + b.gp_rows, M, bws + b.slab, b.nchunkZ, gpack, 1, 1, st, dp)) return 1;
+  // g_K = sym(L^-T Phi L^-1), Phi summed over the draws
   if (solves) {                      // X = L^-T Phi is there already; S^T = L^-T X^T (the consumer symmetrises S)
     hipLaunchKernelGGL(k_trsm_slab<2>, dim3(nslab, b.batch), 64 * TNW, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, Dfac, dstride, bws + b.Dinv, dinv_stride, vec,
-                       bws + b.X, bws + b.S);
+                       bws + b.X, bws + b.S, nd);
   } else if (big_factor(b.np)) {     // big factor: both products on the matrix cores
     const int klim = b.nbn * NB, nt = cdiv(klim, GT);
     const dim3 grid(nt, nt, b.batch);                // column tile on the slow axis: the longest k ranges start first
-    hipLaunchKernelGGL(k_gemm_mfma<1>, grid, 256, 0, st, bws + b.Linv, bws + b.Linv, bstride, b.np, klim, vec, bws + b.X);
-    hipLaunchKernelGGL(k_gemm_mfma<0>, grid, 256, 0, st, bws + b.X, bws + b.Linv, bstride, b.np, klim, vec, bws + b.S);
+    hipLaunchKernelGGL(k_gemm_mfma<1>, grid, 256, 0, st, bws + b.Linv, bws + b.Linv, bstride, b.np, klim, vec, bws + b.X, nd);
+    hipLaunchKernelGGL(k_gemm_mfma<0>, grid, 256, 0, st, bws + b.X, bws + b.Linv, bstride, b.np, klim, vec, bws + b.S, nd);
   } else {
-    hipLaunchKernelGGL(k_gemm_phiX, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, bws + b.Linv, bstride, b.np, b.nbn, vec, bws + b.X);
+    hipLaunchKernelGGL(k_gemm_phiX, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, bws + b.Linv, bstride, b.np, b.nbn, vec, bws + b.X, nd);
     hipLaunchKernelGGL(k_gemm_S, dim3(b.nbn, b.nbn, b.batch), 256, 0, st, bws + b.X, bws + b.Linv, bstride, b.np, b.nbn, bws + b.S);
   }
   if (check_launch("cache bwd: gK")) return 1;
@@ -1146,16 +1205,16 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_e
     hipLaunchKernelGGL(k_Kbwd_rbf, dim3(M, Do), 64, 0, st, Di, Do, M, b.np, Z, ws + w.ell, ws + w.var, bws + b.S,
                        bws + b.gZpart, bws + b.kpart);
     hipLaunchKernelGGL(k_chain_rbf, Do * Di + Do + cdiv(M * Di, 256), 256, 0, st, Di, Do, M, S, pack, gpack, raw_ell, raw_var, ws + w.nu,
-                       bws + b.vjpZ, bws + b.gZpart, bws + b.kpart, g_raw_ell, g_raw_var, g_Z);
+                       bws + b.vjpZ, bws + b.gZpart, bws + b.kpart, g_raw_ell, g_raw_var, g_Z, nd, pf);
     return check_launch("cache bwd: chain");
   }
 #define X(D_)                                                                                                              \
   if (Do == D_) {                                                                                                          \
     hipLaunchKernelGGL(k_Kbwd_df<D_>, M, 64, 0, st, M, b.np, Z, ws + w.ell, ws + w.var, bws + b.S, bws + b.gZpart,         \
                        bws + b.kpart);                                                                                     \
-    hipLaunchKernelGGL(k_df_gomega<D_>, S, ((D_ * D_ + 63) / 64) * 64, 0, st, S, pack, gpack, ws + w.var, bws + b.gom);                  \
+    hipLaunchKernelGGL(k_df_gomega<D_>, dim3(S, nd), ((D_ * D_ + 63) / 64) * 64, 0, st, S, pack, gpack, ws + w.var, bws + b.gom, pf);    \
     hipLaunchKernelGGL(k_chain_df<D_>, D_ * D_ + D_ + cdiv(M * D_, 256), 256, 0, st, M, S, pack, gpack, raw_ell, raw_var, bws + b.gom, bws + b.vjpZ,      \
-                       bws + b.gZpart, bws + b.kpart, g_raw_ell, g_raw_var, g_Z);                                          \
+                       bws + b.gZpart, bws + b.kpart, g_raw_ell, g_raw_var, g_Z, nd, pf);                                  \
     return check_launch("cache bwd: chain df");                                                                            \
   }
   X(6) X(4) X(2) X(3) X(8) X(16)

@@ -153,7 +153,8 @@ __device__ __forceinline__ void stage_pack_lds(const float* pack, size_t n_f4) {
 // x (N,DI) -> f (N,DO); one wave per row, grid-stride over rows.
 template <class EV, int DI, int DO, bool USE_LDS>
 __global__ __launch_bounds__(256) void rhs_kernel(const float* __restrict__ pack, int M, int S, size_t lds_f4,
-                           const float* __restrict__ x, int N, float* __restrict__ f, int mode) {
+                           const float* __restrict__ x, int N, float* __restrict__ f, int mode, Draws dw) {
+  pack += blockIdx.y * dw.pack; x += blockIdx.y * dw.in; f += blockIdx.y * dw.out;      // blockIdx.y = Monte-Carlo draw
   if (USE_LDS) stage_pack_lds(pack, lds_f4);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
@@ -203,9 +204,11 @@ template <int DI> __device__ __forceinline__ void store_state(float* __restrict_
 template <class EV, int DI, int DO, int ORDER, int METHOD, bool USE_LDS>
 __global__ __launch_bounds__(256) void rollout_kernel(const float* __restrict__ pack, int M, int S, size_t lds_f4,
                                const float* __restrict__ z0, const float* __restrict__ ts, int N, int T,
-                               float* __restrict__ zt, float* __restrict__ xstage) {
+                               float* __restrict__ zt, float* __restrict__ xstage, Draws dw) {
   static_assert(DI == ORDER * DO, "state dim = order * D_out");
   constexpr int NS = METHOD == 0 ? 1 : (METHOD == 1 ? 4 : 2);
+  pack += blockIdx.y * dw.pack; z0 += blockIdx.y * dw.in; zt += blockIdx.y * dw.out;    // blockIdx.y = Monte-Carlo draw
+  if (xstage) xstage += blockIdx.y * dw.out2;
   if (USE_LDS) stage_pack_lds(pack, lds_f4);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
@@ -259,8 +262,9 @@ __global__ __launch_bounds__(256) void rollout_kernel(const float* __restrict__ 
 
 template <class EV, int DI, int DO>
 __global__ __launch_bounds__(64 * EV::kTeam) void rhs_team_kernel(const float* __restrict__ pack, int M, int S,
-                                                        const float* __restrict__ x, int N, float* __restrict__ f, int mode) {
+                                                        const float* __restrict__ x, int N, float* __restrict__ f, int mode, Draws dw) {
   __shared__ float slots[2 * EV::kTeam * TeamCombine::DP];
+  pack += blockIdx.y * dw.pack; x += blockIdx.y * dw.in; f += blockIdx.y * dw.out;      // blockIdx.y = Monte-Carlo draw
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   EV ev;
   ev.init(pack, M, S, slots, wave, lane);
@@ -296,10 +300,13 @@ __device__ __forceinline__ void ode_rhs_mut(EV& ev, const float (&y)[DI], float 
 template <class EV, int DI, int DO, int ORDER, int METHOD>
 __global__ __launch_bounds__(64 * EV::kTeam) void rollout_team_kernel(const float* __restrict__ pack, int M, int S,
                                                             const float* __restrict__ z0, const float* __restrict__ ts,
-                                                            int N, int T, float* __restrict__ zt, float* __restrict__ xstage) {
+                                                            int N, int T, float* __restrict__ zt, float* __restrict__ xstage, Draws dw) {
   static_assert(DI == ORDER * DO, "state dim = order * D_out");
   constexpr int NS = METHOD == 0 ? 1 : (METHOD == 1 ? 4 : 2);
   __shared__ float slots[2 * EV::kTeam * TeamCombine::DP];
+  // blockIdx.y = Monte-Carlo draw: its own pack (function draw), the shared initial states, its own trajectories
+  pack += blockIdx.y * dw.pack; z0 += blockIdx.y * dw.in; zt += blockIdx.y * dw.out;
+  if (xstage) xstage += blockIdx.y * dw.out2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   EV ev;
   ev.init(pack, M, S, slots, wave, lane);
@@ -374,50 +381,50 @@ static const int kTeamMaxRows = 2048;  // below this, 4 waves per trajectory bea
 static inline int team_grid(int N) { return N < 2048 ? N : 2048; }
 
 template <int DI, int DO>
-static int launch_rhs_rbf(const float* pack, int M, int S, const float* x, int N, float* f, int mode, hipStream_t st) {
+static int launch_rhs_rbf(const float* pack, int M, int S, const float* x, int N, float* f, int mode, hipStream_t st, Draws dw) {
   int grid, block;
   grid_for(N, grid, block);
   if (N <= kTeamMaxRows && DO <= 16) {
     if (RbfTeamEval<DI, DO, 1>::fits(M, S)) {
-      hipLaunchKernelGGL((rhs_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO>), team_grid(N), 256, 0, st, pack, M, S, x, N, f, mode);
+      hipLaunchKernelGGL((rhs_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO>), dim3(team_grid(N), dw.nd), 256, 0, st, pack, M, S, x, N, f, mode, dw);
       return check_launch("rhs_rbf_team");
     }
   }
   if (N <= kTeamMaxRows) {     // past the register-resident quarter pack: the same team, records streamed from L2
-    hipLaunchKernelGGL((rhs_team_kernel<RbfStreamTeam<DI, DO>, DI, DO>), team_grid(N), 256, 0, st, pack, M, S, x, N, f, mode);
+    hipLaunchKernelGGL((rhs_team_kernel<RbfStreamTeam<DI, DO>, DI, DO>), dim3(team_grid(N), dw.nd), 256, 0, st, pack, M, S, x, N, f, mode, dw);
     return check_launch("rhs_rbf_team_stream");
   }
   const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
   if constexpr (rbf_reg_fits<DI, DO, 4, 2>()) {
     if (SJ == 4 && MJ == 2) {
-      hipLaunchKernelGGL((rhs_kernel<RbfRegEval<DI, DO, 4, 2>, DI, DO, false>), grid, block, 0, st, pack, M, S, (size_t)0, x, N, f, mode);
+      hipLaunchKernelGGL((rhs_kernel<RbfRegEval<DI, DO, 4, 2>, DI, DO, false>), dim3(grid, dw.nd), block, 0, st, pack, M, S, (size_t)0, x, N, f, mode, dw);
       return check_launch("rhs_rbf");
     }
   }
   if constexpr (rbf_reg_fits<DI, DO, 1, 1>()) {
     if (SJ == 1 && MJ == 1) {
-      hipLaunchKernelGGL((rhs_kernel<RbfRegEval<DI, DO, 1, 1>, DI, DO, false>), grid, block, 0, st, pack, M, S, (size_t)0, x, N, f, mode);
+      hipLaunchKernelGGL((rhs_kernel<RbfRegEval<DI, DO, 1, 1>, DI, DO, false>), dim3(grid, dw.nd), block, 0, st, pack, M, S, (size_t)0, x, N, f, mode, dw);
       return check_launch("rhs_rbf");
     }
   }
-  hipLaunchKernelGGL((rhs_kernel<RbfStreamEval<DI, DO>, DI, DO, false>), grid, block, 0, st, pack, M, S, (size_t)0, x, N, f, mode);
+  hipLaunchKernelGGL((rhs_kernel<RbfStreamEval<DI, DO>, DI, DO, false>), dim3(grid, dw.nd), block, 0, st, pack, M, S, (size_t)0, x, N, f, mode, dw);
   return check_launch("rhs_rbf");
 }
 
 template <int D>
-static int launch_rhs_df(const float* pack, int M, int S, const float* x, int N, float* f, int mode, hipStream_t st) {
+static int launch_rhs_df(const float* pack, int M, int S, const float* x, int N, float* f, int mode, hipStream_t st, Draws dw) {
   using L = DfLayout<D>;
   const size_t f4 = L::rff_f4(S) + L::ind_f4(M);
   int grid, block;
   grid_for(N, grid, block);
   if constexpr (D <= 8) {
     if (N <= kTeamMaxRows && DfTeamEval<D, 1>::fits(M, S)) {
-      hipLaunchKernelGGL((rhs_team_kernel<DfTeamEval<D, 1>, D, D>), team_grid(N), 256, 0, st, pack, M, S, x, N, f, mode);
+      hipLaunchKernelGGL((rhs_team_kernel<DfTeamEval<D, 1>, D, D>), dim3(team_grid(N), dw.nd), 256, 0, st, pack, M, S, x, N, f, mode, dw);
       return check_launch("rhs_df_team");
     }
   }
   if (N <= kTeamMaxRows) {
-    hipLaunchKernelGGL((rhs_team_kernel<DfStreamTeam<D>, D, D>), team_grid(N), 256, 0, st, pack, M, S, x, N, f, mode);
+    hipLaunchKernelGGL((rhs_team_kernel<DfStreamTeam<D>, D, D>), dim3(team_grid(N), dw.nd), 256, 0, st, pack, M, S, x, N, f, mode, dw);
     return check_launch("rhs_df_team_stream");
   }
   // one evaluation per row: staging the pack in LDS only pays when a workgroup evaluates many rows
@@ -425,53 +432,53 @@ static int launch_rhs_df(const float* pack, int M, int S, const float* x, int N,
     block = 256; grid = 256;
     auto kern = rhs_kernel<DfEval<D, true>, D, D, true>;
     if (set_max_lds((const void*)kern, f4 * 16)) return 1;
-    hipLaunchKernelGGL(kern, grid, block, f4 * 16, st, pack, M, S, f4, x, N, f, mode);
+    hipLaunchKernelGGL(kern, dim3(grid, dw.nd), block, f4 * 16, st, pack, M, S, f4, x, N, f, mode, dw);
   } else {
-    hipLaunchKernelGGL((rhs_kernel<DfEval<D, false>, D, D, false>), grid, block, 0, st, pack, M, S, (size_t)0, x, N, f, mode);
+    hipLaunchKernelGGL((rhs_kernel<DfEval<D, false>, D, D, false>), dim3(grid, dw.nd), block, 0, st, pack, M, S, (size_t)0, x, N, f, mode, dw);
   }
   return check_launch("rhs_df");
 }
 
 template <int DI, int DO, int ORDER, int METHOD>
-static int launch_rollout_rbf(const float* pack, int M, int S, const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st) {
+static int launch_rollout_rbf(const float* pack, int M, int S, const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st, Draws dw) {
   int grid, block;
   grid_for(N, grid, block);
   if constexpr (wide_ts<DO>() > 0 && DI <= 8) {
     constexpr int TS = wide_ts<DO>();
     if (wide_team_enabled() && N <= kWideMaxRows && RbfWideTeam<DI, DO, TS>::fits(M, S)) {
-      hipLaunchKernelGGL((rollout_team_kernel<RbfWideTeam<DI, DO, TS>, DI, DO, ORDER, METHOD>), N, 64 * TS, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
+      hipLaunchKernelGGL((rollout_team_kernel<RbfWideTeam<DI, DO, TS>, DI, DO, ORDER, METHOD>), dim3(N, dw.nd), 64 * TS, 0, st, pack, M, S, z0, ts, N, T, zt, xstage, dw);
       return check_launch("rollout_rbf_wide");
     }
   }
   if (N <= kTeamMaxRows && DO <= 16) {
     if (RbfTeamEval<DI, DO, 1>::fits(M, S)) {
-      hipLaunchKernelGGL((rollout_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO, ORDER, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
+      hipLaunchKernelGGL((rollout_team_kernel<RbfTeamEval<DI, DO, 1>, DI, DO, ORDER, METHOD>), dim3(team_grid(N), dw.nd), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage, dw);
       return check_launch("rollout_rbf_team");
     }
   }
   if (N <= kTeamMaxRows) {
-    hipLaunchKernelGGL((rollout_team_kernel<RbfStreamTeam<DI, DO>, DI, DO, ORDER, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
+    hipLaunchKernelGGL((rollout_team_kernel<RbfStreamTeam<DI, DO>, DI, DO, ORDER, METHOD>), dim3(team_grid(N), dw.nd), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage, dw);
     return check_launch("rollout_rbf_team_stream");
   }
   const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
   if constexpr (rbf_reg_fits<DI, DO, 4, 2>()) {
     if (SJ == 4 && MJ == 2) {
-      hipLaunchKernelGGL((rollout_kernel<RbfRegEval<DI, DO, 4, 2>, DI, DO, ORDER, METHOD, false>), grid, block, 0, st, pack, M, S, (size_t)0, z0, ts, N, T, zt, xstage);
+      hipLaunchKernelGGL((rollout_kernel<RbfRegEval<DI, DO, 4, 2>, DI, DO, ORDER, METHOD, false>), dim3(grid, dw.nd), block, 0, st, pack, M, S, (size_t)0, z0, ts, N, T, zt, xstage, dw);
       return check_launch("rollout_rbf");
     }
   }
   if constexpr (rbf_reg_fits<DI, DO, 1, 1>()) {
     if (SJ == 1 && MJ == 1) {
-      hipLaunchKernelGGL((rollout_kernel<RbfRegEval<DI, DO, 1, 1>, DI, DO, ORDER, METHOD, false>), grid, block, 0, st, pack, M, S, (size_t)0, z0, ts, N, T, zt, xstage);
+      hipLaunchKernelGGL((rollout_kernel<RbfRegEval<DI, DO, 1, 1>, DI, DO, ORDER, METHOD, false>), dim3(grid, dw.nd), block, 0, st, pack, M, S, (size_t)0, z0, ts, N, T, zt, xstage, dw);
       return check_launch("rollout_rbf");
     }
   }
-  hipLaunchKernelGGL((rollout_kernel<RbfStreamEval<DI, DO>, DI, DO, ORDER, METHOD, false>), grid, block, 0, st, pack, M, S, (size_t)0, z0, ts, N, T, zt, xstage);
+  hipLaunchKernelGGL((rollout_kernel<RbfStreamEval<DI, DO>, DI, DO, ORDER, METHOD, false>), dim3(grid, dw.nd), block, 0, st, pack, M, S, (size_t)0, z0, ts, N, T, zt, xstage, dw);
   return check_launch("rollout_rbf");
 }
 
 template <int D, int METHOD>
-static int launch_rollout_df(const float* pack, int M, int S, const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st) {
+static int launch_rollout_df(const float* pack, int M, int S, const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st, Draws dw) {
   using L = DfLayout<D>;
   const size_t f4 = L::rff_f4(S) + L::ind_f4(M);
   int grid, block;
@@ -479,18 +486,18 @@ static int launch_rollout_df(const float* pack, int M, int S, const float* z0, c
   if constexpr (wide_ts<D>() > 0) {
     constexpr int TS = wide_ts<D>();
     if (wide_team_enabled() && N <= kWideMaxRows && DfWideTeam<D, TS>::fits(M, S)) {
-      hipLaunchKernelGGL((rollout_team_kernel<DfWideTeam<D, TS>, D, D, 1, METHOD>), N, 64 * TS, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
+      hipLaunchKernelGGL((rollout_team_kernel<DfWideTeam<D, TS>, D, D, 1, METHOD>), dim3(N, dw.nd), 64 * TS, 0, st, pack, M, S, z0, ts, N, T, zt, xstage, dw);
       return check_launch("rollout_df_wide");
     }
   }
   if constexpr (D <= 8) {
     if (N <= kTeamMaxRows && DfTeamEval<D, 1>::fits(M, S)) {
-      hipLaunchKernelGGL((rollout_team_kernel<DfTeamEval<D, 1>, D, D, 1, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
+      hipLaunchKernelGGL((rollout_team_kernel<DfTeamEval<D, 1>, D, D, 1, METHOD>), dim3(team_grid(N), dw.nd), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage, dw);
       return check_launch("rollout_df_team");
     }
   }
   if (N <= kTeamMaxRows) {     // e.g. BASELINE configs[4] (D = 16, M = 512): 4 wavefronts per trajectory, records streamed from L2
-    hipLaunchKernelGGL((rollout_team_kernel<DfStreamTeam<D>, D, D, 1, METHOD>), team_grid(N), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage);
+    hipLaunchKernelGGL((rollout_team_kernel<DfStreamTeam<D>, D, D, 1, METHOD>), dim3(team_grid(N), dw.nd), 256, 0, st, pack, M, S, z0, ts, N, T, zt, xstage, dw);
     return check_launch("rollout_df_team_stream");
   }
   if (f4 * 16 <= kLdsLimitBytes) {
@@ -498,9 +505,9 @@ static int launch_rollout_df(const float* pack, int M, int S, const float* z0, c
     else { block = 256; grid = 256; }
     auto kern = rollout_kernel<DfEval<D, true>, D, D, 1, METHOD, true>;
     if (set_max_lds((const void*)kern, f4 * 16)) return 1;
-    hipLaunchKernelGGL(kern, grid, block, f4 * 16, st, pack, M, S, f4, z0, ts, N, T, zt, xstage);
+    hipLaunchKernelGGL(kern, dim3(grid, dw.nd), block, f4 * 16, st, pack, M, S, f4, z0, ts, N, T, zt, xstage, dw);
   } else {
-    hipLaunchKernelGGL((rollout_kernel<DfEval<D, false>, D, D, 1, METHOD, false>), grid, block, 0, st, pack, M, S, (size_t)0, z0, ts, N, T, zt, xstage);
+    hipLaunchKernelGGL((rollout_kernel<DfEval<D, false>, D, D, 1, METHOD, false>), dim3(grid, dw.nd), block, 0, st, pack, M, S, (size_t)0, z0, ts, N, T, zt, xstage, dw);
   }
   return check_launch("rollout_df");
 }
@@ -509,13 +516,13 @@ static int launch_rollout_df(const float* pack, int M, int S, const float* z0, c
 #define GP_RBF_DIMS(X) X(6, 6) X(6, 3) X(4, 4) X(4, 2) X(2, 2) X(2, 1) X(8, 8) X(8, 4) X(16, 16) X(16, 8) X(3, 3) X(12, 6)
 #define GP_DF_DIMS(X) X(6) X(4) X(2) X(3) X(8) X(16)
 
-int rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, int N, float* f, int mode, hipStream_t st) {
+int rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, int N, float* f, int mode, hipStream_t st, Draws dw) {
   if (kernel == 0) {
-#define X(a, b) if (Di == a && Do == b) return launch_rhs_rbf<a, b>(pack, M, S, x, N, f, mode, st);
+#define X(a, b) if (Di == a && Do == b) return launch_rhs_rbf<a, b>(pack, M, S, x, N, f, mode, st, dw);
     GP_RBF_DIMS(X)
 #undef X
   } else {
-#define X(a) if (Di == a && Do == a) return launch_rhs_df<a>(pack, M, S, x, N, f, mode, st);
+#define X(a) if (Di == a && Do == a) return launch_rhs_df<a>(pack, M, S, x, N, f, mode, st, dw);
     GP_DF_DIMS(X)
 #undef X
   }
@@ -523,32 +530,32 @@ int rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack, const f
 }
 
 template <int DI, int DO>
-static int rollout_rbf_dispatch(int order, int method, const float* pack, int M, int S, const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st) {
+static int rollout_rbf_dispatch(int order, int method, const float* pack, int M, int S, const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st, Draws dw) {
   if constexpr (DI == DO) {
-    if (order == 1 && method == 0) return launch_rollout_rbf<DI, DO, 1, 0>(pack, M, S, z0, ts, N, T, zt, xstage, st);
-    if (order == 1 && method == 1) return launch_rollout_rbf<DI, DO, 1, 1>(pack, M, S, z0, ts, N, T, zt, xstage, st);
-    if (order == 1 && method == 2) return launch_rollout_rbf<DI, DO, 1, 2>(pack, M, S, z0, ts, N, T, zt, xstage, st);
+    if (order == 1 && method == 0) return launch_rollout_rbf<DI, DO, 1, 0>(pack, M, S, z0, ts, N, T, zt, xstage, st, dw);
+    if (order == 1 && method == 1) return launch_rollout_rbf<DI, DO, 1, 1>(pack, M, S, z0, ts, N, T, zt, xstage, st, dw);
+    if (order == 1 && method == 2) return launch_rollout_rbf<DI, DO, 1, 2>(pack, M, S, z0, ts, N, T, zt, xstage, st, dw);
   }
   if constexpr (DI == 2 * DO) {
-    if (order == 2 && method == 0) return launch_rollout_rbf<DI, DO, 2, 0>(pack, M, S, z0, ts, N, T, zt, xstage, st);
-    if (order == 2 && method == 1) return launch_rollout_rbf<DI, DO, 2, 1>(pack, M, S, z0, ts, N, T, zt, xstage, st);
-    if (order == 2 && method == 2) return launch_rollout_rbf<DI, DO, 2, 2>(pack, M, S, z0, ts, N, T, zt, xstage, st);
+    if (order == 2 && method == 0) return launch_rollout_rbf<DI, DO, 2, 0>(pack, M, S, z0, ts, N, T, zt, xstage, st, dw);
+    if (order == 2 && method == 1) return launch_rollout_rbf<DI, DO, 2, 1>(pack, M, S, z0, ts, N, T, zt, xstage, st, dw);
+    if (order == 2 && method == 2) return launch_rollout_rbf<DI, DO, 2, 2>(pack, M, S, z0, ts, N, T, zt, xstage, st, dw);
   }
   return set_error("gpode_rollout_fwd: order=%d needs Di == order*Do (Di=%d Do=%d)", order, DI, DO);
 }
 
 int rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, int S, const float* pack,
-                const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st) {
+                const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st, Draws dw) {
   if (method < 0 || method > 2) return set_error("gpode_rollout_fwd: method %d (0 euler, 1 rk4, 2 midpoint)", method);
   if (kernel == 0) {
-#define X(a, b) if (Di == a && Do == b) return rollout_rbf_dispatch<a, b>(order, method, pack, M, S, z0, ts, N, T, zt, xstage, st);
+#define X(a, b) if (Di == a && Do == b) return rollout_rbf_dispatch<a, b>(order, method, pack, M, S, z0, ts, N, T, zt, xstage, st, dw);
     GP_RBF_DIMS(X)
 #undef X
   } else {
     if (order != 1) return set_error("gpode_rollout_fwd: DF kernel is first-order only (kernels.py:259-262)");
-#define X(a) if (Di == a && Do == a) return method == 0 ? launch_rollout_df<a, 0>(pack, M, S, z0, ts, N, T, zt, xstage, st) \
-                                            : method == 1 ? launch_rollout_df<a, 1>(pack, M, S, z0, ts, N, T, zt, xstage, st) \
-                                                          : launch_rollout_df<a, 2>(pack, M, S, z0, ts, N, T, zt, xstage, st);
+#define X(a) if (Di == a && Do == a) return method == 0 ? launch_rollout_df<a, 0>(pack, M, S, z0, ts, N, T, zt, xstage, st, dw) \
+                                            : method == 1 ? launch_rollout_df<a, 1>(pack, M, S, z0, ts, N, T, zt, xstage, st, dw) \
+                                                          : launch_rollout_df<a, 2>(pack, M, S, z0, ts, N, T, zt, xstage, st, dw);
     GP_DF_DIMS(X)
 #undef X
   }

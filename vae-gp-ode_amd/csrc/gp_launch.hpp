@@ -53,19 +53,31 @@ inline int num_cus() {
   return n;
 }
 
+// Monte-Carlo draws batched into ONE launch (the reference loops `for l in range(L)` over whole flow calls, odegpvae.py:41-43):
+// blockIdx.y = draw.  Strides in floats of the operands that differ per draw -- 0 = shared by all draws (the inducing locations
+// handed to the prior-only rhs, the initial states z0 of a rollout).  Which operand each stride belongs to is listed per entry point.
+struct Draws {
+  int nd = 1;
+  size_t pack = 0, in = 0, out = 0, in2 = 0, out2 = 0;
+};
+
 // entry points implemented across the .hip files
 int dims_supported(int kernel, int Di, int Do);
-int rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, int N, float* f, int mode, hipStream_t st);
+//   rhs_fwd:     in = x, out = f                       rollout_fwd: in = z0, out = zt, out2 = xstage
+//   rollout_bwd: in = xstage, in2 = gzt, out = gz0, out2 = astage
+//   rhs_vjp:     in = x, in2 = a, out = gx             param_grad:  in = xr, in2 = ar, out = gpack (slab: nchunk * pack_floats per draw)
+int rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, int N, float* f, int mode, hipStream_t st,
+            Draws dw = Draws{});
 int rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, int S, const float* pack,
-                const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st);
+                const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st, Draws dw = Draws{});
 int rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S, const float* pack, const float* xstage,
-                const float* gzt, const float* ts, int N, int T, float* gz0, float* astage, hipStream_t st);
+                const float* gzt, const float* ts, int N, int T, float* gz0, float* astage, hipStream_t st, Draws dw = Draws{});
 int rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, const float* a, int R, float* gx,
-            int prior_only, hipStream_t st);
+            int prior_only, hipStream_t st, Draws dw = Draws{});
 int param_grad(int kernel, int Di, int Do, int M, int S, const float* pack, const float* xr, const float* ar, int R,
-               float* slab, int nchunk, float* gpack, int accumulate, int prior_only, hipStream_t st);
-int cache_sizes(int kernel, int Di, int Do, int M, int S, size_t* pack_floats, size_t* ws_floats);
-int cache_build_fwd(int kernel, int Di, int Do, int M, int S,
+               float* slab, int nchunk, float* gpack, int accumulate, int prior_only, hipStream_t st, Draws dw = Draws{});
+int cache_sizes(int kernel, int Di, int Do, int M, int S, size_t* pack_floats, size_t* ws_floats, int nd = 1);
+int cache_build_fwd(int kernel, int Di, int Do, int M, int S, int nd,
                     const float* raw_ell, const float* raw_var, const float* Z, const float* Um, const float* Us_packed,
                     const float* eps_u, const float* rff_w, const float* rff_eps, const float* rff_u,
                     float* pack, float* ws, float* ell, float* var, float* omega, float* phase, float* u,
@@ -81,11 +93,11 @@ int svgp_kl_bwd(int M, int Do, const float* Um, const float* Us, const float* g,
 
 void set_backward_solves(int mode);
 int get_backward_solves();
-int cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, size_t* bws_floats);
-int cache_build_bwd(int kernel, int Di, int Do, int M, int S, const float* raw_ell, const float* raw_var, const float* Z,
+int cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, int nd, size_t* bws_floats);
+int cache_build_bwd(int kernel, int Di, int Do, int M, int S, int nd, const float* raw_ell, const float* raw_var, const float* Z,
                     const float* eps_u, const float* pack, const float* ws, float* gpack, float* bws,
                     float* g_raw_ell, float* g_raw_var, float* g_Z, float* g_Um, float* g_Us, int prepared, hipStream_t st);
-int cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, const float* ws, float* bws, hipStream_t st);
+int cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, int nd, const float* ws, float* bws, hipStream_t st);
 
 // conv VAE blocks (vae_conv.hip)
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S,

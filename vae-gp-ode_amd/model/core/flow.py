@@ -49,13 +49,15 @@ class Flow(nn.Module):
         self.atol, self.rtol = atol, rtol  # ignored by fixed-grid methods (as in torchdiffeq)
         self.use_adjoint = use_adjoint     # same forward; gradients are discretise-then-optimise either way
 
-    def forward(self, z0, ts):
-        """z0 (N,D), ts (T,) -> zt (N,T,D) for a fresh function draw (flow.py:68-86)."""
+    def forward(self, z0, ts, draws=None):
+        """z0 (N,D), ts (T,) -> zt (N,T,D) for a fresh function draw (flow.py:68-86).  ``draws`` = L: L fresh draws integrated in
+        one pass -> (L,N,T,D), the stack ODEGPVAE.sample_trajectories builds from L calls (odegpvae.py:41-44); ``_num_evals`` ends
+        at the count of ONE solve, as it does after the reference's last call."""
         if self.solver not in EVALS_PER_STEP:
             raise ValueError("solver '%s': this build integrates on the fixed grid with 'euler', 'midpoint' or 'rk4' only" % self.solver)
         gp = self.odefunc.diffeq
         self.odefunc._num_evals.fill_(0)
-        zt = ops.flow(gp, z0, ts, self.odefunc.order, self.solver)
+        zt = ops.flow(gp, z0, ts, self.odefunc.order, self.solver, draws)
         self.odefunc._num_evals += EVALS_PER_STEP[self.solver] * (ts.shape[0] - 1)
         return zt
 

@@ -53,6 +53,17 @@ class RBF(nn.Module):
     # -- cached per-draw state (set by SVGP_Layer.build_cache) ---------------------------------
     def _set_cache(self, cache, noise):
         self._cache = cache
+        if cache.stacked:
+            # L draws built together: the attributes show the LAST one, as after the reference's loop (odegpvae.py:41-43).  The
+            # views are taken lazily -- indexing launches nothing, but keep the torch-native work off a side-stream build
+            last = lambda t: t[-1]
+            self.rff_weights = last(noise['rff_w'])
+            if self.dimwise or self.kernel_id != 'RBF':
+                self.rff_omega, self.rff_phase, self.nu = last(cache.omega), last(cache.phase), last(cache.nu)
+            else:
+                self.rff_omega, self.rff_phase = last(cache.omega)[..., 0], last(cache.phase)[..., 0]
+                self.nu = last(cache.nu).reshape(self.D_out, -1).t()
+            return
         self.rff_weights = noise['rff_w']
         if cache.Do != self.D_out or cache.Di != self.D_in:      # evaluated zero-padded (ops.WidthPad): expose the unpadded slices
             if ops.launching_on_side():                          # SVGP_Layer.take_prebuilt_cache() calls again after the join

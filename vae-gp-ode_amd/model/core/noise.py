@@ -64,3 +64,19 @@ class DeviceNoise:
             o += n
         out['rff_u'] = torch.rand(sh['rff_u'], generator=g, device=device)
         return out
+
+    def draw_n(self, kernel, Di, Do, M, S, device, L):
+        """L draws with a leading draw axis, still two launches (one normal, one uniform): tensor k is the contiguous block
+        [L][shape_k] of the normal buffer.  (Not the same numbers as L successive draw() calls -- the stream is consumed in a
+        different order -- but the same distribution, and identical on every rank that seeds alike.)"""
+        sh = draw_shapes(kernel, Di, Do, M, S, True)
+        g = self.generator(device)
+        names = ('rff_w', 'rff_eps', 'eps_u')
+        sizes = [L * int(np.prod(sh[k])) for k in names]
+        flat = torch.randn(sum(sizes), generator=g, device=device)
+        out, o = {}, 0
+        for k, n in zip(names, sizes):
+            out[k] = flat[o:o + n].view((L,) + tuple(sh[k]))
+            o += n
+        out['rff_u'] = torch.rand((L,) + tuple(sh['rff_u']), generator=g, device=device)
+        return out

@@ -27,6 +27,10 @@ class ODEGPVAE(nn.Module):
         ts = self._ts
         if L == 1:
             return self.flow(z0, ts).unsqueeze(0)
+        field = self.flow.odefunc.diffeq
+        if getattr(field, 'batched_draws_supported', lambda: False)():
+            # the L draws in ONE pass: K_uu factored once, one rollout launch over L * N trajectories, one reverse sweep
+            return self.flow(z0, ts, draws=L)
         return torch.stack([self.flow(z0, ts) for _ in range(L)], 0)
 
     def encode_initial_state(self, X):
@@ -46,8 +50,8 @@ class ODEGPVAE(nn.Module):
         N, T, nc, d, _ = X.shape
         horizon = T_custom if T_custom else T
         field = self.flow.odefunc.diffeq
-        if L == 1 and hasattr(field, 'prebuild_cache'):
-            field.prebuild_cache()                   # overlap mode only: the draw's cache builds next to the encoder
+        if hasattr(field, 'prebuild_cache') and (L == 1 or field.batched_draws_supported()):
+            field.prebuild_cache(None if L == 1 else L)   # overlap mode only: the cache of the draw(s) builds next to the encoder
         z0, code_s, code_v = self.encode_initial_state(X)
         ztL = self.sample_trajectories(z0, horizon, L)
         return self.build_decoding(ztL, (L, N, horizon, nc, d, d), logits), code_s, code_v

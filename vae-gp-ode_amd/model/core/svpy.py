@@ -78,26 +78,40 @@ class SVGP_Layer(torch.nn.Module):
         return self.noise_source.draw(self.kernel_n, self.D_in, self.D_out, self.M, self.S, dev,
                                       **({} if self.dimwise or self.kernel_n != 'RBF' else {'dimwise': False}))
 
+    def _take_noise_draws(self, L):
+        """L draws stacked along a leading axis, in the order L successive build_cache() calls would have consumed them."""
+        dev = self.inducing_loc.optvar.device
+        plain = self.dimwise or self.kernel_n != 'RBF'
+        if not self._next_noise and plain and hasattr(self.noise_source, 'draw_n'):
+            return self.noise_source.draw_n(self.kernel_n, self.D_in, self.D_out, self.M, self.S, dev, L)   # one launch for all draws
+        per = [self._expand_shared(self._take_noise()) for _ in range(L)]
+        return {k: torch.stack([nz[k] for nz in per]) for k in per[0]}
+
+    def _expand_shared(self, nz):
+        if nz['rff_eps'].dim() == 2:   # dimwise=False draws one frequency / phase set (kernels.py:118-124,131-132): repeat it per output
+            nz = dict(nz, rff_eps=nz['rff_eps'].unsqueeze(-1).expand(-1, -1, self.D_out).contiguous(),
+                      rff_u=nz['rff_u'].unsqueeze(-1).expand(-1, -1, self.D_out).contiguous())
+        return nz
+
     # -- reference API ------------------------------------------------------------------------
     def sample_inducing(self):
         """One draw u ~ q(u) = N(m, S) in whitened form (svpy.py:88-101); returns (M,D_out)."""
         self.build_cache()
         return self.cache.u
 
-    def _cache_inputs(self, noise=None):
-        """Everything the cache-build kernels read, produced by torch on the CURRENT stream: the draw, and the derived tensors
+    def _cache_inputs(self, noise=None, draws=None):
+        """Everything the cache-build kernels read, produced by torch on the CURRENT stream: the draw(s), and the derived tensors
         of the operator variants (q_diag: softplus scale scattered onto the packed diagonal; dimwise=False: shared
         hyper-parameters / frequencies repeated per output).  Returned tensors are kept referenced by the cache."""
         if noise is not None:
             self._next_noise.insert(0, noise)
-        nz = self._take_noise()
-        if nz['rff_eps'].dim() == 2:   # dimwise=False draws one frequency / phase set (kernels.py:118-124,131-132): repeat it per output
-            nz = dict(nz, rff_eps=nz['rff_eps'].unsqueeze(-1).expand(-1, -1, self.D_out).contiguous(),
-                      rff_u=nz['rff_u'].unsqueeze(-1).expand(-1, -1, self.D_out).contiguous())
+        nz = self._expand_shared(self._take_noise()) if draws is None else self._take_noise_draws(draws)
         raw_ell, raw_var = self.kern.raw_dimwise()
         params = (raw_ell.detach(), raw_var.detach(), self.inducing_loc.optvar.detach(), self.Um.optvar.detach(), self.us_packed().detach())
         pad = self.width_pad
         if pad is not None:
+            if draws is not None:
+                raise NotImplementedError('batched draws at a zero-padded latent width: the flow falls back to one build per draw')
             nz, params = pad.noise(nz), tuple(t.contiguous() for t in pad.params(*params))
         return nz, params
 
@@ -108,19 +122,24 @@ class SVGP_Layer(torch.nn.Module):
         self.kern._set_cache(self.cache, nz)
         return self.cache
 
-    def build_cache(self, noise=None, want_Lu=False):
-        """Fix one function draw: Fourier features, inducing sample, nu (svpy.py:103-121)."""
-        nz, params = self._cache_inputs(noise)
+    def build_cache(self, noise=None, want_Lu=False, draws=None):
+        """Fix one function draw: Fourier features, inducing sample, nu (svpy.py:103-121).  ``draws`` = L fixes L of them in one
+        build (the L calls of odegpvae.py:41-43): K_uu is factored once, the cache's tensors carry a leading draw axis, and the
+        attributes on ``kern`` show the last draw -- the state the reference's loop leaves behind."""
+        nz, params = self._cache_inputs(noise, draws)
         return self._launch_cache_build(nz, params, want_Lu)
 
-    def prebuild_cache(self):
+    def batched_draws_supported(self):
+        return self.width_pad is None
+
+    def prebuild_cache(self, draws=None):
         """Overlap mode (ops.set_overlap): draw the noise now and build the cache on the side stream, so that the
         Cholesky chain runs next to the encoder; Flow.forward picks it up with take_prebuilt_cache()."""
         if not ops.overlap_enabled():
             return
         # every tensor the side-stream kernels read is produced on the current stream BEFORE the fork (the side stream then
         # waits for it) and stays referenced by the cache until the step's join
-        nz, params = self._cache_inputs()
+        nz, params = self._cache_inputs(draws=draws)
         side = ops.fork_side_stream()
         with ops.launch_on(side):
             self._prebuilt = self._launch_cache_build(nz, params)

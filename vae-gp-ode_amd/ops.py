@@ -121,9 +121,10 @@ def join_side_stream():
                     p.grad.add_(g)
 
 
-def cache_sizes(kernel, Di, Do, M, S):
+def cache_sizes(kernel, Di, Do, M, S, ndraws=1):
+    """(floats of ONE draw's pack, floats of the build workspace for ``ndraws`` draws that share the factor)."""
     p, w = ctypes.c_size_t(0), ctypes.c_size_t(0)
-    _lib.call('gpode_cache_sizes', KERNEL_ID[kernel], Di, Do, M, S, ctypes.byref(p), ctypes.byref(w))
+    _lib.call('gpode_cache_sizes_n', KERNEL_ID[kernel], Di, Do, M, S, ndraws, ctypes.byref(p), ctypes.byref(w))
     return p.value, w.value
 
 
@@ -131,7 +132,12 @@ class GPCache:
     """Per-draw cache: the lane-major ``pack`` the kernels consume, plus the attributes the reference
     caches on ``kern`` (kernels.py:134-137,172)."""
     __slots__ = ('kernel', 'Di', 'Do', 'M', 'S', 'pack', 'ws', 'ell', 'var', 'omega', 'phase', 'u', 'Lu', 'nu',
-                 'u_prior', 'noise', 'inputs')
+                 'u_prior', 'noise', 'inputs', 'nd', 'stacked')
+
+    @property
+    def lead(self):
+        """() for a single draw; (L,) when L Monte-Carlo draws share this build (every per-draw tensor then has a leading draw axis)."""
+        return (self.nd,) if self.stacked else ()
 
     def check_factorisation(self):
         """Raise like torch.linalg.cholesky does when K_uu + jitter*I is not positive definite
@@ -160,31 +166,36 @@ def set_backward_solves(mode):
 
 
 def cache_build(kernel, raw_ell, raw_var, Z, Um, Us_packed, eps_u, rff_w, rff_eps, rff_u, want_Lu=False):
-    """SVGP_Layer.build_cache (svpy.py:103-121) on the GPU."""
+    """SVGP_Layer.build_cache (svpy.py:103-121) on the GPU.  Noise with a LEADING draw axis (eps_u (L,M,Do), rff_w (L,S,Do) ...)
+    builds L Monte-Carlo draws at once: K_uu + jitter I is factored ONCE (it depends on the parameters only, kernels.py:163 / :384)
+    and the L right-hand sides are solved as a block; pack, omega, phase, u, nu, u_prior then carry the draw axis too."""
     Do, Di = raw_ell.shape
     M = Z.shape[0]
-    S = rff_eps.shape[1]
+    stacked = eps_u.dim() == 3
+    nd = eps_u.shape[0] if stacked else 1
+    lead = (nd,) if stacked else ()
+    S = rff_eps.shape[-2]
     raw_ell = _chk(raw_ell, 'raw_ell', (Do, Di)); raw_var = _chk(raw_var, 'raw_var', (Do,))
     Z = _chk(Z, 'Z', (M, Di)); Um = _chk(Um, 'Um', (M, Do))
     Us_packed = _chk(Us_packed, 'Us_packed', (Do, M * (M + 1) // 2))
-    eps_u = _chk(eps_u, 'eps_u', (M, Do))
-    rff_w = _chk(rff_w, 'rff_w', (S if kernel == 'RBF' else 2 * S, Do))
-    rff_eps = _chk(rff_eps, 'rff_eps', (Di, S, Do)); rff_u = _chk(rff_u, 'rff_u', (1, S, Do))
-    pf, wf = cache_sizes(kernel, Di, Do, M, S)
+    eps_u = _chk(eps_u, 'eps_u', lead + (M, Do))
+    rff_w = _chk(rff_w, 'rff_w', lead + (S if kernel == 'RBF' else 2 * S, Do))
+    rff_eps = _chk(rff_eps, 'rff_eps', lead + (Di, S, Do)); rff_u = _chk(rff_u, 'rff_u', lead + (1, S, Do))
+    pf, wf = cache_sizes(kernel, Di, Do, M, S, nd)
     dev = Z.device
     new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     c = GPCache()
-    c.kernel, c.Di, c.Do, c.M, c.S = kernel, Di, Do, M, S
-    c.pack, c.ws = new(pf), new(wf)
-    c.ell, c.var, c.omega, c.phase, c.u = new(Do, Di), new(Do), new(Di, S, Do), new(1, S, Do), new(M, Do)
-    c.u_prior = new(M, Do)
+    c.kernel, c.Di, c.Do, c.M, c.S, c.nd, c.stacked = kernel, Di, Do, M, S, nd, stacked
+    c.pack, c.ws = new(*lead, pf), new(wf)
+    c.ell, c.var, c.omega, c.phase, c.u = new(Do, Di), new(Do), new(*lead, Di, S, Do), new(*lead, 1, S, Do), new(*lead, M, Do)
+    c.u_prior = new(*lead, M, Do)
     if kernel == 'RBF':
-        c.nu = new(Do, M, 1)
+        c.nu = new(*lead, Do, M, 1)
         c.Lu = new(Do, M, M) if want_Lu else None
     else:
-        c.nu = new(M * Do, 1)
+        c.nu = new(*lead, M * Do, 1)
         c.Lu = new(M * Do, M * Do) if want_Lu else None
-    _lib.call('gpode_cache_build_fwd', KERNEL_ID[kernel], Di, Do, M, S,
+    _lib.call('gpode_cache_build_fwd_n', KERNEL_ID[kernel], Di, Do, M, S, nd,
               _ptr(raw_ell), _ptr(raw_var), _ptr(Z), _ptr(Um), _ptr(Us_packed),
               _ptr(eps_u), _ptr(rff_w), _ptr(rff_eps), _ptr(rff_u),
               _ptr(c.pack), _ptr(c.ws), _ptr(c.ell), _ptr(c.var), _ptr(c.omega), _ptr(c.phase), _ptr(c.u),
@@ -192,9 +203,15 @@ def cache_build(kernel, raw_ell, raw_var, Z, Um, Us_packed, eps_u, rff_w, rff_ep
     return c
 
 
+def _one_draw(cache, what):
+    if cache.stacked:
+        raise _lib.GpodeError('%s evaluates ONE function draw; this cache holds %d (use rollout / the flow)' % (what, cache.nd))
+
+
 def rhs(cache, x, mode=0):
     """SVGP_Layer.forward (svpy.py:123-142): x (N,Di) -> f (N,Do). mode 1: prior only, 2: update only."""
     x = _chk(x, 'x')
+    _one_draw(cache, 'rhs')
     if x.dim() != 2 or x.shape[1] != cache.Di:
         raise _lib.GpodeError('x must be (N,%d), got %s' % (cache.Di, tuple(x.shape)))
     N = x.shape[0]
@@ -208,8 +225,9 @@ NSTAGE = {'euler': 1, 'rk4': 4, 'midpoint': 2}
 
 
 def rollout(cache, z0, ts, order, method, save_stages=False):
-    """Flow.forward (flow.py:68-86) for a built cache: z0 (N,D), ts (T,) -> zt (N,T,D).
-    save_stages=True also returns the inputs of all RHS evaluations (N,T-1,NS,D) for the reverse sweep."""
+    """Flow.forward (flow.py:68-86) for a built cache: z0 (N,D), ts (T,) -> zt (N,T,D); a cache of L draws integrates all L * N
+    trajectories in ONE launch -> zt (L,N,T,D) (the stack of odegpvae.py:41-44).
+    save_stages=True also returns the inputs of all RHS evaluations ([L,] N,T-1,NS,D) for the reverse sweep."""
     if method not in METHOD_ID:
         raise _lib.GpodeError("solver '%s' is not a fixed-grid method of this build (euler, rk4, midpoint)" % method)
     z0 = _chk(z0, 'z0'); ts = _chk(ts, 'ts')
@@ -217,27 +235,32 @@ def rollout(cache, z0, ts, order, method, save_stages=False):
     if D != cache.Di or D != order * cache.Do:
         raise _lib.GpodeError('state dim %d must equal D_in=%d = order*D_out=%d' % (D, cache.Di, order * cache.Do))
     T = ts.shape[0]
-    zt = torch.empty((N, T, D), dtype=torch.float32, device=z0.device)
-    xs = torch.empty((N, max(T - 1, 0), NSTAGE[method], D), dtype=torch.float32, device=z0.device) if save_stages else None
-    _lib.call('gpode_rollout_fwd', KERNEL_ID[cache.kernel], order, METHOD_ID[method], cache.Di, cache.Do, cache.M,
-              cache.S, _ptr(cache.pack), _ptr(z0), _ptr(ts), N, T, _ptr(zt), _ptr(xs), _stream())
+    lead = cache.lead
+    zt = torch.empty(lead + (N, T, D), dtype=torch.float32, device=z0.device)
+    xs = torch.empty(lead + (N, max(T - 1, 0), NSTAGE[method], D), dtype=torch.float32, device=z0.device) if save_stages else None
+    _lib.call('gpode_rollout_fwd_n', KERNEL_ID[cache.kernel], order, METHOD_ID[method], cache.Di, cache.Do, cache.M,
+              cache.S, cache.nd, _ptr(cache.pack), _ptr(z0), _ptr(ts), N, T, _ptr(zt), _ptr(xs), _stream())
     return (zt, xs) if save_stages else zt
 
 
 def rollout_bwd(cache, xstage, gzt, ts, order, method):
-    """Reverse sweep: gzt (N,T,D) -> gz0 (N,D), astage (N,T-1,NS,Do)."""
+    """Reverse sweep: gzt ([L,] N,T,D) -> gz0 ([L,] N,D), astage ([L,] N,T-1,NS,Do)."""
     gzt = _chk(gzt, 'gzt'); xstage = _chk(xstage, 'xstage'); ts = _chk(ts, 'ts')
-    N, T, D = gzt.shape
-    gz0 = torch.empty((N, D), dtype=torch.float32, device=gzt.device)
-    ast = torch.empty((N, T - 1, NSTAGE[method], cache.Do), dtype=torch.float32, device=gzt.device)
-    _lib.call('gpode_rollout_bwd', KERNEL_ID[cache.kernel], order, METHOD_ID[method], cache.Di, cache.Do, cache.M,
-              cache.S, _ptr(cache.pack), _ptr(xstage), _ptr(gzt), _ptr(ts), N, T, _ptr(gz0), _ptr(ast), _stream())
+    lead = cache.lead
+    if gzt.dim() != 3 + len(lead) or tuple(gzt.shape[:len(lead)]) != lead:
+        raise _lib.GpodeError('gzt: expected %s + (N,T,D), got %s' % (lead, tuple(gzt.shape)))
+    N, T, D = gzt.shape[-3:]
+    gz0 = torch.empty(lead + (N, D), dtype=torch.float32, device=gzt.device)
+    ast = torch.empty(lead + (N, T - 1, NSTAGE[method], cache.Do), dtype=torch.float32, device=gzt.device)
+    _lib.call('gpode_rollout_bwd_n', KERNEL_ID[cache.kernel], order, METHOD_ID[method], cache.Di, cache.Do, cache.M,
+              cache.S, cache.nd, _ptr(cache.pack), _ptr(xstage), _ptr(gzt), _ptr(ts), N, T, _ptr(gz0), _ptr(ast), _stream())
     return gz0, ast
 
 
 def rhs_vjp(cache, x, a):
     """gx = J_f(x)^T a for rows x (R,Di), a (R,Do)."""
     x = _chk(x, 'x'); a = _chk(a, 'a')
+    _one_draw(cache, 'rhs_vjp')
     gx = torch.empty_like(x)
     _lib.call('gpode_rhs_vjp', KERNEL_ID[cache.kernel], cache.Di, cache.Do, cache.M, cache.S, _ptr(cache.pack),
               _ptr(x), _ptr(a), x.shape[0], _ptr(gx), _stream())
@@ -248,25 +271,29 @@ _PGRAD_CHUNKS = int(os.environ.get('GPODE_PGRAD_CHUNKS', '0'))     # 0: by the n
 
 
 def param_grad(cache, x, a, gpack=None, nchunk=None, keep=None):
-    """Gradient of sum_r <a_r, f(x_r)> w.r.t. every field of the pack, in pack layout.
+    """Gradient of sum_r <a_r, f(x_r)> w.r.t. every field of the pack, in pack layout; rows x ([L,] R,Di), a ([L,] R,Do) -- with L
+    draws every draw's rows go through its own pack, gpack is (L, pack_floats).
     ``keep`` (a list): the chunk scratch is appended to it -- a caller that launches on a side stream must hold it until that
     stream has been joined (the caching allocator only knows the stream the block was allocated on)."""
     x = _chk(x, 'x'); a = _chk(a, 'a')
-    R = x.shape[0]
+    lead = cache.lead
+    if x.dim() != 2 + len(lead) or tuple(x.shape[:len(lead)]) != lead:
+        raise _lib.GpodeError('x: expected %s + (R,%d), got %s' % (lead, cache.Di, tuple(x.shape)))
+    R = x.shape[-2]
     if nchunk is None:
         # one workgroup per chunk of rows, every chunk a full pack-sized slab for the reduction to read: ~32 rows per chunk, between
         # 64 and 256 chunks (configs[0], 1920 rows: 64 chunks 0.855 ms / 256 chunks 0.867 ms per step; configs[1], 15360 rows: 256)
         nchunk = _PGRAD_CHUNKS if _PGRAD_CHUNKS > 0 else min(256, max(64, R // 32))
     nchunk = max(1, min(nchunk, R))
-    pf = cache.pack.numel()
-    slab = torch.empty(nchunk * pf, dtype=torch.float32, device=x.device)
+    pf = cache.pack.shape[-1]
+    slab = torch.empty(cache.nd * nchunk * pf, dtype=torch.float32, device=x.device)
     acc = 1 if gpack is not None else 0
     if gpack is None:
         # NOT torch.zeros: a torch-native fill launches on torch's current stream, and under launch_on(side) that is not the
         # stream the chunk reduction writes gpack on -- the fill could land after it (seen as a run-to-run wobble of the GP
         # parameter gradients whenever the side stream was ahead).  accumulate = 0: the reduction writes every entry.
-        gpack = torch.empty(pf, dtype=torch.float32, device=x.device)
-    _lib.call('gpode_param_grad', KERNEL_ID[cache.kernel], cache.Di, cache.Do, cache.M, cache.S, _ptr(cache.pack),
+        gpack = torch.empty(lead + (pf,), dtype=torch.float32, device=x.device)
+    _lib.call('gpode_param_grad_n', KERNEL_ID[cache.kernel], cache.Di, cache.Do, cache.M, cache.S, cache.nd, _ptr(cache.pack),
               _ptr(x), _ptr(a), R, _ptr(slab), nchunk, _ptr(gpack), acc, _stream())
     if keep is not None:
         keep.append(slab)
@@ -415,15 +442,20 @@ def conditional(raw_ell, raw_var, Z, Um, Us, x, full_cov=False, us_rank1=False):
 
 
 class _Flow(torch.autograd.Function):
-    """One GP function draw + fixed-grid integration (flow.py:68-86), differentiable w.r.t. z0 and the five
-    GP parameter tensors.  Forward: gpode_cache_build_fwd + gpode_rollout_fwd.  Backward: gpode_rollout_bwd
-    (reverse sweep), gpode_param_grad (pack-layout parameter gradients), gpode_cache_build_bwd."""
+    """GP function draw(s) + fixed-grid integration (flow.py:68-86), differentiable w.r.t. z0 and the five GP parameter tensors.
+    ``draws`` None: one draw, zt (N,T,D).  ``draws`` = L: the L draws of ODEGPVAE.sample_trajectories (odegpvae.py:37-45) in one
+    pass -- ONE cache build that factors K_uu once, ONE rollout launch over L * N trajectories, zt (L,N,T,D); the backward is one
+    reverse sweep, one parameter-sum launch and one cache backward on the gradients summed over the draws.
+    Forward: gpode_cache_build_fwd_n + gpode_rollout_fwd_n.  Backward: gpode_rollout_bwd_n (reverse sweep), gpode_param_grad_n
+    (pack-layout parameter gradients), gpode_cache_build_bwd_n."""
 
     @staticmethod
-    def forward(ctx, z0, ts, raw_ell, raw_var, Z, Um, Us, gp, order, method):
+    def forward(ctx, z0, ts, raw_ell, raw_var, Z, Um, Us, gp, order, method, draws=None):
         cache = gp.take_prebuilt_cache() if hasattr(gp, 'take_prebuilt_cache') else None
         if cache is None:
-            cache = gp.build_cache()
+            cache = gp.build_cache() if draws is None else gp.build_cache(draws=draws)
+        if (cache.nd if cache.stacked else None) != draws:
+            raise _lib.GpodeError('the prebuilt cache holds %s draws, the flow was asked for %s' % (cache.lead or 'one', draws))
         ctx.params = (raw_ell, raw_var, Z, Um, Us)
         need = any(ctx.needs_input_grad)
         ctx.prepared = None
@@ -445,9 +477,12 @@ class _Flow(torch.autograd.Function):
     def backward(ctx, gzt):
         ts, xs, raw_ell, raw_var, Z = ctx.saved_tensors
         c = ctx.cache
+        lead = c.lead
         gz0, ast = rollout_bwd(c, xs, gzt.contiguous(), ts, ctx.order, ctx.method)
+        if c.stacked:
+            gz0 = gz0.sum(0)                         # every draw starts from the same z0 (odegpvae.py:42)
         if not any(ctx.needs_input_grad[2:7]):
-            return (gz0,) + (None,) * 9
+            return (gz0,) + (None,) * 10
         leaves = all(p.is_leaf and p.requires_grad for p in ctx.params) and all(ctx.needs_input_grad[2:7])
         if _overlap['on'] and leaves:
             # parameter gradients on the side stream, next to the encoder's backward; join_side_stream() adds them
@@ -455,31 +490,32 @@ class _Flow(torch.autograd.Function):
             _main_marker()
             scratch = []
             with launch_on(side):
-                gpack = param_grad(c, xs.reshape(-1, c.Di), ast.reshape(-1, c.Do), keep=scratch)
+                gpack = param_grad(c, xs.reshape(lead + (-1, c.Di)), ast.reshape(lead + (-1, c.Do)), keep=scratch)
                 g = cache_build_bwd(c, raw_ell, raw_var, Z, gpack, prepared=ctx.prepared)
             grads = [g['raw_ell'], g['raw_var'], g['Z'], g['Um'], g['Us']]
             # every buffer a side-stream kernel touches stays referenced until join_side_stream(): the allocator would
             # otherwise hand the block to the encoder-backward kernels the main stream launches meanwhile
             _overlap['pending'].append((ctx.params, [gg.view_as(p) for gg, p in zip(grads, ctx.params)],
                                         (g, gpack, xs, ast, c, scratch, raw_ell, raw_var, Z, ctx.prepared)))
-            return (gz0,) + (None,) * 9
+            return (gz0,) + (None,) * 10
         if ctx.prepared is not None:
             torch.cuda.current_stream().wait_stream(side_stream())
-        gpack = param_grad(c, xs.reshape(-1, c.Di), ast.reshape(-1, c.Do))
+        gpack = param_grad(c, xs.reshape(lead + (-1, c.Di)), ast.reshape(lead + (-1, c.Do)))
         g = cache_build_bwd(c, raw_ell, raw_var, Z, gpack, prepared=ctx.prepared)
-        return (gz0, None, g['raw_ell'], g['raw_var'], g['Z'], g['Um'], g['Us'], None, None, None)
+        return (gz0, None, g['raw_ell'], g['raw_var'], g['Z'], g['Um'], g['Us'], None, None, None, None)
 
 
-def flow(gp, z0, ts, order, method):
+def flow(gp, z0, ts, order, method, draws=None):
+    """One function draw -> zt (N,T,D); ``draws`` = L -> the L draws of odegpvae.py:41-44 in one pass, zt (L,N,T,D)."""
     k = gp.kern
     raw_ell, raw_var = k.raw_dimwise() if hasattr(k, 'raw_dimwise') else (k.unconstrained_lengthscales, k.unconstrained_variance)
     params = (raw_ell, raw_var, gp.inducing_loc.optvar, gp.Um.optvar, gp.us_packed() if hasattr(gp, 'us_packed') else gp.Us_sqrt.optvar)
     pad = getattr(gp, 'width_pad', None)
     if pad is None:
-        return _Flow.apply(z0, ts, *params, gp, order, method)
+        return _Flow.apply(z0, ts, *params, gp, order, method, draws)
     # a width outside the compiled list: the compiled kernels on zero-padded operands (see WidthPad); autograd carries the
     # gradients back through the scatter / slice
-    zt = _Flow.apply(pad.state(z0), ts, *pad.params(*params), gp, order, method)
+    zt = _Flow.apply(pad.state(z0), ts, *pad.params(*params), gp, order, method, draws)
     return pad.unstate(zt)
 
 
@@ -488,25 +524,27 @@ def cache_bwd_prepare(cache):
     and later handed to cache_build_bwd(..., prepared=ws)."""
     c = cache
     bw = ctypes.c_size_t(0)
-    _lib.call('gpode_cache_bwd_sizes', KERNEL_ID[c.kernel], c.Di, c.Do, c.M, c.S, ctypes.byref(bw))
+    _lib.call('gpode_cache_bwd_sizes_n', KERNEL_ID[c.kernel], c.Di, c.Do, c.M, c.S, c.nd, ctypes.byref(bw))
     bws = torch.empty(bw.value, dtype=torch.float32, device=c.pack.device)
-    _lib.call('gpode_cache_bwd_prepare', KERNEL_ID[c.kernel], c.Di, c.Do, c.M, c.S, _ptr(c.ws), _ptr(bws), _stream())
+    _lib.call('gpode_cache_bwd_prepare_n', KERNEL_ID[c.kernel], c.Di, c.Do, c.M, c.S, c.nd, _ptr(c.ws), _ptr(bws), _stream())
     return bws
 
 
 def cache_build_bwd(cache, raw_ell, raw_var, Z, gpack, prepared=None):
-    """Pack-layout gradient -> gradients of the five raw GP parameter tensors (state_dict layouts)."""
+    """Pack-layout gradient ([L,] pack_floats) -> gradients of the five raw GP parameter tensors (state_dict layouts), summed
+    over the draws of the cache."""
     c = cache
     bw = ctypes.c_size_t(0)
-    _lib.call('gpode_cache_bwd_sizes', KERNEL_ID[c.kernel], c.Di, c.Do, c.M, c.S, ctypes.byref(bw))
+    _lib.call('gpode_cache_bwd_sizes_n', KERNEL_ID[c.kernel], c.Di, c.Do, c.M, c.S, c.nd, ctypes.byref(bw))
     dev = gpack.device
     new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     bws = prepared if prepared is not None else new(bw.value)
     out = dict(raw_ell=new(c.Do, c.Di), raw_var=new(c.Do), Z=new(c.M, c.Di), Um=new(c.M, c.Do),
                Us=new(c.Do, c.M * (c.M + 1) // 2))
-    _lib.call('gpode_cache_build_bwd', KERNEL_ID[c.kernel], c.Di, c.Do, c.M, c.S,
-              _ptr(_chk(raw_ell, 'raw_ell')), _ptr(_chk(raw_var, 'raw_var')), _ptr(_chk(Z, 'Z')), _ptr(c.noise['eps_u']),
-              _ptr(c.pack), _ptr(c.ws), _ptr(gpack), _ptr(bws),
+    _lib.call('gpode_cache_build_bwd_n', KERNEL_ID[c.kernel], c.Di, c.Do, c.M, c.S, c.nd,
+              _ptr(_chk(raw_ell, 'raw_ell')), _ptr(_chk(raw_var, 'raw_var')), _ptr(_chk(Z, 'Z')),
+              _ptr(_chk(c.noise['eps_u'], 'eps_u', c.lead + (c.M, c.Do))),
+              _ptr(_chk(c.pack, 'pack')), _ptr(c.ws), _ptr(_chk(gpack, 'gpack', c.lead + (c.pack.shape[-1],))), _ptr(bws),
               _ptr(out['raw_ell']), _ptr(out['raw_var']), _ptr(out['Z']), _ptr(out['Um']), _ptr(out['Us']),
               int(prepared is not None), _stream())
     out['_workspace'] = bws   # referenced by the caller for as long as a side stream may still be writing it
