@@ -250,6 +250,8 @@ def main():
     ap.add_argument('--workload', default='cfg2', choices=sorted(WORKLOADS))
     ap.add_argument('--mode', default='elbo', choices=['elbo', 'integrator'])
     ap.add_argument('--seed', type=int, default=121)
+    ap.add_argument('--L', type=int, default=1, help='Monte-Carlo draws per step (main.py:200 trains at L = 1, then L = 5); a trajectory '
+                    'is one (sample, draw) pair, so a step integrates batch x L of them')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip extra.configs (configs[0], configs[2], integrator-only figures)')
     ap.add_argument('--no-overlap', action='store_true', help='keep the GP cache build / cache backward on the main stream')
@@ -364,7 +366,7 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
 
     def fwd_bwd():
         opt.zero_grad()
-        loss, nl, klr, klu = compute_loss(model, Xd, 1)
+        loss, nl, klr, klu = compute_loss(model, Xd, a.L)
         loss.backward()
         ops.join_side_stream()
         return loss
@@ -439,14 +441,14 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
-    value = w['batch'] * n_gpus * a.steps / el
-    roof = dominant_kernel_roofline(w, dev)
+    value = w['batch'] * a.L * n_gpus * a.steps / el          # trajectories = (sample, Monte-Carlo draw) pairs
+    roof = dominant_kernel_roofline(w, dev, a.L)
     out = {
         'metric': 'latent_trajectories_per_sec', 'value': value, 'unit': 'trajectories/s',
         'n_gpus': n_gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': el / a.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': w['desc'] + '; step = full ELBO training step (encoder, GP draw, rk4 rollout, decoder, ELBO, backward, Adam), L=1',
-                   'global_batch': w['batch'] * n_gpus, 'solver': 'rk4 (3/8 rule)', 'parallelism': 'dp%d' % n_gpus,
+        'config': {'workload': w['desc'] + '; step = full ELBO training step (encoder, GP draw, rk4 rollout, decoder, ELBO, backward, Adam), L=%d' % a.L,
+                   'global_batch': w['batch'] * n_gpus, 'mc_draws': a.L, 'solver': 'rk4 (3/8 rule)', 'parallelism': 'dp%d' % n_gpus,
                    'hip_graph': graphed, 'graph_scope': mode, 'gp_side_stream': not a.no_overlap,
                    'batchnorm': 'global-minibatch statistics (all-gather per layer)' if bn_sync is not None else 'per-process statistics'},
         'elbo_step_ms': el / a.steps * 1e3,
@@ -460,6 +462,10 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
         if n_gpus == 1 and not a.no_extra:
             extra = other_configs(a, dev, a.workload)      # (same launch form as the headline leg: graph replay, side-stream overlap)
             main = extra.pop(a.workload)
+            if 'L5' in main:
+                if a.L == 1:
+                    main['L5']['elbo_step_ms_over_L1'] = main['L5']['elbo_step_ms'] / (el / a.steps * 1e3)
+                out['L5'] = main['L5']
             out['integrator_ms'] = main['integrator_ms']
             out['integrator_traj_per_s'] = main['integrator_traj_per_s']
             roof['integrator'] = {'bound': 'valu', 'kernel': 'rollout_team_kernel (rk4 rollout of the GP-ODE, one launch per draw)',
@@ -474,16 +480,23 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
     return out
 
 
-def quick_integrator(w, dev, seed, steps=50, warmup=5):
+def quick_integrator(w, dev, seed, steps=50, warmup=5, L=1):
     """GP draw + rk4 rollout of workload `w` on one GPU: (ms per graph-replayed draw + rollout, ms of the rollout launch alone
-    bracketed by events on the launch stream, the inputs for a CPU leg)."""
+    bracketed by events on the launch stream, the inputs for a CPU leg).  L > 1: L draws through ONE build + ONE rollout launch."""
     from vae_gp_ode_amd import ops
     from vae_gp_ode_amd.graph import GraphedStep
     flow, p, nz, z0, ts, nzd, z0d, tsd = make_inputs(w, seed, dev, 0)
     gp = flow.odefunc.diffeq
+    if L > 1:                                        # L different function draws (a leading draw axis on every noise tensor)
+        gl = torch.Generator().manual_seed(seed + 2)
+        nzL = {k: torch.stack([v] + [torch.rand(v.shape, generator=gl) if k == 'rff_u' else torch.randn(v.shape, generator=gl)
+                                     for _ in range(L - 1)]).to(dev) for k, v in nz.items()}
     with torch.no_grad():
         def step(ev=None):
-            c = gp.build_cache(noise=nzd)
+            if L > 1:
+                c = gp.build_cache(noise=nzL, draws=L)
+            else:
+                c = gp.build_cache(noise=nzd)
             if ev is not None:
                 ev[0].record()
             zt = ops.rollout(c, z0d, tsd, w['order'], 'rk4')
@@ -511,8 +524,10 @@ def quick_integrator(w, dev, seed, steps=50, warmup=5):
     return ms, roll_ms, (p, nz, z0, ts)
 
 
-def quick_elbo(w, dev, seed, steps=30, warmup=5):
-    """Full ELBO training step of workload `w` on one GPU, graph-replayed: (ms per step, model, X)."""
+def quick_elbo(w, dev, seed, steps=30, warmup=5, L=1):
+    """Full ELBO training step of workload `w` on one GPU, graph-replayed (the launch form of the headline leg: side-stream
+    overlap as set by the caller): (ms per step, model, X)."""
+    from vae_gp_ode_amd import ops
     from vae_gp_ode_amd.graph import GraphedStep, device_generators
     from vae_gp_ode_amd.model.create_model import compute_loss
     from vae_gp_ode_amd.optim import HipAdam
@@ -522,8 +537,9 @@ def quick_elbo(w, dev, seed, steps=30, warmup=5):
 
     def whole_step():
         opt.zero_grad()
-        loss, *_ = compute_loss(model, Xd, 1)
+        loss, *_ = compute_loss(model, Xd, L)
         loss.backward()
+        ops.join_side_stream()
         opt.step()
         return loss
     model.flow.odefunc.diffeq.noise_source.generator(dev)
@@ -560,27 +576,42 @@ def rollout_only_ms(w, dev, seed, reps=10):
 
 
 def other_configs(a, dev, main_name):
-    """`extra.configs` of the line: configs[0] (the reference's CPU-runnable case and the north-star configuration, with the CPU
-    oracle timed beside it in both modes) and configs[2], plus the integrator-only figures of the headline workload; one GPU."""
+    """`extra.configs` of the line, one GPU: every BASELINE configuration gets a driver-run number -- configs[0] (the reference's
+    CPU-runnable case and the north-star configuration, with the CPU oracle timed beside it in both modes and the L = 5 form of
+    main.py:200), configs[2], the per-GPU shards of configs[3] and configs[4] (no CPU legs), plus the integrator-only figures of the
+    headline workload."""
     out = {}
-    for name in dict.fromkeys(('cfg1', 'cfg3', main_name)):
+    for name in dict.fromkeys(('cfg1', 'cfg3', 'cfg4', 'cfg5', main_name)):
         w = WORKLOADS[name]
         rec = {'workload': w['desc']}
-        ims, roll_ms, cpu_in = quick_integrator(w, dev, a.seed)
+        heavy = name == 'cfg5'                       # 48 ms steps: fewer repetitions, no saturation sweep
+        ims, roll_ms, cpu_in = quick_integrator(w, dev, a.seed, steps=10 if heavy else 50)
         rec['integrator_ms'] = ims
         rec['integrator_traj_per_s'] = w['batch'] / (ims * 1e-3)
         rec['rollout_ms'] = roll_ms
         rec['rollout_valu_frac'] = w['mflop'] * 1e6 * w['batch'] / (roll_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS
-        # the same rollout kernel with 16 x the trajectories per launch: the benchmark batches (32 - 256 per GPU) are one 4-wavefront
-        # team per CU or less, i.e. on the kernel's latency floor; this is where it saturates (tools/rollout_saturation.py)
-        big = rollout_only_ms(dict(w, batch=16 * max(w['batch'], 256)), dev, a.seed)
-        rec['rollout_saturated'] = {'trajectories': 16 * max(w['batch'], 256), 'rollout_ms': big,
-                                    'valu_frac': w['mflop'] * 1e6 * 16 * max(w['batch'], 256) / (big * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
+        if not heavy:
+            # the same rollout kernel with 16 x the trajectories per launch: the benchmark batches (32 - 256 per GPU) are one 4-wavefront
+            # team per CU or less, i.e. on the kernel's latency floor; this is where it saturates (tools/rollout_saturation.py)
+            big = rollout_only_ms(dict(w, batch=16 * max(w['batch'], 256)), dev, a.seed)
+            rec['rollout_saturated'] = {'trajectories': 16 * max(w['batch'], 256), 'rollout_ms': big,
+                                        'valu_frac': w['mflop'] * 1e6 * 16 * max(w['batch'], 256) / (big * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
         if name != main_name:
-            ems, model, X = quick_elbo(w, dev, a.seed)
+            ems, model, X = quick_elbo(w, dev, a.seed, steps=8 if heavy else 30, warmup=2 if heavy else 5)
             rec['elbo_step_ms'] = ems
             rec['elbo_traj_per_s'] = w['batch'] / (ems * 1e-3)
             rec['elbo_step_frac'] = w['elbo_mflop'] * 1e6 * rec['elbo_traj_per_s'] / 1e12 / PEAK_FP32_TFLOPS
+        if name in ('cfg1', main_name) and not heavy:
+            # L = 5 (main.py:200): ONE cache build that factors K_uu once, ONE rollout launch over 5 x batch trajectories, one
+            # reverse sweep, one cache backward -- the reference runs five of each
+            L = 5
+            ims5, roll5, _ = quick_integrator(w, dev, a.seed, L=L)
+            ems5, _, _ = quick_elbo(w, dev, a.seed, L=L)
+            l1_step = rec.get('elbo_step_ms')
+            rec['L5'] = {'mc_draws': L, 'integrator_ms': ims5, 'integrator_traj_per_s': L * w['batch'] / (ims5 * 1e-3), 'rollout_ms': roll5,
+                         'integrator_ms_over_L1': ims5 / ims, 'elbo_step_ms': ems5, 'elbo_traj_per_s': L * w['batch'] / (ems5 * 1e-3),
+                         'elbo_step_ms_over_L1': (ems5 / l1_step) if l1_step else None,
+                         'elbo_step_frac': w['elbo_mflop'] * 1e6 * L * w['batch'] / (ems5 * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
         if name == 'cfg1' and not a.no_cpu_baseline:
             rec['cpu_baseline_integrator'] = cpu_baseline(w, *cpu_in, budget_s=4.0)
             rec['integrator_gpu_over_cpu'] = rec['integrator_traj_per_s'] / rec['cpu_baseline_integrator']['value']
@@ -588,16 +619,16 @@ def other_configs(a, dev, main_name):
                 rec['cpu_baseline_elbo'] = cpu_baseline_elbo(w, model, X, budget_s=6.0)
                 rec['elbo_gpu_over_cpu'] = rec['elbo_traj_per_s'] / rec['cpu_baseline_elbo']['value']
         out[name] = rec
-        print('[bench] %s: %s' % (name, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in rec.items() if not isinstance(v, (dict, str))}),
+        print('[bench] %s: %s' % (name, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in rec.items() if not isinstance(v, str)}),
               file=sys.stderr, flush=True)
     return out
 
 
-def dominant_kernel_roofline(w, dev, reps=20):
+def dominant_kernel_roofline(w, dev, L=1, reps=20):
     """The FLOP-dominant kernel of the step is the decoder's 32->16, k5, s2 transposed convolution (decnn.7) on
     batch*T images; time it alone with HIP events (torch's current stream is the launch stream)."""
     from vae_gp_ode_amd import vae_ops as V
-    B = w['batch'] * w['T']
+    B = w['batch'] * w['T'] * L
     x = torch.randn(B, 32, 13, 13, device=dev)
     wt = torch.randn(32, 16, 5, 5, device=dev) * 0.05
     b = torch.zeros(16, device=dev)

@@ -103,9 +103,14 @@ class SVGP_Layer(torch.nn.Module):
         """Everything the cache-build kernels read, produced by torch on the CURRENT stream: the draw(s), and the derived tensors
         of the operator variants (q_diag: softplus scale scattered onto the packed diagonal; dimwise=False: shared
         hyper-parameters / frequencies repeated per output).  Returned tensors are kept referenced by the cache."""
-        if noise is not None:
-            self._next_noise.insert(0, noise)
-        nz = self._expand_shared(self._take_noise()) if draws is None else self._take_noise_draws(draws)
+        if noise is not None and draws is not None:  # the L draws handed over stacked: a leading draw axis on every tensor
+            if any(v.shape[0] != draws for v in noise.values()):
+                raise ValueError('noise for %d draws must carry a leading axis of that length' % draws)
+            nz = {k: v.to(self.inducing_loc.optvar.device) for k, v in noise.items()}
+        else:
+            if noise is not None:
+                self._next_noise.insert(0, noise)
+            nz = self._expand_shared(self._take_noise()) if draws is None else self._take_noise_draws(draws)
         raw_ell, raw_var = self.kern.raw_dimwise()
         params = (raw_ell.detach(), raw_var.detach(), self.inducing_loc.optvar.detach(), self.Um.optvar.detach(), self.us_packed().detach())
         pad = self.width_pad
