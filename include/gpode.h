@@ -154,6 +154,27 @@ int gpode_set_backward_solves(int mode);
 int gpode_kernel_matrix(int kernel, int Di, int Do, const float* raw_ell, const float* raw_var,
                         const float* X, int N, const float* X2, int M2, float* out, void* stream);
 
+/* The kernel's own methods, for a caller that keeps its SVGP_Layer class and binds method by method -- the stages of
+ * gpode_cache_build_fwd, cut where the reference cuts them:
+ *   gpode_kern_cache   kern.build_cache(S, device) (kernels.py:126-137 / :305-316) with kern.sample_freq (kernels.py:112-124) inside:
+ *                      omega (Di,S,Do) = rff_eps / ell^T, phase (1,S,Do) = 2 pi rff_u (either may be NULL), and in `pack` a
+ *                      PRIOR-ONLY cache (no inducing records) that gpode_rhs_fwd(..., M = 0, ..., mode = 1) evaluates:
+ *                      kern.rff_forward(x, S) (kernels.py:140-153 / :319-351) on exactly these Fourier features.
+ *   gpode_compute_nu   kern.compute_nu(Ku, u_prior, inducing_val) (kernels.py:155-172 / :376-387): Cholesky of the CALLER's
+ *                      Ku + 1e-5 I (RBF (Do,M,M); DF (M D, M D)) and nu = L^-T (u - L^-1 u_prior); u_prior, u (M,Do); nu RBF (Do,M,1),
+ *                      DF (M D,1).  ws: gpode_compute_nu_ws floats; afterwards gpode_cache_info(ws) reports a non-positive-definite Ku.
+ *   gpode_f_update     kern.f_update(x, x2) (kernels.py:174-181 / :390-393): out (N,Do) = K(x, x2) nu for the caller's nu and x2 (M,Di).
+ * `pack` / `scratch`: gpode_kern_scratch(kernel, Di, Do, M, S) floats (M = 0 for gpode_kern_cache, S = 0 for gpode_f_update); 0 = no
+ * specialisation. */
+size_t gpode_kern_scratch(int kernel, int Di, int Do, int M, int S);
+int gpode_kern_cache(int kernel, int Di, int Do, int S, const float* raw_ell, const float* raw_var, const float* rff_w,
+                     const float* rff_eps, const float* rff_u, float* pack, float* omega, float* phase, void* stream);
+int gpode_compute_nu_ws(int kernel, int Di, int Do, int M, size_t* ws_floats);
+int gpode_compute_nu(int kernel, int Di, int Do, int M, const float* Ku, const float* u_prior, const float* u, float* nu, float* ws,
+                     void* stream);
+int gpode_f_update(int kernel, int Di, int Do, int M, const float* raw_ell, const float* raw_var, const float* x2, const float* nu,
+                   const float* x, int N, float* out, float* scratch, void* stream);
+
 /* SVGP_Layer.build_conditional (svpy.py:176-210), RBF kernel: q(f(x)) = N(m(x), Sigma(x)) at the rows of x (N,Di).
  * raw_ell (Do,Di), raw_var (Do), Z (M,Di), Um (M,Do) as in gpode_cache_build_fwd.  us_rank1 = 0: Us = the packed lower
  * triangle (Do, M(M+1)/2); us_rank1 = 1 (q_diag=True): Us = the constrained scale as (Do,M) columns s_d, and Us Us^T is the

@@ -306,8 +306,22 @@ def data_case(name, seed):
                         digits=digits, angles=angles, rotated=rotated)
 
 
+def _only(names):
+    """`python make_golden.py NAME ...` regenerates just those fixtures (every case seeds itself: the files do not depend on
+    which others are generated in the same run); without arguments all of them."""
+    if not names:
+        return
+    g = globals()
+    for fn in ('gp_case', 'model_case', 'model_case_intermediates', 'cond_case', 'data_case'):
+        def gate(name, *a, _f=g[fn], **k):
+            if name in names:
+                return _f(name, *a, **k)
+        g[fn] = gate
+
+
 if __name__ == '__main__':
     torch.set_num_threads(1)
+    _only(set(sys.argv[1:]))
     data_case('data_path', 301)
     # q(f(x)) of the sparse GP layer (build_conditional): dimwise RBF orders 1-2, diagonal inducing covariance, shared hyper-parameters
     cond_case('cond_rbf1', 1, 6, 16, 5, 401)
@@ -319,6 +333,9 @@ if __name__ == '__main__':
     gp_case('gp_rbf2_tiny', 'RBF', 2, N=4, M=16, S=32, q=3, T=5, seed=102)
     gp_case('gp_df1_tiny', 'DF', 1, N=4, M=16, S=32, q=6, T=5, seed=103)
     gp_case('gp_df1_tiny_q4', 'DF', 1, N=5, M=12, S=16, q=4, T=4, seed=104, spread=0.05)
+    # latent widths the reference accepts like any other (main.py:45,77,79): an odd one, and one past the register-resident kernels
+    gp_case('gp_df1_tiny_q5', 'DF', 1, N=5, M=12, S=16, q=5, T=4, seed=109, spread=0.05)
+    gp_case('gp_df1_tiny_q10', 'DF', 1, N=5, M=12, S=16, q=10, T=4, seed=110, spread=0.05)
     # q_diag=True: diagonal inducing covariance, Us_sqrt.optvar (M,Do) under a softplus (svpy.py:79-82,95-96,153-167)
     gp_case('gp_rbf1_tiny_qdiag', 'RBF', 1, N=4, M=16, S=32, q=6, T=5, seed=105, q_diag=True)
     gp_case('gp_df1_tiny_qdiag', 'DF', 1, N=4, M=16, S=32, q=6, T=5, seed=106, q_diag=True)

@@ -267,6 +267,15 @@ STREAM_CASES = [                                   # shapes past the register-re
     ('RBF', 16, 8, 2, 40, 64, 'rk4'),
     ('RBF', 8, 8, 1, 1056, 64, 'euler'),          # eight batched 1056-row factors on the big-factor (panelled / matrix-core) kernels
     ('DF', 16, 16, 1, 512, 256, 'rk4'),           # BASELINE configs[4] at full width: K_uu is 8192 x 8192 (oracle: ~30 s of CPU)
+    # every divergence-free width 2 .. 16 is compiled (main.py:45,77,79 take any integer): the remaining odd / in-between ones
+    ('DF', 7, 7, 1, 40, 64, 'rk4'),               # register-resident team, odd width
+    ('DF', 7, 7, 1, 160, 64, 'euler'),            # the same width streamed (M > 128)
+    ('DF', 9, 9, 1, 24, 64, 'rk4'),               # first width past the register-resident kernels
+    ('DF', 11, 11, 1, 24, 32, 'rk4'),
+    ('DF', 12, 12, 1, 40, 64, 'midpoint'),
+    ('DF', 13, 13, 1, 24, 64, 'euler'),
+    ('DF', 14, 14, 1, 24, 32, 'rk4'),
+    ('DF', 15, 15, 1, 40, 96, 'rk4'),
 ]
 
 
@@ -402,10 +411,13 @@ def test_rbf_widths_outside_the_compiled_list(Di, Do, order, method):
 
 
 def test_df_width_outside_the_compiled_list_is_refused_loudly():
+    """Every divergence-free width 2 .. 16 is compiled (fixtures at 5 and 10, the others in STREAM_CASES); past 16 the layer says so
+    instead of evaluating something else (the DF kernel cannot be zero-padded: it carries the width itself)."""
     from vae_gp_ode_amd import _lib
     from vae_gp_ode_amd.model.core.svpy import SVGP_Layer
-    gp = SVGP_Layer(5, 5, 8, 16, kernel='DF').cuda()
-    with pytest.raises(_lib.GpodeError, match='divergence-free kernel is compiled for D in'):
+    assert all(_lib.load().gpode_supported(1, d, d) for d in range(2, 17))
+    gp = SVGP_Layer(17, 17, 8, 16, kernel='DF').cuda()
+    with pytest.raises(_lib.GpodeError, match='divergence-free kernel is compiled for D = 2 .. 16'):
         gp.build_cache()
 
 

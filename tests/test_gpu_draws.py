@@ -27,7 +27,9 @@ SHAPES = [('rbf_lds', 'RBF', 6, 6, 100, 256, 8, 6, 5),      # six 128-row system
           ('df_tiny', 'DF', 4, 4, 16, 32, 4, 5, 2),          # one 64-row system in LDS
           ('df_chain', 'DF', 6, 6, 100, 256, 8, 6, 5),       # 600 rows: launch chain + k_solve_back (configs[1])
           ('df_big', 'DF', 8, 8, 128, 64, 4, 4, 2),          # 1024 rows: panelled factor, matrix-core updates, panelled solves
-          ('rbf_many', 'RBF', 2, 2, 40, 64, 4, 4, 20)]       # more draws than one 16-column solve slab / one round of 8 wavefronts
+          ('rbf_many', 'RBF', 2, 2, 40, 64, 4, 4, 20),      # more draws than one 16-column solve slab / one round of 8 wavefronts
+          ('df_w5', 'DF', 5, 5, 20, 32, 4, 4, 3),           # widths outside the original compiled list
+          ('df_w11', 'DF', 11, 11, 16, 32, 4, 4, 2)]       # more draws than one 16-column solve slab / one round of 8 wavefronts
 
 
 def _params(kernel, Di, Do, M, seed):

@@ -21,7 +21,9 @@ pytestmark = pytest.mark.gpu
 
 GP_CASES = [('gp_rbf1_tiny', 'RBF', 1), ('gp_rbf2_tiny', 'RBF', 2), ('gp_df1_tiny', 'DF', 1),
             ('gp_df1_tiny_q4', 'DF', 1), ('gp_rbf1_cfg1', 'RBF', 1), ('gp_df1_cfg2', 'DF', 1),
-            ('gp_rbf2_cfg3', 'RBF', 2)]
+            ('gp_rbf2_cfg3', 'RBF', 2),
+            # latent widths the reference accepts like any other (main.py:45,77,79): odd, and past the register-resident kernels
+            ('gp_df1_tiny_q5', 'DF', 1), ('gp_df1_tiny_q10', 'DF', 1)]
 
 
 def relerr(a, b):

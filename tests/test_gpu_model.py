@@ -150,7 +150,7 @@ def test_df_kernel_matrix_matches_reference():
     """`gpode_kernel_matrix(kernel=DF)` (DivergenceFreeKernel.K, kernels.py:289-303) through the public kern.K API against the
     fixture's K(Z) (96 x 96, before the jitter) and K(Z, x) (96 x 24, the asymmetric DF block layout of SURVEY F7/F8)."""
     from test_gpu_backward import make_layer
-    for name in ('gp_df1_tiny', 'gp_df1_tiny_q4', 'gp_df1_cfg2'):
+    for name in ('gp_df1_tiny', 'gp_df1_tiny_q4', 'gp_df1_tiny_q5', 'gp_df1_tiny_q10', 'gp_df1_cfg2'):
         g = load_golden(name)
         flow, gp = make_layer(g, 'DF', 1, 'rk4')
         Z = gp.inducing_loc.optvar.detach()

@@ -9,7 +9,9 @@ from oracle import gpode_oracle as O
 
 GP_CASES = [('gp_rbf1_tiny', 'RBF', 1), ('gp_rbf2_tiny', 'RBF', 2), ('gp_df1_tiny', 'DF', 1),
             ('gp_df1_tiny_q4', 'DF', 1), ('gp_rbf1_cfg1', 'RBF', 1), ('gp_df1_cfg2', 'DF', 1),
-            ('gp_rbf2_cfg3', 'RBF', 2)]
+            ('gp_rbf2_cfg3', 'RBF', 2),
+            # latent widths the reference accepts like any other (main.py:45,77,79): odd, and past the register-resident kernels
+            ('gp_df1_tiny_q5', 'DF', 1), ('gp_df1_tiny_q10', 'DF', 1)]
 SHARED_CASES = [('gp_rbf1_tiny_shared', 'RBF', 1), ('gp_rbf2_tiny_shared', 'RBF', 2)]   # dimwise=False (kernels.py:81-96)
 QDIAG_CASES = [('gp_rbf1_tiny_qdiag', 'RBF', 1), ('gp_df1_tiny_qdiag', 'DF', 1)]   # q_diag=True (svpy.py:79-82)
 

@@ -46,6 +46,12 @@ SIGNATURES = {
     'gpode_cache_bwd_sizes_n': (_i, [_i] * 6 + [_sz_p]),
     'gpode_cache_build_bwd_n': (_i, [_i] * 6 + [_c_float_p] * 13 + [_i, ctypes.c_void_p]),
     'gpode_cache_bwd_prepare_n': (_i, [_i] * 6 + [_c_float_p] * 2 + [ctypes.c_void_p]),
+    # the kernel's own methods (kern.build_cache / sample_freq, kern.compute_nu, kern.f_update)
+    'gpode_kern_scratch': (ctypes.c_size_t, [_i] * 5),
+    'gpode_kern_cache': (_i, [_i] * 4 + [_c_float_p] * 8 + [ctypes.c_void_p]),
+    'gpode_compute_nu_ws': (_i, [_i] * 4 + [_sz_p]),
+    'gpode_compute_nu': (_i, [_i] * 4 + [_c_float_p] * 5 + [ctypes.c_void_p]),
+    'gpode_f_update': (_i, [_i] * 4 + [_c_float_p] * 5 + [_i, _c_float_p, _c_float_p, ctypes.c_void_p]),
 }
 
 _sz = ctypes.c_size_t

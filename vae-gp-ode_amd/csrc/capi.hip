@@ -146,6 +146,32 @@ int gpode_kernel_matrix(int kernel, int Di, int Do, const float* raw_ell, const 
   return gp::kernel_matrix(kernel, Di, Do, raw_ell, raw_var, X, N, X2, M2, out, (hipStream_t)stream);
 }
 
+size_t gpode_kern_scratch(int kernel, int Di, int Do, int M, int S) {
+  if (!gp::dims_supported(kernel, Di, Do) || M < 0 || S < 0) return 0;
+  return gp::kern_scratch_floats(kernel, Di, Do, M, S);
+}
+int gpode_kern_cache(int kernel, int Di, int Do, int S, const float* raw_ell, const float* raw_var, const float* rff_w,
+                     const float* rff_eps, const float* rff_u, float* pack, float* omega, float* phase, void* stream) {
+  if (!raw_ell || !raw_var || !rff_w || !rff_eps || !rff_u || !pack) return gp::set_error("gpode_kern_cache: null pointer");
+  return gp::kern_cache(kernel, Di, Do, S, raw_ell, raw_var, rff_w, rff_eps, rff_u, pack, omega, phase, (hipStream_t)stream);
+}
+int gpode_compute_nu_ws(int kernel, int Di, int Do, int M, size_t* ws_floats) {
+  if (!ws_floats) return gp::set_error("gpode_compute_nu_ws: null pointer");
+  return gp::compute_nu_ws(kernel, Di, Do, M, ws_floats);
+}
+int gpode_compute_nu(int kernel, int Di, int Do, int M, const float* Ku, const float* u_prior, const float* u, float* nu, float* ws,
+                     void* stream) {
+  if (!Ku || !u_prior || !u || !nu || !ws) return gp::set_error("gpode_compute_nu: null pointer");
+  return gp::compute_nu(kernel, Di, Do, M, Ku, u_prior, u, nu, ws, (hipStream_t)stream);
+}
+int gpode_f_update(int kernel, int Di, int Do, int M, const float* raw_ell, const float* raw_var, const float* x2, const float* nu,
+                   const float* x, int N, float* out, float* scratch, void* stream) {
+  if (N < 0) return gp::set_error("gpode_f_update: N=%d", N);
+  if (N == 0) return 0;
+  if (!raw_ell || !raw_var || !x2 || !nu || !x || !out || !scratch) return gp::set_error("gpode_f_update: null pointer");
+  return gp::f_update(kernel, Di, Do, M, raw_ell, raw_var, x2, nu, x, N, out, scratch, (hipStream_t)stream);
+}
+
 int gpode_conditional_ws(int Di, int Do, int M, int N, size_t* ws_floats) {
   if (!ws_floats) return gp::set_error("gpode_conditional_ws: null pointer");
   return gp::conditional_ws(Di, Do, M, N, ws_floats);

@@ -627,7 +627,7 @@ static int launch_bwd_df(const float* pack, int M, int S, const float* xstage, c
 }
 
 #define GP_BWD_RBF_DIMS(X) X(6, 6) X(6, 3) X(4, 4) X(4, 2) X(2, 2) X(2, 1) X(8, 8) X(8, 4) X(3, 3) X(16, 16) X(16, 8) X(12, 6)
-#define GP_BWD_DF_DIMS(X) X(6) X(4) X(2) X(3) X(8) X(16)
+#define GP_BWD_DF_DIMS(X) X(6) X(4) X(2) X(3) X(8) X(16) X(5) X(7) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 template <int DI, int DO>
 static int bwd_rbf_dispatch(int order, int method, const float* pack, int M, int S, const float* xstage, const float* gzt,

@@ -153,10 +153,10 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
   if (blk < a.nb_hyp) {
     // status word, then the smallest / largest diagonal entry of the factor (float bit patterns; positive floats order like
     // unsigned integers, so atomicMin / atomicMax on the bits work)
-    if (threadIdx.x < 4) a.info[threadIdx.x] = threadIdx.x == 1 ? 0x7f800000 : 0;
+    if (a.info && threadIdx.x < 4) a.info[threadIdx.x] = threadIdx.x == 1 ? 0x7f800000 : 0;
     for (int e = tid; e < Do * Di; e += 256) {
       float l = sEll[e];
-      a.ell_ws[e] = l;
+      if (a.ell_ws) a.ell_ws[e] = l;
       if (a.ell_out) a.ell_out[e] = l;
       float il2 = 1.f / (l * l);
       a.uni[e] = -0.5f * GP_LOG2E * il2;            // RBF wl[d][i]  /  DF wab[a][b]
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_prep(PrepArgs a) {
     }
     for (int d = tid; d < Do; d += 256) {
       float v = sVar[d];
-      a.var_ws[d] = v;
+      if (a.var_ws) a.var_ws[d] = v;
       if (a.var_out) a.var_out[d] = v;
       if (a.kernel == 1) a.uni[2 * Do * Di + d] = v;
     }
@@ -756,6 +756,7 @@ __global__ __launch_bounds__(256) void k_solve_back(const float* __restrict__ Aa
     const float v = sv[j];
     nu[(size_t)b * n + j] = v;
     if (nu_out) nu_out[(size_t)b * n + j] = v;
+    if (!pack_ind) continue;                         // kern.compute_nu on its own: no pack to publish into
     // coefficient field of the inducing record (gp_eval.hpp)
     const int RQ2 = cdiv(Di + Do, 4);
     int m, d;
@@ -1138,12 +1139,27 @@ __global__ void k_nu_publish(int n, const float* __restrict__ nu, float* __restr
   pack_ind += (size_t)blockIdx.z * pack_dstride;
   const float v = nu[(size_t)b * n + j];
   if (nu_out) nu_out[(size_t)b * n + j] = v;
+  if (!pack_ind) return;
   const int RQ2 = cdiv(Di + Do, 4);
   int m, d;
   float coef;
   if (kernel == 0) { m = j; d = b; coef = var[d] * v; } else { m = j / Do; d = j % Do; coef = v; }
   const int field = Di + d;
   pack_ind[(((size_t)(m >> 6) * RQ2 + (field >> 2)) * 64 + (m & 63)) * 4 + (field & 3)] = coef;
+}
+
+// A <- a caller's kernel matrix + jitter I, augmented like k_Kzz: rhs row n = u_prior, huge diagonal there, identity padding.
+//   RBF: Ku (Do, M, M), u_prior (M, Do);  DF: Ku (M D, M D), u_prior (M, D) flattened
+__global__ void k_fill_from_K(int kernel, int Do, int n, int np, const float* __restrict__ Ku, const float* __restrict__ u_prior,
+                              float* __restrict__ A) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y, b = blockIdx.z;
+  if (c >= np) return;
+  float v;
+  if (r < n && c < n) v = Ku[((size_t)b * n + r) * n + c] + (r == c ? kJitter : 0.f);
+  else if (r == n) v = c < n ? (kernel == 0 ? u_prior[(size_t)c * Do + b] : u_prior[c]) : (c == n ? 1e30f : 0.f);
+  else v = (r == c) ? 1.f : 0.f;
+  A[((size_t)b * np + r) * np + c] = v;
 }
 
 // dense lower-triangular copy of the factor (zeros above the diagonal)
@@ -1305,6 +1321,101 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S, int nd,
   }
   if (Lu) hipLaunchKernelGGL(k_copy_L, dim3(cdiv(w.n, 128), w.n, w.batch), 128, 0, st, Lmat, Dfac, dstride, w.n, w.np, bstride, Lu);
   return check_launch("cache build");
+}
+
+// ---------------------------------------------------------------------------------------------
+// The kernel's own methods, for a caller that keeps its SVGP_Layer and binds per method (kernels.py:112-137 / :305-316,
+// :155-172 / :376-387, :174-181 / :390-393).  They are the stages of cache_build_fwd above, split where the reference splits them:
+//   kern_cache   kern.build_cache(S): omega = eps / ell, phase = 2 pi u, and a PRIOR-ONLY pack (M = 0 inducing records) that
+//                rhs_fwd(mode 1) evaluates -- kern.rff_forward(x) on the kernel's own Fourier features
+//   compute_nu   kern.compute_nu(Ku, u_prior, u): Cholesky of the CALLER's Ku + jitter I and the two triangular solves
+//   f_update     kern.f_update(x, x2): K(x, x2) nu with the caller's nu -- an UPDATE-ONLY pack (S = 0) from (x2, nu), rhs_fwd(mode 2)
+// scratch: kern_scratch_floats(kernel, Di, Do, M, S) floats = that pack + softplus'd hyper-parameters.
+// ---------------------------------------------------------------------------------------------
+size_t kern_scratch_floats(int kernel, int Di, int Do, int M, int S) {
+  return pack_floats_for(kernel, Di, Do, M, S) + (size_t)cdiv(Do * Di + Do, 4) * 4;
+}
+
+static void kern_prep(int kernel, int Di, int Do, int M, int S, const float* raw_ell, const float* raw_var, const float* Z,
+                      const float* rff_w, const float* rff_eps, const float* rff_u, float* pack, float* omega, float* phase, hipStream_t st) {
+  const size_t SJ = cdiv(S, 64), MJ = cdiv(M, 64);
+  const size_t rff_f4 = (kernel == 0 ? SJ * Do * cdiv(Di + 2, 4) : SJ * Do * cdiv(2 * Do + 3, 4)) * 64;
+  const size_t ind_f4 = (kernel == 0 ? MJ * cdiv(Di + Do, 4) : MJ * cdiv(2 * Do, 4)) * 64;
+  float* hyp = pack + pack_floats_for(kernel, Di, Do, M, S);        // [ell (Do Di) | var (Do)] behind the pack
+  PrepArgs a;
+  a.kernel = kernel; a.Di = Di; a.Do = Do; a.M = M; a.S = S;
+  a.raw_ell = raw_ell; a.raw_var = raw_var; a.Z = Z; a.Um = nullptr; a.Us = nullptr;
+  a.eps_u = nullptr; a.rff_w = rff_w; a.rff_eps = rff_eps; a.rff_u = rff_u;
+  a.pack = pack; a.pack_ind = pack + 4 * rff_f4; a.uni = pack + 4 * (rff_f4 + ind_f4);
+  a.ell_ws = hyp; a.var_ws = hyp + (size_t)Do * Di; a.u_ws = nullptr;
+  a.ell_out = nullptr; a.var_out = nullptr; a.omega_out = omega; a.phase_out = phase; a.u_out = nullptr;
+  a.info = nullptr;
+  a.nb_rff = cdiv((int)(SJ * Do * 64), 256);
+  a.nb_u = 0;                                        // no inducing sample here (sample_inducing is the layer's, svpy.py:88-101)
+  a.nb_ind = cdiv((int)(MJ * 64), 256);
+  a.nb_hyp = 1;
+  a.nb_om = (omega || phase) ? cdiv(Di * S * Do, 256) : 0;
+  a.s_eps_u = a.s_rff_w = a.s_rff_eps = a.s_rff_u = a.s_pack = 0;
+  hipLaunchKernelGGL(k_prep, dim3(a.nb_rff + a.nb_u + a.nb_ind + a.nb_hyp + a.nb_om, 1), 256, 0, st, a);
+}
+
+int kern_cache(int kernel, int Di, int Do, int S, const float* raw_ell, const float* raw_var, const float* rff_w, const float* rff_eps,
+               const float* rff_u, float* pack, float* omega, float* phase, hipStream_t st) {
+  if (!dims_supported(kernel, Di, Do)) return set_error("gpode_kern_cache: no specialisation for kernel=%d Di=%d Do=%d", kernel, Di, Do);
+  if (S < 1) return set_error("gpode_kern_cache: S=%d", S);
+  kern_prep(kernel, Di, Do, 0, S, raw_ell, raw_var, nullptr, rff_w, rff_eps, rff_u, pack, omega, phase, st);
+  return check_launch("kern.build_cache");
+}
+
+int compute_nu_ws(int kernel, int Di, int Do, int M, size_t* ws_floats) {
+  if (!dims_supported(kernel, Di, Do) || M < 1) return set_error("gpode_compute_nu: kernel=%d Di=%d Do=%d M=%d", kernel, Di, Do, M);
+  *ws_floats = ws_layout(kernel, Di, Do, M, 1, 1).total;
+  return 0;
+}
+
+int compute_nu(int kernel, int Di, int Do, int M, const float* Ku, const float* u_prior, const float* u, float* nu, float* ws, hipStream_t st) {
+  size_t need = 0;
+  if (compute_nu_ws(kernel, Di, Do, M, &need)) return 1;
+  const WsLayout w = ws_layout(kernel, Di, Do, M, 1, 1);
+  float* A = ws + w.A;
+  float* Lmat = ws + w.Lmat;
+  float* Dfac = ws + w.Dfac;
+  int* info = reinterpret_cast<int*>(ws + w.info);
+  const size_t bstride = (size_t)w.np * w.np, dstride = (size_t)w.nblk * NB * NB, MD = (size_t)M * Do;
+  if (hipMemsetAsync(info, 0, 4 * sizeof(int), st) != hipSuccess) return set_error("gpode_compute_nu: memset failed");
+  hipLaunchKernelGGL(k_fill_from_K, dim3(cdiv(w.np, 128), w.np, w.batch), 128, 0, st, kernel, Do, w.n, w.np, Ku, u_prior, A);
+  cholesky_blocked(A, Lmat, Dfac, w.np, w.nblk, w.batch, info, st, w.n);
+  if (check_launch("compute_nu: cholesky")) return 1;
+  const int u_stride = kernel == 0 ? Do : 1, u_bstride = kernel == 0 ? 1 : 0;
+  if (big_factor(w.np)) {
+    const int npanel = cdiv(w.n, ST);
+    for (int P = npanel - 1; P >= 0; --P)
+      hipLaunchKernelGGL(k_solve_back_panel, dim3(P + 1, w.batch, 1), 256, 0, st, Lmat, w.n, w.np, bstride, Dfac, dstride, u,
+                         u_stride, u_bstride, A, ws + w.nu, P, P == npanel - 1 ? 1 : 0, MD, MD);
+    hipLaunchKernelGGL(k_nu_publish, dim3(cdiv(w.n, 256), w.batch, 1), 256, 0, st, w.n, ws + w.nu, nu, kernel, Di, Do, (const float*)nullptr,
+                       (float*)nullptr, MD, (size_t)0);
+  } else {
+    const size_t lds = sizeof(float) * w.np;
+    if (set_max_lds((const void*)k_solve_back<0>, lds)) return 1;
+    hipLaunchKernelGGL(k_solve_back<0>, dim3(w.batch, 1), 256, lds, st, Lmat, w.n, w.np, bstride, Dfac, dstride, u, u_stride, u_bstride,
+                       ws + w.nu, nu, kernel, Di, Do, M, (const float*)nullptr, (float*)nullptr, MD, MD, (size_t)0);
+  }
+  return check_launch("kern.compute_nu");
+}
+
+int f_update(int kernel, int Di, int Do, int M, const float* raw_ell, const float* raw_var, const float* x2, const float* nu,
+             const float* x, int N, float* out, float* pack, hipStream_t st) {
+  if (!dims_supported(kernel, Di, Do) || M < 1) return set_error("gpode_f_update: kernel=%d Di=%d Do=%d M=%d", kernel, Di, Do, M);
+  kern_prep(kernel, Di, Do, M, 0, raw_ell, raw_var, x2, nullptr, nullptr, nullptr, pack, nullptr, nullptr, st);
+  const size_t MJ = cdiv(M, 64);
+  (void)MJ;
+  float* pack_ind = pack;                             // S = 0: the inducing records open the pack
+  const float* var = pack + pack_floats_for(kernel, Di, Do, M, 0) + (size_t)Do * Di;
+  const int n = kernel == 0 ? M : M * Do, batch = kernel == 0 ? Do : 1;
+  hipLaunchKernelGGL(k_nu_publish, dim3(cdiv(n, 256), batch, 1), 256, 0, st, n, nu, (float*)nullptr, kernel, Di, Do, var, pack_ind,
+                     (size_t)0, (size_t)0);
+  if (check_launch("kern.f_update: pack")) return 1;
+  return rhs_fwd(kernel, Di, Do, M, 0, pack, x, N, out, 2, st);
 }
 
 // ---------------------------------------------------------------------------------------------

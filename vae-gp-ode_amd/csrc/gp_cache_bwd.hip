@@ -1217,9 +1217,9 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, int nd, const floa
                        bws + b.gZpart, bws + b.kpart, g_raw_ell, g_raw_var, g_Z, nd, pf);                                  \
     return check_launch("cache bwd: chain df");                                                                            \
   }
-  X(6) X(4) X(2) X(3) X(8) X(16)
+  X(6) X(4) X(2) X(3) X(8) X(16) X(5) X(7) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 #undef X
-  return set_error("gpode_cache_build_bwd: DF backward is built for D in {2,3,4,6,8,16}");
+  return set_error("gpode_cache_build_bwd: DF backward is built for D = 2 .. 16");
 }
 
 }  // namespace gp

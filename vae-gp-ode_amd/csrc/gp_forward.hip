@@ -514,7 +514,7 @@ static int launch_rollout_df(const float* pack, int M, int S, const float* z0, c
 
 // dispatch tables -----------------------------------------------------------------------------
 #define GP_RBF_DIMS(X) X(6, 6) X(6, 3) X(4, 4) X(4, 2) X(2, 2) X(2, 1) X(8, 8) X(8, 4) X(16, 16) X(16, 8) X(3, 3) X(12, 6)
-#define GP_DF_DIMS(X) X(6) X(4) X(2) X(3) X(8) X(16)
+#define GP_DF_DIMS(X) X(6) X(4) X(2) X(3) X(8) X(16) X(5) X(7) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 int rhs_fwd(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, int N, float* f, int mode, hipStream_t st, Draws dw) {
   if (kernel == 0) {

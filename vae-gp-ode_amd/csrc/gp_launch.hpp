@@ -83,6 +83,13 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S, int nd,
                     float* pack, float* ws, float* ell, float* var, float* omega, float* phase, float* u,
                     float* Lu, float* nu, float* u_prior, hipStream_t st);
 
+size_t kern_scratch_floats(int kernel, int Di, int Do, int M, int S);
+int kern_cache(int kernel, int Di, int Do, int S, const float* raw_ell, const float* raw_var, const float* rff_w, const float* rff_eps,
+               const float* rff_u, float* pack, float* omega, float* phase, hipStream_t st);
+int compute_nu_ws(int kernel, int Di, int Do, int M, size_t* ws_floats);
+int compute_nu(int kernel, int Di, int Do, int M, const float* Ku, const float* u_prior, const float* u, float* nu, float* ws, hipStream_t st);
+int f_update(int kernel, int Di, int Do, int M, const float* raw_ell, const float* raw_var, const float* x2, const float* nu,
+             const float* x, int N, float* out, float* pack, hipStream_t st);
 int kernel_matrix(int kernel, int Di, int Do, const float* raw_ell, const float* raw_var, const float* X, int N,
                   const float* X2, int M2, float* out, hipStream_t st);
 int conditional_ws(int Di, int Do, int M, int N, size_t* ws_floats);

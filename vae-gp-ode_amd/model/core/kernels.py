@@ -6,6 +6,7 @@ Same class names, constructor signatures, parameter names/shapes (``unconstraine
 (csrc/gp_cache.hip, csrc/gp_forward.hip) behind the C ABI of include/gpode.h.  Only the dimwise RBF
 (reference default, main.py:63) and the divergence-free kernel are on the hot path.
 """
+import numpy as np
 import torch
 from torch import nn
 
@@ -53,6 +54,7 @@ class RBF(nn.Module):
     # -- cached per-draw state (set by SVGP_Layer.build_cache) ---------------------------------
     def _set_cache(self, cache, noise):
         self._cache = cache
+        self._kern_nu = None
         if cache.stacked:
             # L draws built together: the attributes show the LAST one, as after the reference's loop (odegpvae.py:41-43).  The
             # views are taken lazily -- indexing launches nothing, but keep the torch-native work off a side-stream build
@@ -80,6 +82,66 @@ class RBF(nn.Module):
             self.rff_omega, self.rff_phase = cache.omega[..., 0], cache.phase[..., 0]
             self.nu = cache.nu.reshape(self.D_out, -1).t()
 
+    # -- the kernel's own per-draw methods (a caller that keeps its own SVGP_Layer binds these) -------------------------------
+    def _draw(self, shape, seed=None, uniform=False):
+        """The reference's sample_normal / sample_uniform (kernels.py:13-26): a fresh RandomState per call for the normals (so
+        --seed does not reach them), the global numpy RNG for an unseeded uniform."""
+        if uniform and seed is None:
+            return torch.tensor(np.random.uniform(low=0.0, high=1.0, size=shape).astype(np.float32))
+        rng = np.random.RandomState() if seed is None else np.random.RandomState(seed)
+        return torch.tensor((rng.uniform(low=0.0, high=1.0, size=shape) if uniform else rng.normal(size=shape)).astype(np.float32))
+
+    def _per_output(self, eps, u):
+        """Shared draws of the non-dimwise kernel (D_in,S) / (1,S) repeated per output, as the kernels consume them."""
+        if eps.dim() == 2:
+            eps = eps.unsqueeze(-1).expand(-1, -1, self.D_out).contiguous()
+        if u is not None and u.dim() == 2:
+            u = u.unsqueeze(-1).expand(-1, -1, self.D_out).contiguous()
+        return eps, u
+
+    def _kern_cache(self, rff_w, rff_eps, rff_u, device):
+        ell, var = self.raw_dimwise()
+        eps3, u3 = self._per_output(rff_eps.to(device), rff_u.to(device))
+        return ops.kern_cache(self.kernel_id, ell.detach(), var.detach(), rff_w.to(device), eps3, u3)
+
+    def sample_freq(self, S, seed=None, device='cpu'):
+        """omega = eps / lengthscales^T, eps ~ N(0, 1): a sample from the spectral density (kernels.py:112-124).
+        -> (D_in, S, D_out), or (D_in, S) for the shared-parameter kernel."""
+        dim3 = self.dimwise or self.kernel_id != 'RBF'
+        eps = self._draw((self.D_in, S, self.D_out) if dim3 else (self.D_in, S), seed)
+        dev = self.unconstrained_lengthscales.device
+        c = self._kern_cache(torch.zeros((S if self.kernel_id == 'RBF' else 2 * S), self.D_out), eps, torch.zeros(1, S, self.D_out), dev)
+        return c.omega if dim3 else c.omega[..., 0]
+
+    def build_cache(self, S, device=None, noise=None):
+        """Fix the Fourier features of one prior draw: rff_weights, rff_omega, rff_phase (kernels.py:126-137 / :305-316);
+        kern.rff_forward(x, S) then evaluates THIS draw.  ``noise``: dict(rff_w, rff_eps, rff_u) instead of drawing (the draw
+        order without it is the reference's: weights, frequencies, phases)."""
+        dim3 = self.dimwise or self.kernel_id != 'RBF'
+        if noise is None:
+            noise = dict(rff_w=self._draw((S if self.kernel_id == 'RBF' else 2 * S, self.D_out)),
+                         rff_eps=self._draw((self.D_in, S, self.D_out) if dim3 else (self.D_in, S)),
+                         rff_u=self._draw((1, S, self.D_out) if dim3 else (1, S), uniform=True))
+        dev = self.unconstrained_lengthscales.device
+        c = self._kern_cache(noise['rff_w'], noise['rff_eps'], noise['rff_u'], dev)
+        self._cache, self._kern_nu = c, None
+        self.rff_weights = c.noise['rff_w']
+        self.rff_omega, self.rff_phase = (c.omega, c.phase) if dim3 else (c.omega[..., 0], c.phase[..., 0])
+        self.nu = None
+        return c
+
+    def compute_nu(self, Ku, u_prior, inducing_val):
+        """nu = K(Z,Z)^-1 (u - f_prior(Z)) in whitened form, from the caller's Ku / u_prior / u (kernels.py:155-172 / :376-387);
+        sets ``self.nu`` ((D_out,M,1) dimwise RBF, (M,D_out) shared RBF, (M D,1) DF) for kern.f_update(x, x2)."""
+        dev = self.unconstrained_lengthscales.device
+        Kd = Ku.to(dev, torch.float32)
+        if self.kernel_id == 'RBF' and not self.dimwise:      # one (M,M) matrix shared by all outputs
+            Kd = Kd.unsqueeze(0).expand(self.D_out, -1, -1).contiguous()
+        nu, ws = ops.compute_nu(self.kernel_id, self.D_in, self.D_out, Kd, u_prior.to(dev, torch.float32), inducing_val.to(dev, torch.float32))
+        self._kern_nu, self._kern_nu_ws = nu, ws
+        self.nu = nu if (self.dimwise or self.kernel_id != 'RBF') else nu.reshape(self.D_out, -1).t()
+        return self.nu
+
     def _need_cache(self):
         if self._cache is None:
             raise RuntimeError('call SVGP_Layer.build_cache() first (flow.py:22-25 does it before every odeint)')
@@ -90,7 +152,11 @@ class RBF(nn.Module):
         return self._rhs(x, 1)
 
     def f_update(self, x, x2=None):
-        """Pathwise update K(x,Z) nu with the cached nu (kernels.py:174-181 / :390-393)."""
+        """Pathwise update K(x,Z) nu with the cached nu (kernels.py:174-181 / :390-393).  After kern.compute_nu(...) it is
+        evaluated on the given x2 with that nu; inside a layer-built draw the cached (Z, nu) are used."""
+        if getattr(self, '_kern_nu', None) is not None and x2 is not None:
+            ell, var = self.raw_dimwise()
+            return ops.f_update(self.kernel_id, ell.detach(), var.detach(), x, x2.to(x.device, torch.float32), self._kern_nu)
         return self._rhs(x, 2)
 
     def _rhs(self, x, mode):

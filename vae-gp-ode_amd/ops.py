@@ -208,6 +208,60 @@ def _one_draw(cache, what):
         raise _lib.GpodeError('%s evaluates ONE function draw; this cache holds %d (use rollout / the flow)' % (what, cache.nd))
 
 
+def kern_cache(kernel, raw_ell, raw_var, rff_w, rff_eps, rff_u):
+    """kern.build_cache(S, device) (kernels.py:126-137 / :305-316): fixes the Fourier features of ONE prior draw.  Returns a GPCache
+    without inducing records (M = 0): rhs(cache, x, mode=1) is kern.rff_forward(x, S); cache.omega / cache.phase are the
+    attributes the reference sets (kern.sample_freq's omega = eps / ell^T inside)."""
+    Do, Di = raw_ell.shape
+    S = rff_eps.shape[1]
+    raw_ell = _chk(raw_ell, 'raw_ell', (Do, Di)); raw_var = _chk(raw_var, 'raw_var', (Do,))
+    rff_w = _chk(rff_w, 'rff_w', (S if kernel == 'RBF' else 2 * S, Do))
+    rff_eps = _chk(rff_eps, 'rff_eps', (Di, S, Do)); rff_u = _chk(rff_u, 'rff_u', (1, S, Do))
+    n = _lib.load().gpode_kern_scratch(KERNEL_ID[kernel], Di, Do, 0, S)
+    if n == 0:
+        raise _lib.GpodeError('kern.build_cache: no specialisation for kernel=%s D_in=%d D_out=%d' % (kernel, Di, Do))
+    new = lambda *s: torch.empty(s, dtype=torch.float32, device=raw_ell.device)
+    c = GPCache()
+    c.kernel, c.Di, c.Do, c.M, c.S, c.nd, c.stacked = kernel, Di, Do, 0, S, 1, False
+    c.pack, c.ws, c.omega, c.phase = new(n), None, new(Di, S, Do), new(1, S, Do)
+    c.ell = c.var = c.u = c.Lu = c.nu = c.u_prior = None
+    c.noise = dict(rff_w=rff_w, rff_eps=rff_eps, rff_u=rff_u)
+    _lib.call('gpode_kern_cache', KERNEL_ID[kernel], Di, Do, S, _ptr(raw_ell), _ptr(raw_var), _ptr(rff_w), _ptr(rff_eps), _ptr(rff_u),
+              _ptr(c.pack), _ptr(c.omega), _ptr(c.phase), _stream())
+    return c
+
+
+def compute_nu(kernel, Di, Do, Ku, u_prior, u):
+    """kern.compute_nu(Ku, u_prior, inducing_val) (kernels.py:155-172 / :376-387) on the CALLER's kernel matrix: nu = L^-T (u - L^-1 u_prior),
+    L = chol(Ku + 1e-5 I).  RBF: Ku (Do,M,M) -> nu (Do,M,1); DF: Ku (M D, M D) -> nu (M D, 1).  Returns (nu, workspace) -- the
+    workspace holds the factorisation status (GPCache.check_factorisation reads it the same way)."""
+    M = u.shape[0]
+    Ku = _chk(Ku, 'Ku', (Do, M, M) if kernel == 'RBF' else (M * Do, M * Do))
+    u_prior = _chk(u_prior, 'u_prior', (M, Do)); u = _chk(u, 'inducing_val', (M, Do))
+    wf = ctypes.c_size_t(0)
+    _lib.call('gpode_compute_nu_ws', KERNEL_ID[kernel], Di, Do, M, ctypes.byref(wf))
+    ws = torch.empty(wf.value, dtype=torch.float32, device=u.device)
+    nu = torch.empty((Do, M, 1) if kernel == 'RBF' else (M * Do, 1), dtype=torch.float32, device=u.device)
+    _lib.call('gpode_compute_nu', KERNEL_ID[kernel], Di, Do, M, _ptr(Ku), _ptr(u_prior), _ptr(u), _ptr(nu), _ptr(ws), _stream())
+    return nu, ws
+
+
+def f_update(kernel, raw_ell, raw_var, x, x2, nu):
+    """kern.f_update(x, x2) (kernels.py:174-181 / :390-393): K(x, x2) nu for a nu from compute_nu -> (N, D_out)."""
+    Do, Di = raw_ell.shape
+    M, N = x2.shape[0], x.shape[0]
+    x = _chk(x, 'x', (N, Di)); x2 = _chk(x2, 'x2', (M, Di))
+    nu = _chk(nu, 'nu', (Do, M, 1) if kernel == 'RBF' else (M * Do, 1))
+    n = _lib.load().gpode_kern_scratch(KERNEL_ID[kernel], Di, Do, M, 0)
+    if n == 0:
+        raise _lib.GpodeError('kern.f_update: no specialisation for kernel=%s D_in=%d D_out=%d' % (kernel, Di, Do))
+    scratch = torch.empty(n, dtype=torch.float32, device=x.device)
+    out = torch.empty((N, Do), dtype=torch.float32, device=x.device)
+    _lib.call('gpode_f_update', KERNEL_ID[kernel], Di, Do, M, _ptr(_chk(raw_ell, 'raw_ell', (Do, Di))), _ptr(_chk(raw_var, 'raw_var', (Do,))),
+              _ptr(x2), _ptr(nu), _ptr(x), N, _ptr(out), _ptr(scratch), _stream())
+    return out
+
+
 def rhs(cache, x, mode=0):
     """SVGP_Layer.forward (svpy.py:123-142): x (N,Di) -> f (N,Do). mode 1: prior only, 2: update only."""
     x = _chk(x, 'x')
@@ -321,7 +375,7 @@ def kernel_matrix(kernel, raw_ell, raw_var, X, X2=None):
 #   state components stay 0 along the whole trajectory (their own K_uu systems are factored and discarded).
 # The padding is a differentiable scatter / slice in torch on (M, D)-sized tensors; the kernels are the compiled ones.
 # The divergence-free kernel is NOT padded: its matrix-valued kernel carries the width itself (the (D - 1) of kernels.py:296 and the
-# normalisation of B(omega), kernels.py:327-336), so it runs at its compiled widths D in {2, 3, 4, 6, 8, 16} only.
+# normalisation of B(omega), kernels.py:327-336); it is compiled for every width D = 2 .. 16 instead.
 # ---------------------------------------------------------------------------------------------
 _RBF_COMPILED = None
 
@@ -394,8 +448,8 @@ def width_pad(kernel, Di, Do):
     if _lib.load().gpode_supported(KERNEL_ID[kernel], Di, Do):
         return None
     if kernel != 'RBF':
-        raise _lib.GpodeError('the divergence-free kernel is compiled for D in {2, 3, 4, 6, 8, 16}; D = %d is not (its kernel carries '
-                              'the width itself, so it cannot be evaluated on zero-padded operands)' % Do)
+        raise _lib.GpodeError('the divergence-free kernel is compiled for D = 2 .. 16 with D_in == D_out; (%d, %d) is not (its kernel '
+                              'carries the width itself, so it cannot be evaluated on zero-padded operands)' % (Di, Do))
     return WidthPad(Di, Do)
 
 
