@@ -339,7 +339,7 @@ def main():
 
 
 def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
-    from vae_gp_ode_amd.model.create_model import compute_loss
+    from vae_gp_ode_amd.model.create_model import backward, compute_loss
     from vae_gp_ode_amd.optim import HipAdam
     from vae_gp_ode_amd.parallel import GradAllReduce
     model, X = make_model_inputs(w, a.seed, dev, rank)
@@ -367,7 +367,7 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
     def fwd_bwd():
         opt.zero_grad()
         loss, nl, klr, klu = compute_loss(model, Xd, a.L)
-        loss.backward()
+        backward(loss)
         ops.join_side_stream()
         return loss
 
@@ -529,7 +529,7 @@ def quick_elbo(w, dev, seed, steps=30, warmup=5, L=1):
     overlap as set by the caller): (ms per step, model, X)."""
     from vae_gp_ode_amd import ops
     from vae_gp_ode_amd.graph import GraphedStep, device_generators
-    from vae_gp_ode_amd.model.create_model import compute_loss
+    from vae_gp_ode_amd.model.create_model import backward, compute_loss
     from vae_gp_ode_amd.optim import HipAdam
     model, X = make_model_inputs(w, seed, dev, 0)
     Xd = X.to(dev)
@@ -538,7 +538,7 @@ def quick_elbo(w, dev, seed, steps=30, warmup=5, L=1):
     def whole_step():
         opt.zero_grad()
         loss, *_ = compute_loss(model, Xd, L)
-        loss.backward()
+        backward(loss)
         ops.join_side_stream()
         opt.step()
         return loss

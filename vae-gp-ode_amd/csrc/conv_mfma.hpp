@@ -608,7 +608,7 @@ template <class L, int IPB> constexpr size_t wgrad_lds_bytes() {
 
 // gw[ci][co][tap] = sum_s part[s][tap][mt][nt][r][lane] (the accumulator layout of k_convT_wgrad_mfma), fixed order.
 // grid = ceil(n / 64), block = 1024 (64 elements x 16 split groups).
-__global__ __launch_bounds__(1024) void k_sum_splits_wgrad(const float* __restrict__ part, int nsplit, int MT, int NT, int KK,
+static __global__ __launch_bounds__(1024) void k_sum_splits_wgrad(const float* __restrict__ part, int nsplit, int MT, int NT, int KK,
                                                             float* __restrict__ gw) {
   __shared__ float red[16][64];
   const int ex = threadIdx.x & 63, sg = threadIdx.x >> 6;
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(1024) void k_sum_splits_wgrad(const float* __restri
 
 // out[e] = sum_s part[s][e] in a fixed order: 16 interleaved partial sums per element, combined through LDS.
 // grid = ceil(n / 64), block = 1024 (64 elements x 16 split groups).
-__global__ __launch_bounds__(1024) void k_sum_splits4(const float* __restrict__ part, int nsplit, size_t n, float* __restrict__ out) {
+static __global__ __launch_bounds__(1024) void k_sum_splits4(const float* __restrict__ part, int nsplit, size_t n, float* __restrict__ out) {
   __shared__ float red[16][64];
   const int ex = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const size_t e = (size_t)blockIdx.x * 64 + ex;

@@ -21,6 +21,7 @@
 #include <cstdint>
 #include "gp_launch.hpp"
 #include <type_traits>
+#include "conv_layers.hpp"
 #include "conv_mfma.hpp"
 #include "conv_dec10_mfma.hpp"
 #include "conv_dec1_mfma.hpp"
@@ -28,31 +29,7 @@
 
 namespace gp {
 
-constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-// ConvTranspose2d(CI -> CO, K, stride S, padding P, output_padding OP), square HI x HI -> HO x HO
-template <int CI_, int CO_, int HI_, int HO_, int OP_, int K_ = 5, int S_ = 2, int P_ = 1> struct CTLayer {
-  static constexpr int CI = CI_, CO = CO_, HI = HI_, HO = HO_, OP = OP_, K = K_, S = S_, P = P_;
-  static_assert(HO == (HI - 1) * S - 2 * P + K + OP, "geometry");
-  // gather form: oy = S qy + py - P, taps ky = py + S t, iy = qy - t
-  static constexpr int PL = (K - 1) / S;                             // zero rows/cols before (max t)
-  static constexpr int QMAX = (HO - 1 + P) / S;                      // largest qy
-  static constexpr int PH = cmax(0, QMAX - (HI - 1));                // zero rows/cols after
-  static constexpr int HP = HI + PL + PH;                            // padded input extent
-  // channel-plane stride of the staged image: == 16 (mod 32) floats, so that the four 16-lane groups of an MFMA
-  // operand fetch (4 consecutive channels x 16 consecutive pixels) fall on disjoint LDS banks
-  static constexpr int PS = ((HP * HP + 15) / 32) * 32 + 16;
-  static constexpr int GP_ = cmax((HI - 1) * S + K, HO + P);         // padded grad_output extent, index = oy + P
-};
-using Dec1 = CTLayer<32, 64, 4, 6, 0, 3, 1, 0>;
-using Dec4 = CTLayer<64, 32, 6, 13, 0>;
-using Dec7 = CTLayer<32, 16, 13, 28, 1>;
-using Dec10 = CTLayer<16, 1, 28, 28, 0, 5, 1, 2>;
-// the encoder's Conv2d layers, described as the transposed convolutions they are the adjoint of (vae.py:52-59: k5 s2 p2):
-// cnn.3 8 -> 16 ch, 14 -> 7 and cnn.6 16 -> 32 ch, 7 -> 4.  Only the directions whose channel counts fill MFMA tiles
-// (source channels % 4, output channels % 16) take the matrix-core engine; cnn.0 (1 or 5 input channels) stays generic.
-using Enc3 = CTLayer<16, 8, 7, 14, 1, 5, 2, 2>;
-using Enc6 = CTLayer<32, 16, 4, 7, 0, 5, 2, 2>;
 
 extern __shared__ __attribute__((aligned(16))) float tsm[];
 
@@ -464,6 +441,15 @@ static int launch_wgrad_mfma(const float* x, const float* gy, float* gw, float* 
   return check_launch("convT_wgrad_mfma");
 }
 
+// second engine (conv_wgrad_v2.hpp, its own translation unit vae_wgrad_v2.hip): 8 consumer + 4 producer wavefronts, one image per plane
+// buffer.  GPODE_WGRAD_V1=1: the first engine (A/B)
+int wgrad_v2_dec7(const float* x, const float* gy, float* gw, float* scratch, int B, hipStream_t st, const float* in_bn);
+int wgrad_v2_dec4(const float* x, const float* gy, float* gw, float* scratch, int B, hipStream_t st, const float* in_bn);
+static bool wgrad_v2_enabled() {
+  static const bool off = [] { const char* e = getenv("GPODE_WGRAD_V1"); return e && e[0] == '1'; }();
+  return !off && use_mfma();
+}
+
 // IPBM / WM x WN x WT: images per group and wavefront split (ci tiles, co tiles, taps) of the MFMA kernel
 template <class L, int COW, int IPBM, int WM, int WN, int WT, bool PIPE>
 static int launch_T3(const float* x, const float* gy, float* gw, float* scratch, int B, hipStream_t st, const float* in_bn) {
@@ -647,8 +633,15 @@ int dec10_bn_bwd_apply(const float* c, const float* gy, const float* w, const fl
 int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch, int B, int Ci, int H, int W, int Co, int K, int S,
                      int P, int Ho, int Wo, const float* in_bn, hipStream_t st) {
   if (H != W || Ho != Wo) return -1;
-  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec7, 16, 2, 1, 1, 8, true>(gy, x, gw, scratch, B, st, in_bn);
-  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) return launch_T3<Dec4, 16, 2, 4, 2, 1, false>(gy, x, gw, scratch, B, st, in_bn);
+  const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0;
+  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) {
+    if (wgrad_v2_enabled() && aligned) return wgrad_v2_dec7(gy, x, gw, scratch, B, st, in_bn);
+    return launch_T3<Dec7, 16, 2, 1, 1, 8, true>(gy, x, gw, scratch, B, st, in_bn);
+  }
+  if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) {
+    if (wgrad_v2_enabled() && aligned) return wgrad_v2_dec4(gy, x, gw, scratch, B, st, in_bn);
+    return launch_T3<Dec4, 16, 2, 4, 2, 1, false>(gy, x, gw, scratch, B, st, in_bn);
+  }
   if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) {
     static const bool old = [] { const char* e = getenv("GPODE_DEC1_ENGINE"); return e && e[0] == '1'; }();
     if (!in_bn && use_mfma() && !old && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {   // gy: the layer's input, x: grad_output

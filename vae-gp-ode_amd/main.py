@@ -192,7 +192,7 @@ def cache_results(logger, args, ep, build_model):
 def main(argv=None):
     args = make_parser().parse_args(argv)
     from .model.core.initialization import initialize_and_fix_kernel_parameters
-    from .model.create_model import build_model, compute_loss, compute_test_error
+    from .model.create_model import build_model, compute_loss, compute_test_error, backward
     from .model.misc.torch_utils import seed_everything
     from .optim import HipAdam
 
@@ -277,7 +277,7 @@ def main(argv=None):
             def step():
                 optimizer.zero_grad()
                 out = compute_loss(model, buf, L)
-                out[0].backward()
+                backward(out[0])
                 if sync is None:
                     optimizer.step()
                 else:                                # the all-reduce and the Adam launch stay between the replays
@@ -331,7 +331,7 @@ def main(argv=None):
             graphed = args.hip_graph and capture_ok
             if not graphed:
                 optimizer.zero_grad()
-                loss.backward()
+                backward(loss)
             if sync is not None:
                 sync.all_reduce_grads()
             if not graphed or sync is not None:

@@ -19,14 +19,30 @@ class ODEfunc(nn.Module):
         self.diffeq = diffeq
         self.order = order
         self.register_buffer('_num_evals', torch.tensor(0.))
+        self._host_evals = None                      # count of the last fused solve, not yet written to the buffer
 
     def before_odeint(self, rebuild_cache):
+        self._host_evals = None
         self._num_evals.fill_(0)
         if rebuild_cache:
             self.diffeq.build_cache()
 
+    def _set_evals(self, n):
+        """The fused rollout knows its evaluation count on the host: the ``_num_evals`` buffer (a state_dict entry of the
+        reference, flow.py:14) is brought up to date when somebody looks -- not by a fill and an add on the device in every step."""
+        self._host_evals = float(n)
+
+    def _flush_evals(self):
+        if self._host_evals is not None:
+            self._num_evals.fill_(self._host_evals)
+            self._host_evals = None
+
     def num_evals(self):
-        return self._num_evals.item()
+        return self._host_evals if self._host_evals is not None else self._num_evals.item()
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._flush_evals()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
 
     def first_order(self, sv):
         return self.diffeq(sv)
@@ -37,6 +53,7 @@ class ODEfunc(nn.Module):
 
     def forward(self, t, sv):
         """One RHS evaluation (flow.py:40-45); autonomous, ``t`` ignored."""
+        self._flush_evals()
         self._num_evals += 1
         return self.first_order(sv) if self.order == 1 else self.second_order(sv)
 
@@ -56,9 +73,8 @@ class Flow(nn.Module):
         if self.solver not in EVALS_PER_STEP:
             raise ValueError("solver '%s': this build integrates on the fixed grid with 'euler', 'midpoint' or 'rk4' only" % self.solver)
         gp = self.odefunc.diffeq
-        self.odefunc._num_evals.fill_(0)
         zt = ops.flow(gp, z0, ts, self.odefunc.order, self.solver, draws)
-        self.odefunc._num_evals += EVALS_PER_STEP[self.solver] * (ts.shape[0] - 1)
+        self.odefunc._set_evals(EVALS_PER_STEP[self.solver] * (ts.shape[0] - 1))
         return zt
 
     def num_evals(self):

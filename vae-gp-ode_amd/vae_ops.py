@@ -519,6 +519,7 @@ class _SigmoidLogLikParts(torch.autograd.Function):
         ctx.save_for_backward(X, z)
         ctx.rows, ctx.inner = rows, inner
         ctx.mark_non_differentiable(z)
+        ctx.set_materialize_grads(False)             # no zero-filled stand-in for the gradient of z (a fill of rows x inner floats per step)
         return part, z
 
     @staticmethod
