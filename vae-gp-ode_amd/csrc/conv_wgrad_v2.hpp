@@ -26,6 +26,12 @@
 
 namespace gp {
 
+// LDS floats: two plane buffers, the BatchNorm table, the pixel-window table, optionally the producers' scatter table of gy
+template <class L> constexpr size_t wgrad_v2_lds_floats(bool gtab) {
+  return (size_t)2 * (WgradGeo<L>::IMGX + WgradGeo<L>::IMGG) + (size_t)4 * L::CI + (size_t)4 * (WgradGeo<L>::NKS + 1) +
+         (gtab ? (size_t)L::CO * L::HO * L::HO : 0);
+}
+
 template <class L> struct WgV2 {
   using G = WgradGeo<L>;
   static constexpr int MT = L::CI / 16, NT = L::CO / 16, KK = L::K * L::K, NUA = KK * MT * NT, NCW = 8;
@@ -94,25 +100,34 @@ __device__ __forceinline__ void wgrad_v2_image(const float* __restrict__ s_x, co
     });
   };
   if constexpr (PIPE) {
-    // One rolled loop body: request step s + 1 into the B set (and the table entry of step s + 2), multiply step s out of the A
-    // set, then move B -> A.  The only LDS wait of the body sits behind the MFMAs, where the reads have long landed.  (The
-    // two-set alternation with `if (s + 1 < NKS) fetch(...)` in each half left the compiler without a count of the reads in
-    // flight at the joins: it waited for lgkmcnt(0) in FRONT of the MFMAs.)  The last step requests one step too many (table
-    // row NKS repeats row NKS - 1; the x read runs 4 floats past the pixels, inside the workgroup's planes): never used.
-    fetch(xq, gq + tq[0], afA, bfA);
+    // Two register sets, alternating, every request UNCONDITIONAL and fenced in front of the MFMAs of the previous step (the
+    // machine scheduler otherwise sinks the reads to their first use; with `if (s + 1 < NKS) fetch(...)` the compiler loses count
+    // of the reads in flight at the join and waits for lgkmcnt(0) in front of the MFMAs).  No register copies: on this chip the
+    // fp32 MFMA runs on the SIMD's vector issue -- the phase probes fit  cycles = 32 x MFMAs + 4 x (every other vector / LDS
+    // instruction of ALL wavefronts of the SIMD)  -- so a v_mov beside an MFMA is not free, it is 1/8 of one.
     int g1 = tq[4];
+    fetch(xq, gq + tq[0], afA, bfA);
+    int s = 0;
 #pragma nounroll
-    for (int s = 0; s < NKS; ++s) {
+    for (; s + 2 < NKS; s += 2) {                    // A holds step s
       fetch(xq + 4 * (s + 1), gq + g1, afB, bfB);
-      const int g2 = tq[4 * min(s + 2, NKS)];
+      const int g2 = tq[4 * (s + 2)];
       __builtin_amdgcn_sched_barrier(0);
       mma(afA, bfA);
       __builtin_amdgcn_sched_barrier(0);
-      static_for<MT>([&](auto m) { afA[decltype(m)::value] = afB[decltype(m)::value]; });
-      static_for<NTP>([&](auto tt) {
-        static_for<NT>([&](auto nn) { bfA[decltype(tt)::value][decltype(nn)::value] = bfB[decltype(tt)::value][decltype(nn)::value]; });
-      });
-      g1 = g2;
+      fetch(xq + 4 * (s + 2), gq + g2, afA, bfA);
+      g1 = tq[4 * (s + 3)];                          // (table row NKS exists: it repeats row NKS - 1)
+      __builtin_amdgcn_sched_barrier(0);
+      mma(afB, bfB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (NKS % 2 == 0) {                              // steps NKS - 2 (in A) and NKS - 1
+      fetch(xq + 4 * (s + 1), gq + g1, afB, bfB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(afA, bfA);
+      mma(afB, bfB);
+    } else {
+      mma(afA, bfA);                                 // step NKS - 1
     }
   } else {                                           // register-bound tile ranges (decnn.4: 25 tiles = 100 accumulator registers under the
 #pragma nounroll                                     // 168-register cap of three wavefronts per SIMD): the SIMD's other consumer covers the fetch
@@ -181,11 +196,19 @@ __global__ __launch_bounds__(768) void k_convT_wgrad_v2(const float* __restrict_
   float* s_buf = igemm_smem;                         // [2][IMG]
   float4* s_tf = reinterpret_cast<float4*>(igemm_smem + 2 * IMG);
   int* s_tab = reinterpret_cast<int*>(igemm_smem + 2 * IMG + 4 * CI);   // [4 (NKS + 1)] window offset of pixel p inside a gy plane
+  // producers' scatter table of gy (element of the source image -> offset in the planes), where it is needed and fits
+  constexpr bool GTAB = !(S == 2 && HO % 4 == 0 && P == 1) && wgrad_v2_lds_floats<L>(true) * sizeof(float) <= 160 * 1024;
+  int* s_gtab = s_tab + 4 * (G::NKS + 1);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave >= W::NCW;
   const int lt = tid - 64 * W::NCW;                  // producer thread index
   if (HAS_BN)
     for (int e = tid; e < CI; e += NTHR) s_tf[e] = reinterpret_cast<const float4*>(in_bn)[e];
+  if (GTAB)
+    for (int e = tid; e < SRCG; e += NTHR) {
+      const int pl = e / (HO * HO), q = e % (HO * HO), rr = q / HO + P, cc = q % HO + P;
+      s_gtab[e] = pl * PSG + (S == 2 ? (cc & 1) * HPL + rr * GPH + (cc >> 1) : rr * GPH + cc);
+    }
   for (int p = tid; p < 4 * (G::NKS + 1); p += NTHR) {
     const int pc = min(p, NPIX - 1), iy = pc / L::HI, ix = pc % L::HI;   // tail pixels: x is zero there
     s_tab[p] = S == 2 ? S * iy * GPH + ix : iy * GPH + ix;
@@ -221,11 +244,19 @@ __global__ __launch_bounds__(768) void k_convT_wgrad_v2(const float* __restrict_
         int pl = (4 * f) / NPIX, q = (4 * f) % NPIX;             // one division per float4, then carries
         const int pl0 = min(pl, CI - 1);
         float4 tf0 = float4{0.f, 0.f, 0.f, 0.f}, tf1 = tf0;       // the BatchNorm row of the float4's plane, and of the next one
-        if (HAS_BN) { tf0 = s_tf[pl0]; tf1 = s_tf[min(pl0 + 1, CI - 1)]; }
+        if (HAS_BN) { tf0 = s_tf[pl0]; if (NPIX % 4 != 0) tf1 = s_tf[min(pl0 + 1, CI - 1)]; }
+        if constexpr (NPIX % 4 == 0) {                            // the four pixels share a plane: one base, constant offsets
+          float* base = s_x + pl * PSX + q;
+          if (on) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (on) s_x[pl * PSX + q] = HAS_BN ? bn_relu(v[k], pl == pl0 ? tf0 : tf1) : v[k];
-          if (NPIX % 4 != 0 || k < 3) { if (++q == NPIX) { q = 0; ++pl; } }
+            for (int k = 0; k < 4; ++k) base[k] = HAS_BN ? bn_relu(v[k], tf0) : v[k];
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (on) s_x[pl * PSX + q] = HAS_BN ? bn_relu(v[k], pl == pl0 ? tf0 : tf1) : v[k];
+            if (k < 3) { if (++q == NPIX) { q = 0; ++pl; } }
+          }
         }
       }
     };
@@ -236,11 +267,23 @@ __global__ __launch_bounds__(768) void k_convT_wgrad_v2(const float* __restrict_
         const float v[4] = {vv[i].x, vv[i].y, vv[i].z, vv[i].w};
         const bool on = f < NG4;
         int pl = (4 * f) / (HO * HO), q = (4 * f) % (HO * HO), row = q / HO, col = q % HO;
+        if constexpr (S == 2 && HO % 4 == 0 && P == 1) {
+          // the four columns 4 j .. 4 j + 3 of one row sit at cc = 4 j + 1 .. 4 j + 4 of the padded plane: odd, even, odd, even --
+          // positions 2 j, 2 j + 1 of the odd half and 2 j + 1, 2 j + 2 of the even half.  One base address, four constant offsets
+          // (the producers' vector instructions come out of the consumers' MFMA time, see wgrad_v2_image).
+          float* base = s_g + pl * PSG + (row + P) * GPH + (col >> 1);
+          if (on) { base[HPL] = v[0]; base[1] = v[1]; base[HPL + 1] = v[2]; base[2] = v[3]; }
+        } else if constexpr (GTAB) {
+          // odd widths: the offsets of the four elements come from a table (one 16-byte read) instead of ~40 vector instructions
+          const int4 o = reinterpret_cast<const int4*>(s_gtab)[min(f, NG4 - 1)];
+          if (on) { s_g[o.x] = v[0]; s_g[o.y] = v[1]; s_g[o.z] = v[2]; s_g[o.w] = v[3]; }
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int rr = row + P, cc = col + P;
-          if (on) s_g[pl * PSG + (S == 2 ? (cc & 1) * HPL + rr * GPH + (cc >> 1) : rr * GPH + cc)] = v[k];
-          if (HO % 4 != 0 || k < 3) { if (++col == HO) { col = 0; if (++row == HO) { row = 0; ++pl; } } }
+          for (int k = 0; k < 4; ++k) {
+            const int rr = row + P, cc = col + P;
+            if (on) s_g[pl * PSG + (S == 2 ? (cc & 1) * HPL + rr * GPH + (cc >> 1) : rr * GPH + cc)] = v[k];
+            if (HO % 4 != 0 || k < 3) { if (++col == HO) { col = 0; if (++row == HO) { row = 0; ++pl; } } }
+          }
         }
       }
     };
@@ -307,7 +350,8 @@ __global__ __launch_bounds__(768) void k_convT_wgrad_v2(const float* __restrict_
 }
 
 template <class L> constexpr size_t wgrad_v2_lds_bytes() {
-  return sizeof(float) * ((size_t)2 * (WgradGeo<L>::IMGX + WgradGeo<L>::IMGG) + (size_t)4 * L::CI + (size_t)4 * (WgradGeo<L>::NKS + 1));
+  constexpr bool gtab = !(L::S == 2 && L::HO % 4 == 0 && L::P == 1) && wgrad_v2_lds_floats<L>(true) * sizeof(float) <= 160 * 1024;
+  return sizeof(float) * wgrad_v2_lds_floats<L>(gtab);
 }
 
 }  // namespace gp

@@ -26,7 +26,7 @@ int wgrad_v2_dec7(const float* x, const float* gy, float* gw, float* scratch, in
   return launch_wgrad_v2<Dec7, true>(x, gy, gw, scratch, B, st, in_bn);
 }
 int wgrad_v2_dec4(const float* x, const float* gy, float* gw, float* scratch, int B, hipStream_t st, const float* in_bn) {
-  return launch_wgrad_v2<Dec4, false>(x, gy, gw, scratch, B, st, in_bn);
+  return launch_wgrad_v2<Dec4, true>(x, gy, gw, scratch, B, st, in_bn);
 }
 
 }  // namespace gp
