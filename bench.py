@@ -395,6 +395,12 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
     #     gradient all-reduce and Adam eager between replays; off launches everything eagerly).
     #   N > 1 over gloo (rehearsal on one card): gloo's collectives are host code and cannot be captured -- forward + backward
     #     are replayed when they hold no collective (--no-sync-bn), otherwise the step runs eagerly.
+    coll = None
+    if sync is not None:                             # what one step asks of the interconnect: count and payload of its collectives
+        from vae_gp_ode_amd import parallel
+        with parallel.stats.step():
+            eager_step()
+        coll = parallel.stats.summary()
     step, graphed, mode = eager_step, False, 'eager'
     if not a.no_graph:
         if sync is None:
@@ -454,6 +460,8 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
         'elbo_step_ms': el / a.steps * 1e3,
         'roofline': roof,
     }
+    if coll is not None:
+        out['collectives_per_step'] = coll
     # whole-step roofline: SURVEY 8(d)'s algorithmic flops per trajectory (forward + backward) x trajectories/s over the fp32 peak
     roof['step_frac'] = w['elbo_mflop'] * 1e6 * (value / n_gpus) / 1e12 / PEAK_FP32_TFLOPS
     roof['step_note'] = '%.0f MFLOP per trajectory (SURVEY 8d, full ELBO step) x per-GPU trajectories/s / %.1f TFLOP/s' % (w['elbo_mflop'], PEAK_FP32_TFLOPS)

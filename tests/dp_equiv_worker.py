@@ -16,6 +16,8 @@ sys.path.insert(0, ROOT)
 def main():
     out, n_global, steps, sync_bn = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] == '1'
     kernel = sys.argv[5] if len(sys.argv) > 5 else 'RBF'
+    order = 2 if kernel.endswith('2') else 1         # 'RBF2': second-order model (position + velocity encoder, vae.py:14-19)
+    kernel = kernel.rstrip('2')
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
     from vae_gp_ode_amd import vae_ops
     from vae_gp_ode_amd.model.core.initialization import initialize_and_fix_kernel_parameters
@@ -28,9 +30,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group('gloo')
-    q, M, S, T = 6, 16, 32, 6
-    args = types.SimpleNamespace(D_in=q, D_out=q, num_inducing=M, num_features=S, dimwise=True, q_diag=False, device='cuda', kernel=kernel,
-                                 ode=1, solver='rk4', use_adjoint=False, frames=5, n_filt=8, latent_dim=q, Ndata=360, dt=0.1)
+    q, M, S, T = (6 if order == 1 else 3), 16, 32, 6
+    args = types.SimpleNamespace(D_in=q * order, D_out=q, num_inducing=M, num_features=S, dimwise=True, q_diag=False, device='cuda', kernel=kernel,
+                                 ode=order, solver='rk4', use_adjoint=False, frames=5, n_filt=8, latent_dim=q, Ndata=360, dt=0.1)
     seed_everything(11)
     m = build_model(args).cuda()
     initialize_and_fix_kernel_parameters(m, 2.0, 1.0)
@@ -47,10 +49,12 @@ def main():
     first_grads = None
     for it in range(steps):
         nz = dict(eps_u=torch.randn(M, q, generator=g), rff_w=torch.randn(S if kernel == 'RBF' else 2 * S, q, generator=g),
-                  rff_eps=torch.randn(q, S, q, generator=g), rff_u=torch.rand(1, S, q, generator=g))
+                  rff_eps=torch.randn(q * order, S, q, generator=g), rff_u=torch.rand(1, S, q, generator=g))
         eps = torch.randn(n_global, q, generator=g)
         gp.set_noise({k: v.cuda() for k, v in nz.items()})
         m.vae.encoder.next_eps = eps[lo:hi].cuda()
+        if order == 2:
+            m.vae.encoder_v.next_eps = torch.randn(n_global, q, generator=g)[lo:hi].cuda()
         opt.zero_grad()
         loss, *_ = compute_loss(m, X[lo:hi].cuda(), 1)
         loss.backward()

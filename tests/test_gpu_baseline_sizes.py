@@ -235,6 +235,42 @@ def test_configs4_forward_at_its_real_size():
     assert e_x < 1e-4
 
 
+def test_configs4_full_step_gradients_at_its_gp_size():
+    """configs[4]'s GP at its REAL size -- divergence-free kernel, q = 16, M = 512: an 8192 x 8192 K_uu through the panelled Cholesky,
+    the matrix-core trailing updates, the streamed rollout team and the big-factor cache backward -- inside the full ELBO step
+    (encoder, draw, rk4 rollout, decoder, loss, backward): the four loss terms and EVERY parameter gradient against the fp64 oracle.
+    Batch 16 and T = 8 instead of 128 x 64: the fp64 autograd of the oracle keeps five (N, M, D, D) temporaries per right-hand-side
+    evaluation (0.7 GB at N = 128, times 252 evaluations), and past t ~ 16 the latent ODE at these shapes is chaotic
+    (test_configs4_forward_at_its_real_size), where a gradient comparison says nothing; every kernel of the step runs the same
+    code path at 16 trajectories as at 128."""
+    from vae_gp_ode_amd.model.create_model import compute_loss
+    _ref_threads()
+    cfg = dict(kernel='DF', ode=1, q=16, M=512, S=256, T=8, N=16)
+    m, X, nz, eps_s, _ = _model_and_draw(cfg)
+    r64, sd64 = _oracle_step(m, cfg, X, nz, eps_s, None, torch.float64)
+    r32, sd32 = _oracle_step(m, cfg, X, nz, eps_s, None, torch.float32)
+    gp = m.flow.odefunc.diffeq
+    gp.set_noise({k: v.cuda() for k, v in nz.items()})
+    m.vae.encoder.next_eps = eps_s.cuda()
+    out = compute_loss(m, X.cuda(), 1)
+    out[0].backward()
+    gp.cache.check_factorisation()
+    for got, key in zip(out, ('loss', 'nlhood', 'kl_reg', 'kl_u')):
+        e = abs(got.item() - r64[key].item()) / abs(r64[key].item())
+        assert e < 5e-5, (key, got.item(), r64[key].item())
+    dead_bias = ('cnn.0.bias', 'cnn.3.bias', 'decnn.1.bias', 'decnn.4.bias', 'decnn.7.bias')
+    report, bad = {}, []
+    for k, p in m.named_parameters():
+        if k.endswith(dead_bias):
+            continue
+        e_hip, e_ref = relerr(p.grad, sd64[k].grad), relerr(sd32[k].grad, sd64[k].grad)
+        report[k.split('.', 2)[-1]] = (e_hip, e_ref)
+        if not (e_hip < max(4 * e_ref, 5e-4) and e_hip < 1e-2):
+            bad.append((k, e_hip, e_ref))
+    print('configs[4] GP size, full step: gradient error vs fp64, hip/fp32-oracle:', {k: '%.0e/%.0e' % v for k, v in report.items()})
+    assert not bad, bad
+
+
 @pytest.mark.parametrize('late', ['main', 'side'])
 @pytest.mark.parametrize('name', ['configs[0]', 'configs[1]'])
 def test_overlap_mode_with_one_stream_held_up_gives_the_single_stream_gradients(name, late, monkeypatch):

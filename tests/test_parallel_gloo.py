@@ -50,6 +50,18 @@ def _worker(rank, world, port, q):
     ok = ok and got.tolist() == [[0.0, 10.0], [1.0, 11.0]]
     ok = ok and torch.allclose(bs.weights('cpu'), torch.tensor([1.0, 2.0 / 3.0] if rank == 0 else [1.5, 1.0]))
     ok = ok and abs(bs.count_all(3 * 49 if rank == 0 else 2 * 49) - 5 * 49) < 1e-9
+    # several independent statistics vectors in one collective == the separate gathers, bit for bit; and the per-step accounting
+    from vae_gp_ode_amd import parallel
+    a, b = torch.randn(17) + rank, torch.randn(2, 5) * (rank + 1)
+    with parallel.stats.step():
+        sep = [bs.gather(a), bs.gather(b)]
+    ok = ok and parallel.stats.summary() == {'all_gather': {'count': 2, 'payload_bytes': 4 * (17 + 10)}}
+    with parallel.stats.step():
+        packed = bs.gather_many([a, b])
+        sync.all_reduce_grads()
+    ok = ok and parallel.stats.summary() == {'all_gather': {'count': 1, 'payload_bytes': 4 * 27},
+                                             'all_reduce': {'count': 1, 'payload_bytes': 4 * fg.total}}
+    ok = ok and all(torch.equal(x, y) for x, y in zip(sep, packed)) and tuple(packed[1].shape) == (world, 2, 5)
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

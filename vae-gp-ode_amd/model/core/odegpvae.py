@@ -33,10 +33,22 @@ class ODEGPVAE(nn.Module):
             return self.flow(z0, ts, draws=L)
         return torch.stack([self.flow(z0, ts) for _ in range(L)], 0)
 
+    def _pair_encoders(self):
+        from ... import vae_ops
+        enc, vel = self.vae.encoder, self.vae.encoder_v
+        return (vae_ops.pack_bn_gathers() and enc.training and vel.training and
+                all(m.training for m in (enc.cnn[1], enc.cnn[4], vel.cnn[1], vel.cnn[4])))
+
     def encode_initial_state(self, X):
         """q(z0 | X): position code from the first frame, velocity code (order 2) from the first ``v_steps`` frames stacked as
         channels; returns the reparameterised sample and the (mean, log-variance) pairs the ELBO needs (odegpvae.py:55-63)."""
         pos = self.vae.encoder
+        if self.order == 2 and self._pair_encoders():
+            # data parallelism with global-minibatch BatchNorm: the two encoders run in lockstep and share their statistics exchanges
+            vel = self.vae.encoder_v
+            (mu_s, logv_s), (mu_v, logv_v) = pos.forward_pair(pos, X[:, 0], vel, torch.squeeze(X[:, 0:self.v_steps]))
+            z0 = pos.sample(mu=mu_s, logvar=logv_s)
+            return torch.concat([z0, vel.sample(mu=mu_v, logvar=logv_v)], dim=1), (mu_s, logv_s), (mu_v, logv_v)
         mu_s, logv_s = pos(X[:, 0])
         z0 = pos.sample(mu=mu_s, logvar=logv_s)
         if self.order == 1:

@@ -47,6 +47,24 @@ class Encoder(nn.Module):
         z = V.linear(h.flatten(1), self.fc.weight, self.fc.bias)
         return z.chunk(2, dim=-1)
 
+    @staticmethod
+    def forward_pair(enc_a, xa, enc_b, xb):
+        """enc_a(xa), enc_b(xb) layer by layer in lockstep, so that the same-depth BatchNorm layers of the two encoders exchange
+        their cross-rank statistics in ONE packed all-gather per direction (data parallelism with global-minibatch BatchNorm only;
+        vae_ops.set_pack_bn_gathers).  Same kernels on the same values as two separate forward() calls."""
+        ca, cb = enc_a.cnn, enc_b.cnn
+        ha = V.conv2d(xa.contiguous(), ca[0].weight, ca[0].bias, 2, 2)
+        hb = V.conv2d(xb.contiguous(), cb[0].weight, cb[0].bias, 2, 2)
+        ha, hb = V.batch_norm_train_pair(ha, ca[1], hb, cb[1], True)
+        ha = V.conv2d(ha, ca[3].weight, ca[3].bias, 2, 2)
+        hb = V.conv2d(hb, cb[3].weight, cb[3].bias, 2, 2)
+        ha, hb = V.batch_norm_train_pair(ha, ca[4], hb, cb[4], True)
+        ha = V.relu(V.conv2d(ha, ca[6].weight, ca[6].bias, 2, 2))
+        hb = V.relu(V.conv2d(hb, cb[6].weight, cb[6].bias, 2, 2))
+        za = V.linear(ha.flatten(1), enc_a.fc.weight, enc_a.fc.bias)
+        zb = V.linear(hb.flatten(1), enc_b.fc.weight, enc_b.fc.bias)
+        return za.chunk(2, dim=-1), zb.chunk(2, dim=-1)
+
     def sample(self, mu, logvar):
         """Reparameterised draw (vae.py:75-78).  ``next_eps`` (if set) replaces the N(0,1) draw once --
         used for parity tests and for data-parallel runs that must share the draw."""

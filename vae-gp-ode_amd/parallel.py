@@ -25,6 +25,42 @@ def shard_batch(X, rank, world):
     return X[lo:hi]
 
 
+class CollectiveStats:
+    """Count and bytes of the collectives this package issues (the gradient all-reduce, the BatchNorm statistics all-gathers):
+    ``with stats.step(): one_eager_step()`` -> ``stats.per_step`` = {'all_reduce': (count, payload bytes), 'all_gather': ...}.
+    xGMI is point-to-point and these messages are tiny, so on N ranks their NUMBER (each a latency-bound ring / tree) is what a
+    step pays for, not their bytes."""
+
+    def __init__(self):
+        self.on = False
+        self.per_step = {}
+
+    def add(self, kind, nbytes):
+        if self.on:
+            c, b = self.per_step.get(kind, (0, 0))
+            self.per_step[kind] = (c + 1, b + int(nbytes))
+
+    class _Step:
+        def __init__(self, st):
+            self.st = st
+
+        def __enter__(self):
+            self.st.per_step, self.st.on = {}, True
+            return self.st
+
+        def __exit__(self, *exc):
+            self.st.on = False
+
+    def step(self):
+        return CollectiveStats._Step(self)
+
+    def summary(self):
+        return {k: {'count': c, 'payload_bytes': b} for k, (c, b) in sorted(self.per_step.items())}
+
+
+stats = CollectiveStats()
+
+
 class FlatGrads:
     """One contiguous gradient buffer; every parameter's ``.grad`` is a view into it, so the bucket is
     all-reduced (and handed to the fused Adam) without gather/scatter copies."""
@@ -62,6 +98,7 @@ class GradAllReduce:
             ops.join_side_stream()                   # overlap mode: the GP parameter gradients must be in the bucket first
         if self.fg.gather is not None:
             self.fg.gather()                         # bucket filled in one launch from the tensors autograd handed over
+        stats.add('all_reduce', self.fg.flat.numel() * self.fg.flat.element_size())
         if self.avg:
             self.dist.all_reduce(self.fg.flat, op=self.dist.ReduceOp.AVG)
         else:
@@ -101,7 +138,20 @@ class BatchNormSync:
     def gather(self, t):
         """t (K,) on every rank -> (world, K), row r = rank r's t."""
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        stats.add('all_gather', t.numel() * t.element_size())
         self.dist.all_gather(list(out.unbind(0)), t)
+        return out
+
+    def gather_many(self, tensors):
+        """Several INDEPENDENT statistics vectors in one collective (e.g. the same-depth BatchNorm layers of the position and the
+        velocity encoder of a second-order model, vae.py:14-19): packed into one payload, all-gathered once, handed back as the
+        (world, K_i) tensors separate ``gather`` calls would return -- the same values, bit for bit, in the same rank order."""
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        got = self.gather(flat)
+        out, o = [], 0
+        for t in tensors:
+            out.append(got[:, o:o + t.numel()].reshape((self.world,) + tuple(t.shape)).contiguous())
+            o += t.numel()
         return out
 
     def weights(self, device):

@@ -107,6 +107,83 @@ def _bn_global_bwd(sync, x, gy, gamma, beta, mean, invstd, relu):
     return gx, gg, gb, cs
 
 
+# -- two independent BatchNorm layers of the same depth (the position and the velocity encoder of a second-order model, vae.py:14-19)
+# with ONE all-gather per direction instead of two: on N ranks every collective of a step is a latency-bound exchange of a few
+# hundred bytes, so their number is what counts (parallel.BatchNormSync.gather_many; switch: set_pack_bn_gathers) ---------------
+_pack_bn = {'on': os.environ.get('GPODE_PACK_BN_GATHERS', '0') == '1'}
+
+
+def set_pack_bn_gathers(on):
+    _pack_bn['on'] = bool(on)
+
+
+def pack_bn_gathers():
+    return _pack_bn['on'] and _bn_sync is not None
+
+
+class _BatchNormTrainPair(torch.autograd.Function):
+    """(BatchNorm2d_train + ReLU)(x1), (BatchNorm2d_train + ReLU)(x2) under cross-rank statistics, the two layers' moments (forward)
+    and backward sums (backward) exchanged in one packed all-gather each.  Same kernels, same rank order of every combination as two
+    _BatchNormTrain calls: results are bit-identical to the unpacked form."""
+
+    @staticmethod
+    def forward(ctx, x1, g1, b1, rm1, rv1, nbt1, x2, g2, b2, rm2, rv2, nbt2, momentum, eps, relu):
+        sync = _bn_sync
+        xs, moms = (_chk(x1, 'x1'), _chk(x2, 'x2')), []
+        for x in xs:
+            B, C, HW = x.shape[0], x.shape[1], x[0, 0].numel()
+            mom = _new((2 * C + 1,), x)
+            _lib.call('gpode_bn_moments', _ptr(x), _ptr(mom), B, C, HW, _ptr(_bn_scratch(B, C, x)), _stream())
+            moms.append(mom)
+        gathered = sync.gather_many(moms)
+        ys, saved = [], []
+        for x, gam, bet, rm, rv, nbt, got in zip(xs, (g1, g2), (b1, b2), (rm1, rm2), (rv1, rv2), (nbt1, nbt2), gathered):
+            B, C, HW = x.shape[0], x.shape[1], x[0, 0].numel()
+            mean, invstd, table, y = _new((C,), x), _new((C,), x), _new((C, 4), x), _new(x.shape, x)
+            _lib.call('gpode_bn_finalize', _ptr(got), sync.world, _ptr(_chk(gam, 'gamma')), _ptr(_chk(bet, 'beta')), _ptr(mean), _ptr(invstd),
+                      _ptr(rm), _ptr(rv), _ptr(nbt), ctypes.c_float(momentum), ctypes.c_float(eps), _ptr(table), C, _stream())
+            _lib.call('gpode_bn_apply', _ptr(x), _ptr(table), _ptr(y), B, C, HW, int(relu), _stream())
+            ys.append(y)
+            saved += [x, gam, bet, mean, invstd]
+        ctx.save_for_backward(*saved)
+        ctx.sync, ctx.relu = sync, int(relu)
+        return ys[0], ys[1]
+
+    @staticmethod
+    def backward(ctx, gy1, gy2):
+        sv, sync = ctx.saved_tensors, ctx.sync
+        packs, sums, scr = [], [], []
+        for i, gy in enumerate((gy1, gy2)):
+            x, gam, bet, mean, invstd = sv[5 * i:5 * i + 5]
+            B, C, HW = x.shape[0], x.shape[1], x[0, 0].numel()
+            gy = gy.contiguous()
+            scratch, s = _bn_scratch(B, C, x), _new((2 * C,), x)
+            _lib.call('gpode_bn_bwd_sums', _ptr(x), _ptr(gy), _ptr(gam), _ptr(bet), _ptr(mean), _ptr(invstd), _ptr(s), B, C, HW, ctx.relu,
+                      _ptr(scratch), _stream())
+            packs.append((x, gy, gam, bet, mean, invstd))
+            sums.append(s)
+            scr.append(scratch)
+        gathered = sync.gather_many(sums)
+        out = []
+        for (x, gy, gam, bet, mean, invstd), got, scratch in zip(packs, gathered, scr):
+            B, C, HW = x.shape[0], x.shape[1], x[0, 0].numel()
+            gx, gg, gb, cs = _new(x.shape, x), _new((C,), x), _new((C,), x), _new((C,), x)
+            _bwd_call('gpode_bn_bwd_apply', _ptr(x), _ptr(gy), _ptr(gam), _ptr(bet), _ptr(mean), _ptr(invstd), _ptr(got),
+                      _ptr(sync.weights(x.device)), sync.world, ctypes.c_float(sync.count_all(B * HW)), _ptr(gx), _ptr(gg), _ptr(gb), _ptr(cs),
+                      B, C, HW, ctx.relu, _ptr(scratch), _stream(), keep=(scratch,))
+            gx._gpode_chansum = cs
+            out.append((gx, gg, gb))
+        (gx1, gg1, gb1), (gx2, gg2, gb2) = out
+        return gx1, gg1, gb1, None, None, None, gx2, gg2, gb2, None, None, None, None, None, None
+
+
+def batch_norm_train_pair(x1, bn1, x2, bn2, relu):
+    """Two training-mode BatchNorm2d modules on their own inputs with packed cross-rank exchanges (see _BatchNormTrainPair)."""
+    return _BatchNormTrainPair.apply(x1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.num_batches_tracked,
+                                     x2, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, bn2.num_batches_tracked,
+                                     bn1.momentum, bn1.eps, relu)
+
+
 _dec10_fused = os.environ.get('GPODE_DEC10_BN_UNFUSED', '0') != '1'
 
 
