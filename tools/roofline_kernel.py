@@ -1,15 +1,19 @@
-"""Launch the roofline kernel of bench.py (decoder decnn.7 forward, B = batch*T images) a few times, for
-rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE need separate passes on gfx950) and --kernel-trace --stats."""
-import sys, torch
+"""Launch ONE of the six matrix-core convolution kernels of bench.py's roofline table a few times, for rocprofv3 --pmc passes
+(FETCH_SIZE and WRITE_SIZE need separate passes on gfx950) and --kernel-trace --stats.
+usage: python3 tools/roofline_kernel.py "<decnn.7|decnn.4> <forward|d/d input|d/d weight>" [images]"""
 import os
+import sys
+
+import torch
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-from vae_gp_ode_amd import vae_ops as V
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-x = torch.randn(B, 32, 13, 13, device='cuda')
-w = torch.randn(32, 16, 5, 5, device='cuda') * 0.05
-b = torch.zeros(16, device='cuda')
+import bench  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else 'decnn.7 forward'
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+launch = bench.conv_kernel_launchers(B, torch.device('cuda', 0))[name][0]
 with torch.no_grad():
     for _ in range(5):
-        V.conv_transpose2d(x, w, b, 2, 1, 1)
+        launch()
 torch.cuda.synchronize()
-print('done')
+print('done', name, B)
