@@ -108,7 +108,7 @@ def make_model_inputs(w, seed, dev, rank):
     synthetic normalised minibatch X (N,T,1,28,28) (data/utils.py:8-15 on random frames)."""
     import types
     from vae_gp_ode_amd.model.core.initialization import initialize_and_fix_kernel_parameters
-    from vae_gp_ode_amd.model.core.noise import DeviceNoise
+    from vae_gp_ode_amd.model.core.noise import install_device_noise
     from vae_gp_ode_amd.model.create_model import build_model
     from vae_gp_ode_amd.model.misc.torch_utils import seed_everything
     q, order = w['q'], w['order']
@@ -118,7 +118,8 @@ def make_model_inputs(w, seed, dev, rank):
     seed_everything(seed)
     model = build_model(args).to(dev)
     initialize_and_fix_kernel_parameters(model, lengthscale_value=2.0, variance_value=1.0)
-    model.flow.odefunc.diffeq.noise_source = DeviceNoise(seed + 1)  # same draw sequence on every rank
+    # the function draw is the same on every rank; the encoders' reparameterisation noise is the rank's own (one rank: all of it in one launch)
+    install_device_noise(model, seed + 1, eps_seed=None if int(os.environ.get('WORLD_SIZE', '1')) == 1 else seed + 7919 * (rank + 1))
     # Keep the synthetic run finite: with the reference's own init, a batch of 4096 random-latent images puts a few
     # sigmoid outputs at exactly 1.0f, and log(1 - z) = -inf poisons the ELBO (the reference's NaN guard exists
     # for this).  Shrinking the last decoder layer keeps every pixel off the fp32 saturation point;
@@ -355,6 +356,8 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
     # within 0.1 of the initial state.
     # one GPU: no gradient bucket; N > 1: the bucket is filled in one launch from the produced gradients before the all-reduce
     opt = HipAdam(model.parameters(), lr=1e-6, bucketed='gather' if dist is not None else False)
+    from vae_gp_ode_amd import vae_ops
+    vae_ops.set_deferred_reductions(opt.allows_deferred_reductions)   # one launch for all final reductions of the backward pass
     sync = GradAllReduce(opt.flat_grads, dist) if dist is not None else None
     bn_sync = None
     if dist is not None and not a.no_sync_bn:          # BatchNorm over the GLOBAL minibatch, as the single-process reference
@@ -415,7 +418,6 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
     if mode in ('whole', 'fwdbwd'):
         try:
             from vae_gp_ode_amd.graph import GraphedStep, device_generators
-            model.flow.odefunc.diffeq.noise_source.generator(dev)   # exists before capture, so that it can be registered with the graph
             gens = device_generators(model)
             if mode == 'whole':
                 g = GraphedStep(whole_step if sync is None else dp_step, generators=gens, warmup=2)
@@ -545,6 +547,8 @@ def quick_elbo(w, dev, seed, steps=30, warmup=5, L=1):
     model, X = make_model_inputs(w, seed, dev, 0)
     Xd = X.to(dev)
     opt = HipAdam(model.parameters(), lr=1e-6, bucketed=False)
+    from vae_gp_ode_amd import vae_ops
+    vae_ops.set_deferred_reductions(opt.allows_deferred_reductions)
 
     def whole_step():
         opt.zero_grad()
@@ -553,7 +557,6 @@ def quick_elbo(w, dev, seed, steps=30, warmup=5, L=1):
         ops.join_side_stream()
         opt.step()
         return loss
-    model.flow.odefunc.diffeq.noise_source.generator(dev)
     g = GraphedStep(whole_step, generators=device_generators(model), warmup=2)
     for _ in range(warmup):
         g()

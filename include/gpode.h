@@ -90,7 +90,10 @@ int gpode_param_grad(int kernel, int Di, int Do, int M, int S, const float* pack
  * (nu = L^-T(u - L^-1 f_prior(Z)), cholesky, K(Z), omega = eps/ell, softplus ...).
  *   gpack : in/out, pack-layout gradient from gpode_param_grad (the f_prior(Z) path is added to it);
  *   ws    : the workspace the forward of THIS draw wrote;  bws: gpode_cache_bwd_sizes() floats of scratch;
- *   outputs: gradients w.r.t. the five raw parameter tensors, in their state_dict layouts. */
+ *   outputs: gradients w.r.t. the five raw parameter tensors, in their state_dict layouts;
+ *   prepared: bit 0 -- bws went through gpode_cache_bwd_prepare (below); bit 1 -- g_Um / g_Us already HOLD a gradient (that of
+ *   KL(q(u)||p(u)), svpy.py:144-175, which reaches the same two parameters) and the flow's is ADDED to it: what autograd's
+ *   accumulation of the two paths would do in one more launch each. */
 int gpode_cache_bwd_sizes(int kernel, int Di, int Do, int M, int S, size_t* bws_floats);
 int gpode_cache_build_bwd(int kernel, int Di, int Do, int M, int S,
                           const float* raw_ell, const float* raw_var, const float* Z, const float* eps_u,
@@ -325,6 +328,12 @@ int gpode_elbo_all_fwd(const float* lpart, int nl_rows, int nl_values, const flo
 int gpode_elbo_all_bwd(const float* g_loss, const float* g_nll, const float* g_kl, const float* g_klu, int nl_rows, const float* hs,
                        const float* hv, int N, int q, int M, int Do, const float* Um, const float* Us, float nobs, float* glrow, float* ghs,
                        float* ghv, float* dUm, float* dUs, void* stream);
+/* All device-side noise of a step in one launch (the reference draws on the host with numpy -- kernels.py:13-26,134-137,
+ * svpy.py:12-27,94 -- and with torch.randn_like, vae.py:76; `--device_noise` / DeviceNoise draws here instead):
+ *   out[0 .. n_normal) ~ N(0,1), out[n_normal .. n_normal + n_uniform) ~ U[0,1): Philox4x32-10 keyed by `seed`, counter = (element
+ *   quad, draw number).  state: two 64-bit words in device memory {draw number, 0}; the kernel advances the draw number itself,
+ *   so a captured launch yields fresh numbers at every replay and equal (seed, state) give equal numbers on every rank. */
+int gpode_noise_fill(float* out, long long n_normal, long long n_uniform, unsigned long long seed, unsigned long long* state, void* stream);
 /* ELBO glue on (N,q)-sized tensors (one launch each):
  *   mu / logvar are (N,q) with row stride ld (ld = 2q: the two halves of the encoder's fc output, vae.py:74), gradients
  *   are written with row stride ldg;
@@ -343,8 +352,9 @@ int gpode_elbo_bwd(const float* gout, int nl, int nk, float nobs, float* glhood,
 
 /* torch.optim.Adam step (main.py:194,211) over a whole parameter list in one launch.  params/grads/m1/m2:
  * DEVICE arrays of `ntensors` device pointers; offs: DEVICE array of element prefix offsets (offs[0]=0);
- * step: 1-based step count (bias correction).  step_dev (optional, DEVICE int): when non-NULL it is incremented on the
- * stream and used instead of `step`, so that a captured HIP graph of the training step replays with a live count. */
+ * step: 1-based step count (bias correction).  step_dev (optional, DEVICE int[2] = {updates done so far, 0}): when non-NULL the
+ * kernel uses step_dev[0] + 1 instead of `step` and advances step_dev[0] itself (the last workgroup to finish; step_dev[1] is its
+ * ticket counter), so that a captured HIP graph of the training step replays with a live count and no separate counter launch. */
 int gpode_adam_multi(void* params, void* grads, void* m1, void* m2, const long long* offs, int ntensors, long long total,
                      float lr, float beta1, float beta2, float eps, int step, int* step_dev, void* stream);
 

@@ -130,8 +130,11 @@ def test_graph_replay_equals_eager_steps():
 
     from vae_gp_ode_amd import ops
 
-    def run(use_graph, overlap=False, bucketed=True):
+    from vae_gp_ode_amd import vae_ops
+
+    def run(use_graph, overlap=False, bucketed=True, deferred=False):
         ops.set_overlap(overlap)
+        vae_ops.set_deferred_reductions(deferred)
         m.load_state_dict(init)
         opt = HipAdam(m.parameters(), lr=1e-3, bucketed=bucketed)
 
@@ -149,20 +152,25 @@ def test_graph_replay_equals_eager_steps():
             for _ in range(3):
                 step()
         torch.cuda.synchronize()
-        assert int(opt.step_dev.item()) == 3
+        assert opt.step_dev.tolist() == [3, 0]
         return [p.detach().clone() for p in m.parameters()], [b.detach().clone() for b in m.buffers()]
     pe, be = run(False)
     try:
         # overlap: GP chains on the side stream; bucketed=False: gradients handed over by autograd, no flat bucket
-        for use_graph, overlap, bucketed in ((True, False, True), (False, True, True), (True, True, True), (False, False, False), (True, True, False),
-                                              (False, False, 'gather'), (True, True, 'gather')):
-            pg, bg = run(use_graph, overlap, bucketed)
+        # deferred: the final reductions of the backward kernels' partials in ONE launch at the end of the pass (the training loops'
+        # setting with handed-over gradients; the sums are the same, so the parameters stay bit-identical)
+        for use_graph, overlap, bucketed, deferred in ((True, False, True, False), (False, True, True, False), (True, True, True, False),
+                                                        (False, False, False, False), (True, True, False, False), (False, False, 'gather', False),
+                                                        (True, True, 'gather', False), (False, False, False, True), (True, True, False, True),
+                                                        (False, True, 'gather', True), (True, True, 'gather', True)):
+            pg, bg = run(use_graph, overlap, bucketed, deferred)
             for a, b in zip(pe, pg):
-                assert torch.equal(a, b), (use_graph, overlap, bucketed)
+                assert torch.equal(a, b), (use_graph, overlap, bucketed, deferred)
             for a, b in zip(be, bg):   # BatchNorm running statistics advance in the replayed steps too
-                assert torch.equal(a, b), (use_graph, overlap, bucketed)
+                assert torch.equal(a, b), (use_graph, overlap, bucketed, deferred)
     finally:
         ops.set_overlap(False)
+        vae_ops.set_deferred_reductions(False)
 
 
 def test_vae_pretraining_loop_feeds_pretrained_run(tmp_path, monkeypatch):

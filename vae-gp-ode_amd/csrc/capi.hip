@@ -358,6 +358,12 @@ int gpode_loglik_rowsum_bwd(const float* X, const float* z, const float* grow, f
                             void* stream) {
   return gp::loglik_rowsum_bwd(X, z, grow, gz, rows, inner, nX, GP_ST);
 }
+int gpode_noise_fill(float* out, long long n_normal, long long n_uniform, unsigned long long seed, unsigned long long* state, void* stream) {
+  if (n_normal < 0 || n_uniform < 0) return gp::set_error("gpode_noise_fill: negative count");
+  if (n_normal + n_uniform == 0) return 0;
+  if (!out || !state) return gp::set_error("gpode_noise_fill: null pointer");
+  return gp::noise_fill(out, n_normal, n_uniform, seed, state, GP_ST);
+}
 int gpode_reparam_fwd(const float* mu, const float* logvar, int ld, const float* eps, float* z, int N, int q, void* stream) {
   if (N == 0) return 0;
   if (!mu || !logvar || !eps || !z || q < 1 || ld < q) return gp::set_error("gpode_reparam_fwd: bad argument");

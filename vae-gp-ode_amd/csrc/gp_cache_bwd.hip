@@ -236,14 +236,15 @@ __global__ __launch_bounds__(256) void k_vec_a(int kernel, int Do, int n, int np
 }
 
 // g_Us[d, n(n+1)/2 + m] = sum_l g_u_l[n,d] eps_u_l[m,d]   (svpy.py:94-100 backward);  g_Um = sum_l g_u_l.  Draws in a fixed order.
+// accum: g_Um / g_Us already hold a gradient (the KL term's, written earlier on another path) and the flow's is added to it
 __global__ void k_gUs(int M, int Do, int nd, const float* __restrict__ g_u, const float* __restrict__ eps_u, float* __restrict__ g_Us,
-                      float* __restrict__ g_Um) {
+                      float* __restrict__ g_Um, int accum) {
   const size_t P = (size_t)M * (M + 1) / 2, MD = (size_t)M * Do;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < MD) {
     float acc = 0.f;
     for (int l = 0; l < nd; ++l) acc += g_u[l * MD + e];
-    g_Um[e] = acc;
+    g_Um[e] = accum ? g_Um[e] + acc : acc;
   }
   if (e >= P * Do) return;
   const int d = (int)(e / P);
@@ -254,7 +255,7 @@ __global__ void k_gUs(int M, int Do, int nd, const float* __restrict__ g_u, cons
   const int m = (int)(k - (size_t)nn * (nn + 1) / 2);
   float acc = 0.f;
   for (int l = 0; l < nd; ++l) acc = fmaf(g_u[l * MD + (size_t)nn * Do + d], eps_u[l * MD + (size_t)m * Do + d], acc);
-  g_Us[e] = acc;
+  g_Us[e] = accum ? g_Us[e] + acc : acc;
 }
 
 // Phi[i][j] = sum_l (-r_l[i] q_l[j] + q_l[i] v_l[j]): the Cholesky backward is linear in Phi, so the draws that share the factor are
@@ -1156,7 +1157,7 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, int nd, const floa
   (void)MJ;
 
   hipLaunchKernelGGL(k_gnu, dim3(cdiv(b.np, 128), b.batch, nd), 128, 0, st, kernel, Di, Do, M, b.n, b.np, gpack_ind, ws + w.var, vec, pf);
-  if (!prepared && cache_bwd_prepare(kernel, Di, Do, M, S, nd, ws, bws, st)) return 1;
+  if (!(prepared & 1) && cache_bwd_prepare(kernel, Di, Do, M, S, nd, ws, bws, st)) return 1;
   const bool solves = use_trsm(b.np);
   const size_t trsm_lds = sizeof(float) * (size_t)(b.nbn + 2) * NB * TSL;
   const int nslab = (b.nbn * NB + TSW - 1) / TSW, vslab = cdiv(nd, TSW);     // slabs of Phi columns; slabs of per-draw vectors
@@ -1180,7 +1181,7 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, int nd, const floa
   if (check_launch("cache bwd: solves")) return 1;
   {
     const size_t P = (size_t)M * (M + 1) / 2 * Do;   // >= M * Do: the same launch sums g_Um
-    hipLaunchKernelGGL(k_gUs, (unsigned)((P + 255) / 256), 256, 0, st, M, Do, nd, bws + b.gu_rows, eps_u, g_Us, g_Um);
+    hipLaunchKernelGGL(k_gUs, (unsigned)((P + 255) / 256), 256, 0, st, M, Do, nd, bws + b.gu_rows, eps_u, g_Us, g_Um, (prepared >> 1) & 1);
   }
   // f_prior(Z) path, every draw through its own pack: d/dZ and parameter gradients (prior only), added to the pack gradient
   Draws dv; dv.nd = nd; dv.pack = pf; dv.in = 0; dv.in2 = MD; dv.out = (size_t)M * Di;

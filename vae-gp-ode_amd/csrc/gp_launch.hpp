@@ -96,6 +96,7 @@ int conditional_ws(int Di, int Do, int M, int N, size_t* ws_floats);
 int conditional(int Di, int Do, int M, int N, const float* raw_ell, const float* raw_var, const float* Z, const float* Um,
                 const float* Us_packed, int us_rank1, const float* x, int full_cov, float* mean, float* var, float* ws, hipStream_t st);
 int svgp_kl_fwd(int M, int Do, const float* Um, const float* Us, float* kl, hipStream_t st);
+int noise_fill(float* out, long long n_normal, long long n_uniform, unsigned long long seed, unsigned long long* state, hipStream_t st);
 int svgp_kl_bwd(int M, int Do, const float* Um, const float* Us, const float* g, float* dUm, float* dUs, hipStream_t st);
 
 void set_backward_solves(int mode);

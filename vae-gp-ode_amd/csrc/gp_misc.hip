@@ -106,4 +106,72 @@ int svgp_kl_bwd(int M, int Do, const float* Um, const float* Us, const float* g,
   return check_launch("svgp_kl_bwd");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device-side noise of a whole step in ONE launch (model/core/noise.py: DeviceNoise).  The reference draws with numpy on the host
+// (kernels.py:13-26,134-137; svpy.py:12-27,94) and torch.randn_like (vae.py:76); throughput runs draw on the device instead:
+// out[0 .. n_normal) ~ N(0,1), out[n_normal .. n_normal + n_uniform) ~ U[0,1), from Philox4x32-10 keyed by `seed`, counter =
+// (element quad, draw number).  The draw number lives in device memory (state[0]) and is advanced by the LAST workgroup to
+// finish (ticket state[1]; every workgroup has read state[0] before it takes its ticket), so a captured launch produces fresh
+// numbers at every replay without any host-side bookkeeping, and the same (seed, draw number) gives the same numbers on every rank.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void k_noise_fill(float* __restrict__ out, long long n_normal, long long n_uniform,
+                                                     unsigned long long seed, unsigned long long* __restrict__ state) {
+  const unsigned long long draw = state[0];
+  const long long qn = (n_normal + 3) / 4, qu = (n_uniform + 3) / 4;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t < qn + qu) {
+    unsigned r[4];
+    philox4x32_10((unsigned)t, (unsigned)((unsigned long long)t >> 32), (unsigned)draw, (unsigned)(draw >> 32), (unsigned)seed,
+                  (unsigned)(seed >> 32), r);
+    float v[4];
+    const bool normal = t < qn;
+    if (normal) {                                    // Box-Muller on two pairs; u in (0, 1]: 2^-33 .. 1, radius <= 6.76
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const float u = fmaf((float)r[2 * p], 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+        const float rad = sqrtf(-2.f * logf(u));
+        const float ang = 6.283185307179586f * ((float)(r[2 * p + 1] >> 8) * 5.9604644775390625e-08f);
+        float sn, cs;
+        sincosf(ang, &sn, &cs);
+        v[2 * p] = rad * cs;
+        v[2 * p + 1] = rad * sn;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (float)(r[k] >> 8) * 5.9604644775390625e-08f;   // 24 bits: [0, 1)
+    }
+    const long long e0 = normal ? 4 * t : n_normal + 4 * (t - qn), e1 = normal ? n_normal : n_normal + n_uniform;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (e0 + k < e1) out[e0 + k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned long long ticket = atomicAdd(&state[1], 1ull);
+    if (ticket == (unsigned long long)gridDim.x - 1) {
+      state[1] = 0;
+      state[0] = draw + 1;
+    }
+  }
+}
+
+int noise_fill(float* out, long long n_normal, long long n_uniform, unsigned long long seed, unsigned long long* state, hipStream_t st) {
+  const long long threads = (n_normal + 3) / 4 + (n_uniform + 3) / 4;
+  if (threads <= 0) return 0;
+  hipLaunchKernelGGL(k_noise_fill, (unsigned)((threads + 255) / 256), 256, 0, st, out, n_normal, n_uniform, seed, state);
+  return check_launch("noise_fill");
+}
+
 }  // namespace gp

@@ -391,7 +391,9 @@ int conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, 
     const int r = tiled_bwd_weight(x, gy, gw, scratch, B, Ci, H, W, Co, K, S, P, Ho, Wo, gy_bn, st);
     if (r > 0) return r;
     if (r == 0) {
-      if (gbias) return chan_sum(gy, gbias, B, Co, Ho * Wo, scratch, st);
+      // the bias partials go BEHIND the weight-gradient slabs (the tail conv_wgrad_scratch reserves): with deferred reductions
+      // (gpode_defer_reductions) the slabs are still unread when k_chan_sum runs
+      if (gbias) return chan_sum(gy, gbias, B, Co, Ho * Wo, scratch + (size_t)(B < 512 ? B : 512) * Co * Ci * K * K, st);
       return 0;
     }
   }
@@ -793,9 +795,11 @@ namespace gp {
 __global__ void k_adam_multi(float* const* __restrict__ params, const float* const* __restrict__ grads,
                              float* const* __restrict__ m1, float* const* __restrict__ m2, const long long* __restrict__ offs,
                              int ntensors, long long total, float lr, float beta1, float beta2, float eps, float bc1, float bc2,
-                             const int* __restrict__ step_dev) {
+                             int* __restrict__ step_dev) {
+  int step = 0;
   if (step_dev) {                                    // step counter kept on the device (captured graphs replay with a live count)
-    const float t = (float)*step_dev;
+    step = step_dev[0] + 1;                          // this update's number; published below by the last workgroup to finish
+    const float t = (float)step;
     bc1 = 1.f - powf(beta1, t);
     bc2 = 1.f - powf(beta2, t);
   }
@@ -811,9 +815,19 @@ __global__ void k_adam_multi(float* const* __restrict__ params, const float* con
     // torch: denom = sqrt(v)/sqrt(bc2) + eps ; p -= lr/bc1 * m / denom
     params[lo][i] -= (lr / bc1) * a / (sqrtf(b) / sqrtf(bc2) + eps);
   }
+  if (step_dev) {
+    // every workgroup has read step_dev[0] before it takes a ticket, so the last one may advance it (no separate launch for the
+    // counter: one graph node less on the tail of every step)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      if (atomicAdd(&step_dev[1], 1) == (int)gridDim.x - 1) {
+        step_dev[1] = 0;
+        step_dev[0] = step;
+      }
+    }
+  }
 }
-
-__global__ void k_inc_step(int* step) { *step += 1; }
 
 // flat[offs[t] + i] = grads[t][i] for every tensor of the table: the data-parallel gradient bucket filled in ONE launch
 // from the tensors autograd handed over (instead of one accumulate kernel per parameter into persistent views)
@@ -831,13 +845,16 @@ int gather_multi(const float* const* grads, const long long* offs, int ntensors,
   return check_launch("gather_multi");
 }
 
-// step_dev != nullptr: *step_dev is incremented on the stream and used as the step count (host `step` ignored)
+// step_dev != nullptr: int[2] {step count, 0}: the count is advanced by the kernel and used as this update's number (host `step` ignored)
 int adam_multi(float* const* params, const float* const* grads, float* const* m1, float* const* m2, const long long* offs,
                int ntensors, long long total, float lr, float beta1, float beta2, float eps, int step, int* step_dev, hipStream_t st) {
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  if (step_dev) hipLaunchKernelGGL(k_inc_step, 1, 1, 0, st, step_dev);
-  hipLaunchKernelGGL(k_adam_multi, ew_grid((size_t)total), 256, 0, st, params, grads, m1, m2, offs, ntensors, total, lr, beta1, beta2, eps, bc1, bc2,
-                     (const int*)step_dev);
+  // with the device-side count every workgroup takes a ticket on ONE address (the last one publishes the count): keep them few --
+  // 550 tickets of the 140k-parameter model serialised into 16 us at the L2, 64 workgroups of grid-stride loops take 1-2 us
+  unsigned grid = ew_grid((size_t)total);
+  if (step_dev && grid > 64) grid = 64;
+  hipLaunchKernelGGL(k_adam_multi, grid, 256, 0, st, params, grads, m1, m2, offs, ntensors, total, lr, beta1, beta2, eps, bc1, bc2,
+                     step_dev);
   return check_launch("adam_multi");
 }
 }  // namespace gp

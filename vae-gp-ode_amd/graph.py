@@ -5,8 +5,9 @@ kernel launches, half of them a few microseconds long; launched one by one the G
 op of this package launches on torch's current stream and allocates through torch's caching allocator, so the
 step can be stream-captured once (``torch.cuda.CUDAGraph`` = hipGraph on ROCm) and replayed: same kernels, same
 arguments, one submission.  Requirements met by the package: static gradient storage (``parallel.FlatGrads``),
-device-resident Adam step count (``optim.HipAdam.step_dev``), device-side noise (``DeviceNoise``; its generator
-must be registered so that every replay draws fresh numbers), no host synchronisation inside the step.
+device-resident Adam step count (``optim.HipAdam.step_dev``), device-side noise (``DeviceNoise``: the library's counter-based
+generator keeps its draw number in device memory, so every replay draws fresh numbers with no torch generator in the graph),
+no host synchronisation inside the step.
 """
 import torch
 
@@ -19,6 +20,20 @@ def _detached(out):
     if isinstance(out, (tuple, list)):
         return type(out)(_detached(o) for o in out)
     return out
+
+
+_capture = {'active': False, 'after': []}
+
+
+def capturing_step():
+    """True while a GraphedStep is capturing: code inside the step may then defer one-time work to after_capture()."""
+    return _capture['active']
+
+
+def after_capture(fn):
+    """Run ``fn()`` once, eagerly, right after the running GraphedStep capture ends (before its first replay): for constants
+    of the captured graph that are only known during the capture (e.g. a table of the gradient tensors' addresses)."""
+    _capture['after'].append(fn)
 
 
 class GraphedStep:
@@ -45,8 +60,16 @@ class GraphedStep:
                 self.graph.register_generator_state(g)
         # thread_local: other threads of the process (e.g. the RCCL watchdog polling its events) may keep calling the
         # runtime while this thread captures
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-            self.out = _detached(step_fn())
+        _capture['active'], _capture['after'] = True, []
+        try:
+            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+                self.out = _detached(step_fn())
+        finally:
+            _capture['active'] = False
+        for fn in _capture['after']:
+            fn()
+        _capture['after'] = []
+        torch.cuda.synchronize()
         self.grads = [p.grad for p in self.grad_params] if self.grad_params is not None else None
         self.eager_steps = warmup
 
@@ -67,7 +90,8 @@ class GraphedStep:
 
 
 def device_generators(model):
-    """The torch.Generator objects of every DeviceNoise source reachable from ``model``."""
+    """torch.Generator objects on the device reachable from ``model`` (a graph that replays torch-native draws must have them
+    registered).  DeviceNoise needs none."""
     from .model.core.noise import DeviceNoise
     gens, seen = [], set()
 
@@ -75,9 +99,11 @@ def device_generators(model):
         if id(obj) in seen:
             return
         seen.add(id(obj))
-        if isinstance(obj, DeviceNoise):
-            if obj._gen is not None:
-                gens.append(obj._gen)
+        if isinstance(obj, DeviceNoise):             # the library's own generator: its state is device memory the kernel advances
+            return
+        if isinstance(obj, torch.Generator):
+            if obj.device.type == 'cuda':
+                gens.append(obj)
             return
         if isinstance(obj, torch.nn.Module):
             for v in vars(obj).values():

@@ -235,6 +235,8 @@ def main(argv=None):
     meters = {k: RunningAverage(10) for k in ('elbo', 'nll', 'reg_kl', 'inducing_kl')}
     bn_sync = None
     optimizer = HipAdam(model.parameters(), lr=args.lr, bucketed='gather' if dist is not None else False)
+    from . import vae_ops as _vae_ops
+    _vae_ops.set_deferred_reductions(optimizer.allows_deferred_reductions)   # one launch for all final reductions of a backward pass
     sync = None
     if dist is not None:
         from .parallel import GradAllReduce, shard_batch
@@ -254,12 +256,12 @@ def main(argv=None):
     if args.hip_graph:
         from . import ops
         from .graph import GraphedStep, device_generators
-        from .model.core.noise import DeviceNoise
-        model.flow.odefunc.diffeq.noise_source = DeviceNoise(args.seed + 1)
+        from .model.core.noise import install_device_noise
+        install_device_noise(model, args.seed + 1, eps_seed=None if world == 1 else args.seed + 7919 * (rank + 1))
         ops.set_overlap(True)
     elif args.device_noise:
-        from .model.core.noise import DeviceNoise
-        model.flow.odefunc.diffeq.noise_source = DeviceNoise(args.seed + 1)
+        from .model.core.noise import install_device_noise
+        install_device_noise(model, args.seed + 1, eps_seed=None if world == 1 else args.seed + 7919 * (rank + 1))
     if args.gp_side_stream and not args.hip_graph:
         from . import ops
         ops.set_overlap(True)
@@ -284,8 +286,6 @@ def main(argv=None):
                     ops.join_side_stream()
                 return out
             buf.copy_(minibatch)
-            gp = model.flow.odefunc.diffeq
-            gp.noise_source.generator(minibatch.device)          # exists before capture: registered with the graph, no draw consumed
             gs = GraphedStep(step, generators=device_generators(model), warmup=1,
                              grad_params=optimizer.params if sync is not None else None)
             graphs[key] = (buf, gs)

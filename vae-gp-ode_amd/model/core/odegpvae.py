@@ -62,6 +62,12 @@ class ODEGPVAE(nn.Module):
         N, T, nc, d, _ = X.shape
         horizon = T_custom if T_custom else T
         field = self.flow.odefunc.diffeq
+        src = getattr(self.vae.encoder, 'eps_source', None)
+        if src is not None and src is getattr(field, 'noise_source', None) and hasattr(field, 'predraw'):
+            # device noise: the function draw(s) AND the encoders' reparameterisation draws in one launch, ahead of the encoder
+            # (the same order of draws whether or not the cache build then runs on the side stream)
+            src.reserve(N * (self.vae.encoder.fc.out_features // 2) * self.order)
+            field.predraw(L if L > 1 and field.batched_draws_supported() else None)
         if hasattr(field, 'prebuild_cache') and (L == 1 or field.batched_draws_supported()):
             field.prebuild_cache(None if L == 1 else L)   # overlap mode only: the cache of the draw(s) builds next to the encoder
         z0, code_s, code_v = self.encode_initial_state(X)

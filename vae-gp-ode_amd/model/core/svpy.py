@@ -87,6 +87,13 @@ class SVGP_Layer(torch.nn.Module):
         per = [self._expand_shared(self._take_noise()) for _ in range(L)]
         return {k: torch.stack([nz[k] for nz in per]) for k in per[0]}
 
+    def predraw(self, draws=None):
+        """Draw the noise of the next build_cache(draws=...) NOW (on the current stream) and keep it for that call -- used with a
+        device noise source whose launch also carries other draws of the step (DeviceNoise.reserve)."""
+        if self._next_noise:
+            return                                   # explicit draws are queued: they win, nothing is drawn
+        self._predrawn = (draws, self._expand_shared(self._take_noise()) if draws is None else self._take_noise_draws(draws))
+
     def _expand_shared(self, nz):
         if nz['rff_eps'].dim() == 2:   # dimwise=False draws one frequency / phase set (kernels.py:118-124,131-132): repeat it per output
             nz = dict(nz, rff_eps=nz['rff_eps'].unsqueeze(-1).expand(-1, -1, self.D_out).contiguous(),
@@ -110,7 +117,11 @@ class SVGP_Layer(torch.nn.Module):
         else:
             if noise is not None:
                 self._next_noise.insert(0, noise)
-            nz = self._expand_shared(self._take_noise()) if draws is None else self._take_noise_draws(draws)
+            pre, self._predrawn = getattr(self, '_predrawn', None), None
+            if pre is not None and pre[0] == draws and not self._next_noise:
+                nz = pre[1]
+            else:
+                nz = self._expand_shared(self._take_noise()) if draws is None else self._take_noise_draws(draws)
         raw_ell, raw_var = self.kern.raw_dimwise()
         params = (raw_ell.detach(), raw_var.detach(), self.inducing_loc.optvar.detach(), self.Um.optvar.detach(), self.us_packed().detach())
         pad = self.width_pad

@@ -70,7 +70,8 @@ class Encoder(nn.Module):
         used for parity tests and for data-parallel runs that must share the draw."""
         eps = getattr(self, 'next_eps', None)
         if eps is None:
-            eps = torch.randn_like(mu)
+            src = getattr(self, 'eps_source', None)  # noise.install_device_noise: the library's generator instead of torch's
+            eps = src.normal(tuple(mu.shape), mu.device) if src is not None and mu.is_cuda else torch.randn_like(mu)
         self.next_eps = None
         return V.reparam(mu, logvar, eps.to(mu))     # mu + exp(logvar / 2) * eps, one launch
 

@@ -43,7 +43,7 @@ def _chk(t, name, shape=None):
 # (profiles/r02b_notes.txt: a torch.zeros there made the GP parameter gradients wobble from run to run).
 # ---------------------------------------------------------------------------------------------
 _launch_override = []          # stack of torch streams that _stream() returns instead of the current stream
-_overlap = {'on': False, 'side': None, 'pending': [], 'forked': False}
+_overlap = {'on': False, 'side': None, 'pending': [], 'forked': False, 'kl': None}
 
 
 def _stream():
@@ -105,13 +105,26 @@ def _main_marker():
     d.zero_()
 
 
+def defer_kl_grads(params, grads):
+    """Overlap mode: the gradients of KL(q(u)||p(u)) w.r.t. (Um, Us) -- written at the very start of the backward pass -- are
+    not handed to autograd (which would add the flow's gradients to them in a launch of its own per tensor) but kept for the
+    flow's deferred backward, whose last kernel adds its own contribution in place.  True if taken."""
+    if not _overlap['on'] or _overlap['kl'] is not None:
+        return False
+    _overlap['kl'] = (tuple(params), tuple(grads))
+    return True
+
+
 def join_side_stream():
     """Current stream waits for the side stream; deferred parameter gradients are accumulated."""
-    if not _overlap['forked'] and not _overlap['pending']:
+    if not _overlap['forked'] and not _overlap['pending'] and _overlap['kl'] is None:
         return
     torch.cuda.current_stream().wait_stream(side_stream())
     _overlap['forked'] = False
     pend, _overlap['pending'] = _overlap['pending'], []
+    kl, _overlap['kl'] = _overlap['kl'], None
+    if kl is not None:                               # no flow backward took the KL gradients along: they are the parameters' own
+        pend.append((kl[0], kl[1], None))
     with torch.no_grad():
         for params, grads, _keep in pend:
             for p, g in zip(params, grads):
@@ -543,9 +556,12 @@ class _Flow(torch.autograd.Function):
             side = fork_side_stream()
             _main_marker()
             scratch = []
+            kl, add_to = _overlap['kl'], None
+            if kl is not None and kl[0][0].data_ptr() == ctx.params[3].data_ptr() and kl[0][1].data_ptr() == ctx.params[4].data_ptr():
+                add_to, _overlap['kl'] = kl[1], None  # the KL gradients of (Um, Us): the cache backward adds the flow's to them
             with launch_on(side):
                 gpack = param_grad(c, xs.reshape(lead + (-1, c.Di)), ast.reshape(lead + (-1, c.Do)), keep=scratch)
-                g = cache_build_bwd(c, raw_ell, raw_var, Z, gpack, prepared=ctx.prepared)
+                g = cache_build_bwd(c, raw_ell, raw_var, Z, gpack, prepared=ctx.prepared, add_to=add_to)
             grads = [g['raw_ell'], g['raw_var'], g['Z'], g['Um'], g['Us']]
             # every buffer a side-stream kernel touches stays referenced until join_side_stream(): the allocator would
             # otherwise hand the block to the encoder-backward kernels the main stream launches meanwhile
@@ -584,22 +600,26 @@ def cache_bwd_prepare(cache):
     return bws
 
 
-def cache_build_bwd(cache, raw_ell, raw_var, Z, gpack, prepared=None):
+def cache_build_bwd(cache, raw_ell, raw_var, Z, gpack, prepared=None, add_to=None):
     """Pack-layout gradient ([L,] pack_floats) -> gradients of the five raw GP parameter tensors (state_dict layouts), summed
-    over the draws of the cache."""
+    over the draws of the cache.  ``add_to`` = (gUm, gUs): tensors that already hold a gradient of Um / Us (the KL term's); the
+    flow's gradient is added to them in place and they are returned as out['Um'], out['Us']."""
     c = cache
     bw = ctypes.c_size_t(0)
     _lib.call('gpode_cache_bwd_sizes_n', KERNEL_ID[c.kernel], c.Di, c.Do, c.M, c.S, c.nd, ctypes.byref(bw))
     dev = gpack.device
     new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     bws = prepared if prepared is not None else new(bw.value)
-    out = dict(raw_ell=new(c.Do, c.Di), raw_var=new(c.Do), Z=new(c.M, c.Di), Um=new(c.M, c.Do),
-               Us=new(c.Do, c.M * (c.M + 1) // 2))
+    out = dict(raw_ell=new(c.Do, c.Di), raw_var=new(c.Do), Z=new(c.M, c.Di))
+    if add_to is None:
+        out['Um'], out['Us'] = new(c.M, c.Do), new(c.Do, c.M * (c.M + 1) // 2)
+    else:
+        out['Um'], out['Us'] = _chk(add_to[0], 'gUm', (c.M, c.Do)), _chk(add_to[1], 'gUs', (c.Do, c.M * (c.M + 1) // 2))
     _lib.call('gpode_cache_build_bwd_n', KERNEL_ID[c.kernel], c.Di, c.Do, c.M, c.S, c.nd,
               _ptr(_chk(raw_ell, 'raw_ell')), _ptr(_chk(raw_var, 'raw_var')), _ptr(_chk(Z, 'Z')),
               _ptr(_chk(c.noise['eps_u'], 'eps_u', c.lead + (c.M, c.Do))),
               _ptr(_chk(c.pack, 'pack')), _ptr(c.ws), _ptr(_chk(gpack, 'gpack', c.lead + (c.pack.shape[-1],))), _ptr(bws),
               _ptr(out['raw_ell']), _ptr(out['raw_var']), _ptr(out['Z']), _ptr(out['Um']), _ptr(out['Us']),
-              int(prepared is not None), _stream())
+              int(prepared is not None) | (2 if add_to is not None else 0), _stream())
     out['_workspace'] = bws   # referenced by the caller for as long as a side stream may still be writing it
     return out

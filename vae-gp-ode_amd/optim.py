@@ -26,7 +26,7 @@ class HipAdam:
         dev = self.params[0].device
         # device-resident copy of the step count: incremented by the update kernel's launch sequence, so a captured
         # HIP graph of the whole training step (see graph.py) replays with the right bias correction
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step_dev = torch.zeros(2, dtype=torch.int32, device=dev)     # {updates done, ticket}: advanced by the update kernel
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         # persistent gradient storage: views into one flat bucket (all-reduced in place under data parallelism)
@@ -37,6 +37,10 @@ class HipAdam:
         if self.gather:
             self.flat_grads.gather = self.gather_grads
 
+        # Handed-over gradients (False / 'gather') are first READ by this optimiser (or the bucket gather), after the backward
+        # pass has ended: the backward kernels' final reductions of workgroup partials may then all run in ONE launch at the end of
+        # the pass (vae_ops.set_deferred_reductions).  With persistent views autograd adds every gradient as it arrives -- too early.
+        self.allows_deferred_reductions = not self.bucketed
         self._zero = {}
         offs, tot = [], 0
         for p in self.params:
@@ -54,6 +58,7 @@ class HipAdam:
         # pinned sources for tables uploaded INSIDE a graph capture (allocating pinned memory is not a capturable call): one per
         # captured graph that holds the update
         self._pinned = [torch.zeros(len(self.params), dtype=torch.int64).pin_memory() for _ in range(8)]
+        self._static_tabs = [torch.zeros(len(self.params), dtype=torch.int64, device=dev) for _ in range(8)]   # see _refresh_grad_table
         self._offs = torch.tensor(offs, dtype=torch.int64, device=dev)
         if self.gather:                              # the update reads the (all-reduced) bucket: a static table of pointers into it
             base = self.flat_grads.flat.data_ptr()
@@ -88,13 +93,24 @@ class HipAdam:
                 self._tables.clear()
             if torch.cuda.is_current_stream_capturing():
                 # inside a capture the upload must be a node of the graph: pinned source kept alive with the table
-                if not self._pinned:
+                if not self._pinned or not self._static_tabs:
                     raise _lib.GpodeError('HipAdam: more than 8 captured graphs hold the update; create the optimiser with more staging buffers')
-                host = self._pinned.pop()
-                host.copy_(torch.tensor(cur, dtype=torch.int64))
-                tab = torch.empty(len(cur), dtype=torch.int64, device=self._p.device)
-                tab.copy_(host, non_blocking=True)
-                self._tables[key] = (tab, host)
+                from . import graph
+                if graph.capturing_step():
+                    # GraphedStep: the table's content is a constant of the captured graph -- it is uploaded ONCE, right after the
+                    # capture ends and before the first replay, instead of by a copy node that every replay would repeat.  The
+                    # table must then live OUTSIDE the graph's memory pool: a block allocated during the capture may have had an
+                    # earlier life inside the same step, and the kernel that wrote it then overwrites the table at every replay.
+                    tab = self._static_tabs.pop()
+                    vals = torch.tensor(cur, dtype=torch.int64)
+                    graph.after_capture(lambda t=tab, v=vals: t.copy_(v))
+                    self._tables[key] = (tab, vals)
+                else:
+                    tab = torch.empty(len(cur), dtype=torch.int64, device=self._p.device)
+                    host = self._pinned.pop()
+                    host.copy_(torch.tensor(cur, dtype=torch.int64))
+                    tab.copy_(host, non_blocking=True)
+                    self._tables[key] = (tab, host)
             else:
                 tab = torch.tensor(cur, dtype=torch.int64, device=self._p.device)   # synchronous upload, once per set
                 self._tables[key] = (tab, None)

@@ -5,7 +5,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 from .ops import _chk, _ptr, _stream
 
 
@@ -26,12 +26,14 @@ def _bn_scratch(B, C, like):
 
 
 # ---- deferred final reductions (include/gpode.h: gpode_defer_reductions / gpode_flush_reductions) --------------------------------
-# EXPERIMENTAL, off (set_deferred_reductions): the weight / bias gradients and BatchNorm channel sums produced by the backward
-# functions below then become valid at the END of the backward pass (one launch for all of them, from autograd's end-of-backward
-# callback) instead of when each function returns.  That is only sound when nothing reads them earlier, and autograd does read:
-# it clones an incoming gradient whenever it is not its sole owner, and adds it when ``p.grad`` exists.  Measured gain when it
-# works: configs[0] 0.927 -> 0.903 ms, configs[1] 3.10 -> 3.07 ms per step; tests/test_gpu_optim.py::
-# test_graph_replay_equals_eager_steps differs with it on (an early read somewhere in the pass), so no training loop enables it.
+# set_deferred_reductions(True): the weight / bias gradients and BatchNorm channel sums produced by the backward functions below
+# become valid at the END of the backward pass -- ONE launch reduces all their workgroup partials (from autograd's end-of-backward
+# callback) instead of one few-microsecond launch per function (14 per step of a first-order model: graph nodes on the critical
+# chain).  Sound only when nothing reads those tensors earlier, and autograd does read in two cases: it CLONES an incoming
+# gradient that has a second owner, and it ADDS to ``p.grad`` when that exists.  Hence: on only with an optimiser that drops the
+# gradients in zero_grad and takes over the tensors autograd hands it (optim.HipAdam(bucketed=False | 'gather'):
+# ``allows_deferred_reductions``) -- the training loops of this package (main.py, main_vae.py, bench.py) switch it on there; the
+# default is off.  configs[0]: 14 reduction launches -> 1.
 _deferred = {'on': False, 'keep': [], 'queued': False}
 _DEFER_ALLOWED = os.environ.get('GPODE_EAGER_REDUCTIONS', '0') != '1'
 
@@ -636,6 +638,9 @@ class _ElboAll(torch.autograd.Function):
         dUm, dUs = torch.empty_like(Um), torch.empty_like(Us)
         _lib.call('gpode_elbo_all_bwd', *[_ptr(g) for g in gs], rows, _ptr(hs), _ptr(hv), N, q, M, Um.shape[1], _ptr(Um), _ptr(Us),
                   ctypes.c_float(nobs), _ptr(glrow), _ptr(ghs), _ptr(ghv), _ptr(dUm), _ptr(dUs), _stream())
+        if (ctx.needs_input_grad[3] and ctx.needs_input_grad[4] and Um.is_leaf and Us.is_leaf and
+                ops.defer_kl_grads((Um, Us), (dUm, dUs))):
+            dUm = dUs = None                         # overlap mode: the flow's deferred backward adds its share to them in place
         # every slice of a likelihood row carries the row's gradient (a broadcast view: nothing is copied)
         return glrow.view(rows, 1).expand(lshape), ghs, ghv, dUm, dUs, None, None, None
 
