@@ -356,8 +356,6 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
     # within 0.1 of the initial state.
     # one GPU: no gradient bucket; N > 1: the bucket is filled in one launch from the produced gradients before the all-reduce
     opt = HipAdam(model.parameters(), lr=1e-6, bucketed='gather' if dist is not None else False)
-    from vae_gp_ode_amd import vae_ops
-    vae_ops.set_deferred_reductions(opt.allows_deferred_reductions)   # one launch for all final reductions of the backward pass
     sync = GradAllReduce(opt.flat_grads, dist) if dist is not None else None
     bn_sync = None
     if dist is not None and not a.no_sync_bn:          # BatchNorm over the GLOBAL minibatch, as the single-process reference
@@ -547,8 +545,6 @@ def quick_elbo(w, dev, seed, steps=30, warmup=5, L=1):
     model, X = make_model_inputs(w, seed, dev, 0)
     Xd = X.to(dev)
     opt = HipAdam(model.parameters(), lr=1e-6, bucketed=False)
-    from vae_gp_ode_amd import vae_ops
-    vae_ops.set_deferred_reductions(opt.allows_deferred_reductions)
 
     def whole_step():
         opt.zero_grad()

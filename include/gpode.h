@@ -213,6 +213,19 @@ int gpode_conv2d_bwd_data(const float* gy, const float* w, const float* bias, fl
  * specialisations only (decnn.4/7/10); other geometries return an error. */
 int gpode_conv2d_bwd_data_bn(const float* gy, const float* gy_bn, const float* w, const float* bias, float* gx, int B, int Ci, int H,
                              int W, int Co, int K, int S, int P, int Ho, int Wo, void* stream);
+/* ConvTranspose2d forward (geometry arguments as gpode_conv2d_bwd_data: the convolution it is the adjoint of; x_bn = NULL or the
+ * input's BatchNorm + ReLU table as above) that ALSO produces what the nn.BatchNorm2d in training mode BEHIND it needs (vae.py:107-120:
+ * ConvTranspose2d -> BatchNorm2d): batch mean / invstd of the output y, the running-statistics update (momentum; unbiased variance;
+ * num_batches_tracked += 1) and the {mean, invstd, gamma, beta} table for the next gpode_conv2d_bwd_data_bn.  The sums are taken while
+ * y is stored and combined in a fixed order by the last workgroup to finish: no statistics pass over y, no separate table launch.
+ *   gamma, beta (C = output channels): the BatchNorm's affine parameters;  running_mean / running_var / num_batches_tracked may be NULL;
+ *   scratch: gpode_convT_fwd_stats_scratch(C) floats;  slot 0..63: launches that may run concurrently need different slots.
+ * Matrix-core specialisations only (decnn.1/4/7); other geometries return an error. */
+size_t gpode_convT_fwd_stats_scratch(int Cout);
+int gpode_convT_fwd_stats(const float* x, const float* x_bn, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co,
+                          int K, int S, int P, int Ho, int Wo, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
+                          float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, float* table,
+                          float* scratch, int slot, void* stream);
 size_t gpode_conv_wgrad_scratch(int B, int Ci, int Co, int K);
 int gpode_conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci, int H, int W,
                             int Co, int K, int S, int P, int Ho, int Wo, void* stream);

@@ -33,3 +33,15 @@ def golden():
             cache[name] = load_golden(name)
         return cache[name]
     return get
+
+
+@pytest.fixture(autouse=True)
+def _process_wide_switches_off():
+    """Process-wide switches a training loop may have left on (side-stream overlap, deferred final reductions -- both set by the
+    optimiser / main() of an earlier test in the same process): every test starts from the defaults."""
+    mods = sys.modules
+    if 'vae_gp_ode_amd.vae_ops' in mods:
+        mods['vae_gp_ode_amd.vae_ops'].set_deferred_reductions(False)
+    if 'vae_gp_ode_amd.ops' in mods:
+        mods['vae_gp_ode_amd.ops'].set_overlap(False)
+    yield

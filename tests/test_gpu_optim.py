@@ -134,9 +134,10 @@ def test_graph_replay_equals_eager_steps():
 
     def run(use_graph, overlap=False, bucketed=True, deferred=False):
         ops.set_overlap(overlap)
-        vae_ops.set_deferred_reductions(deferred)
         m.load_state_dict(init)
         opt = HipAdam(m.parameters(), lr=1e-3, bucketed=bucketed)
+        assert vae_ops._deferred['on'] == (bucketed is not True)    # the optimiser sets the switch for its kind ...
+        vae_ops.set_deferred_reductions(deferred)                    # ... and this test covers both settings where both are sound
 
         def step():
             enc.next_eps = eps

@@ -142,7 +142,7 @@ def test_elbo_glue_ops(N, q):
         assert relerr(x.grad, y.grad) < 2e-5
 
 
-@pytest.mark.parametrize('B', [2, 37, 130])
+@pytest.mark.parametrize('B', [2, 37, 130, 700, 1300])
 @pytest.mark.parametrize('geom', [((64, 6, 6), (64, 32, 5, 5), (2, 1, 0)), ((32, 13, 13), (32, 16, 5, 5), (2, 1, 1)),
                                   ((16, 28, 28), (16, 1, 5, 5), (1, 2, 0))])
 def test_fused_batchnorm_relu_conv_transpose(B, geom):
@@ -172,6 +172,77 @@ def test_fused_batchnorm_relu_conv_transpose(B, geom):
     assert relerr(bn.weight.grad, ref.weight.grad) < 5 * TOL and relerr(bn.bias.grad, ref.bias.grad) < 5 * TOL
     assert relerr(bn.running_mean, ref.running_mean) < 1e-5 and relerr(bn.running_var, ref.running_var) < 1e-5
     assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B', [2, 37, 700, 1300])
+def test_decoder_chain_with_statistics_summed_by_the_producing_convolution(B, monkeypatch):
+    """decnn.1 -> BatchNorm -> ReLU -> decnn.4 -> BatchNorm -> ReLU -> decnn.7 -> BatchNorm -> ReLU -> decnn.10 (vae.py:107-120) with
+    every BatchNorm's batch statistics summed by the transposed convolution in front of it while it stores its output and
+    finalised by that kernel's last workgroup (gpode_convT_fwd_stats; all three producers: the taps-as-columns kernels of
+    decnn.1 / decnn.4 and the plane engine of decnn.4 / decnn.7), two training steps (the second one shifts the sums by the
+    running mean of the first): outputs, every gradient and the running statistics against torch in fp64, and bit-identical
+    results from a second run (the combination order does not depend on which workgroup finishes last)."""
+    from vae_gp_ode_amd import vae_ops as V
+    monkeypatch.setattr(V, '_FUSED_STATS_MIN_IMAGES', 1)
+    g = torch.Generator().manual_seed(5)
+    ref = torch.nn.Sequential(torch.nn.ConvTranspose2d(32, 64, 3, 1, 0), torch.nn.BatchNorm2d(64), torch.nn.ReLU(),
+                              torch.nn.ConvTranspose2d(64, 32, 5, 2, 1), torch.nn.BatchNorm2d(32), torch.nn.ReLU(),
+                              torch.nn.ConvTranspose2d(32, 16, 5, 2, 1, output_padding=1), torch.nn.BatchNorm2d(16), torch.nn.ReLU(),
+                              torch.nn.ConvTranspose2d(16, 1, 5, 1, 2)).double()
+    with torch.no_grad():
+        for m in ref:
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5); m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.3)
+            if isinstance(m, torch.nn.ConvTranspose2d):
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.5)      # channel means of the order of the spread
+    import copy
+
+    def run():
+        d = copy.deepcopy(ref).float().cuda()
+        outs = []
+        for step in range(2):
+            x = (torch.randn(B, 32, 4, 4, generator=torch.Generator().manual_seed(20 + step)) * 0.8).cuda().requires_grad_(True)
+            for p in d.parameters():
+                p.grad = None
+            c = V.conv_transpose2d(x, d[0].weight, d[0].bias, 1, 0, stats_for=d[1])
+            assert getattr(c, '_gpode_bnstats', None) is not None or not V._fused_stats   # the producer took the statistics
+            c = V.bn_relu_conv_transpose2d(c, d[1], d[3].weight, d[3].bias, 2, 1, stats_for=d[4])
+            c = V.bn_relu_conv_transpose2d(c, d[4], d[6].weight, d[6].bias, 2, 1, 1, stats_for=d[7])
+            assert getattr(c, '_gpode_bnstats', None) is not None or not V._fused_stats
+            y = V.bn_relu_conv_transpose2d(c, d[7], d[9].weight, d[9].bias, 1, 2)
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(40 + step)).cuda()
+            y.backward(gy)
+            outs.append((y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in d.parameters()], [b.clone() for b in d.buffers()]))
+        return outs
+    a, b = run(), run()
+    for (y1, gx1, gp1, bf1), (y2, gx2, gp2, bf2) in zip(a, b):
+        assert torch.equal(y1, y2) and torch.equal(gx1, gx2) and all(torch.equal(p, q) for p, q in zip(gp1, gp2))
+        assert all(torch.equal(p, q) for p, q in zip(bf1, bf2))
+    # Gradients are compared in the L2 norm: among the millions of pre-activations of a large batch a few sit within fp32 round-off
+    # of zero, fp32 and fp64 then disagree on their ReLU mask, and each such element changes a handful of gradient entries by O(1)
+    # -- invisible in the L2 norm, but the whole of a max-norm error (torch's own fp32 pass shows the same against fp64).
+    l2 = lambda a, b: float((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm())
+    r, r32 = copy.deepcopy(ref), copy.deepcopy(ref).float()
+    for step, (y, gx, gps, bufs) in enumerate(a):
+        x0 = torch.randn(B, 32, 4, 4, generator=torch.Generator().manual_seed(20 + step)) * 0.8
+        gy0 = torch.randn(y.shape, generator=torch.Generator().manual_seed(40 + step))
+        x64, x32 = x0.double().requires_grad_(True), x0.clone().requires_grad_(True)
+        for p in list(r.parameters()) + list(r32.parameters()):
+            p.grad = None
+        y64 = r(x64)
+        y64.backward(gy0.double())
+        r32(x32).backward(gy0)
+        # (bound: sums of ~1e6 zero-mean terms in fp32 partial sums; torch's CPU BatchNorm accumulates in double and is no yardstick)
+        tol = lambda mine, g64, g32: 2e-3 + 4 * l2(g32, g64)
+        assert relerr(y, y64) < TOL and l2(gx, x64.grad) < tol(gx, x64.grad, x32.grad), (step, relerr(y, y64), l2(gx, x64.grad), l2(x32.grad, x64.grad))
+        for (n, p64), (_, p32), gp in zip(r.named_parameters(), r32.named_parameters(), gps):
+            if n in ('0.bias', '3.bias', '6.bias'):    # a bias in front of a BatchNorm has no gradient: round-off on both sides
+                assert float(gp.abs().max()) < 10 * float(p32.grad.abs().max()) + 1e-3 and float(p64.grad.abs().max()) < 1e-9, (step, n)
+                continue
+            assert l2(gp, p64.grad) < tol(gp, p64.grad, p32.grad), (step, n, l2(gp, p64.grad), l2(p32.grad, p64.grad))
+        for (n, b64), bf in zip(r.named_buffers(), bufs):
+            assert relerr(bf.double(), b64.double()) < 1e-5, (step, n)
 
 
 @pytest.mark.gpu

@@ -246,6 +246,17 @@ int gpode_conv2d_bwd_data_bn(const float* gy, const float* gy_bn, const float* w
   if (!gy || !gy_bn || !w || !gx) return gp::set_error("gpode_conv2d_bwd_data_bn: null pointer");
   return gp::conv2d_bwd_data(gy, w, bias, gx, B, Ci, H, W, Co, K, S, P, Ho, Wo, gy_bn, GP_ST);
 }
+size_t gpode_convT_fwd_stats_scratch(int Cout) { return gp::convT_fwd_stats_scratch(Cout); }
+int gpode_convT_fwd_stats(const float* x, const float* x_bn, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co,
+                          int K, int S, int P, int Ho, int Wo, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
+                          float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, float* table,
+                          float* scratch, int slot, void* stream) {
+  if (!x || !w || !y || !gamma || !beta || !save_mean || !save_invstd || !table || !scratch)
+    return gp::set_error("gpode_convT_fwd_stats: null pointer");
+  if ((running_mean == nullptr) != (running_var == nullptr)) return gp::set_error("gpode_convT_fwd_stats: running_mean and running_var go together");
+  return gp::convT_fwd_stats(x, x_bn, w, bias, y, B, Ci, H, W, Co, K, S, P, Ho, Wo, gamma, beta, save_mean, save_invstd, running_mean,
+                             running_var, num_batches_tracked, momentum, eps, table, scratch, slot, GP_ST);
+}
 size_t gpode_conv_wgrad_scratch(int B, int Ci, int Co, int K) { return gp::conv_wgrad_scratch(B, Ci, Co, K); }
 int gpode_conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci, int H, int W,
                             int Co, int K, int S, int P, int Ho, int Wo, void* stream) {

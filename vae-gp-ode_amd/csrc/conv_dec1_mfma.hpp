@@ -11,6 +11,7 @@
 // channel), one image ahead.  T is double-buffered in LDS, so an image costs one barrier.
 #pragma once
 #include "conv_mfma.hpp"
+#include "bn_sink.hpp"
 
 namespace gp {
 namespace dec1 {
@@ -18,8 +19,10 @@ namespace dec1 {
 constexpr int CI = 32, CO = 64, NPI = 16, HO = 6, NPO = 36, KK = 9, NN = CO * KK, NTW = 9, KS = CI / 4;
 constexpr int TLD = NN + 4;                          // row stride of T: 580 = 4 mod 64, the 16 pixel rows start 4 banks apart
 
+// STATS: the BatchNorm statistics of the output (decnn.2) are summed while it is stored (bn_sink.hpp)
+template <bool STATS>
 __global__ __launch_bounds__(256, 2) void k_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                float* __restrict__ y, int B) {
+                                                float* __restrict__ y, int B, BnSink sink) {
   float* sT = igemm_smem;                            // [2][16][TLD]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
@@ -47,6 +50,12 @@ __global__ __launch_bounds__(256, 2) void k_fwd(const float* __restrict__ x, con
         if (oy - ky >= 0 && oy - ky < 4 && ox - kx >= 0 && ox - kx < 4) m |= 1u << (3 * ky + kx);
     gmask[i] = m;
     gbias[i] = bias ? bias[co] : 0.f;
+  }
+  float gk[NOUT], ss[NOUT], sq[NOUT];                // STATS: shift, sum (y - k), sum (y - k)^2 of this thread's nine outputs
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) {
+    gk[i] = STATS ? bn_sink_shift(sink, (tid + 256 * i) / NPO) : 0.f;
+    ss[i] = sq[i] = 0.f;
   }
   float af[KS];
   auto loadA = [&](int b) {                          // A[m = pixel][k = ci] = x[b][ci][pixel]
@@ -89,8 +98,31 @@ __global__ __launch_bounds__(256, 2) void k_fwd(const float* __restrict__ x, con
 #pragma unroll
       for (int t = 0; t < KK; ++t) v += (gmask[i] >> t & 1) ? tv[t] : 0.f;
       yb[256 * i] = v;
+      if (STATS) {
+        const float d = v - gk[i];
+        ss[i] += d;
+        sq[i] = fmaf(d, d, sq[i]);
+      }
     }
     buf ^= 1;
+  }
+  if constexpr (STATS) {
+    // per-thread sums -> LDS by output index, then thread c adds the 36 entries of channel c in order
+    __syncthreads();
+    float* S0 = sT;                                  // [2304], [2304], then the workgroup's [CO][2]
+    float* S1 = sT + CO * NPO;
+    float* sm = sT + 2 * CO * NPO;
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) { S0[tid + 256 * i] = ss[i]; S1[tid + 256 * i] = sq[i]; }
+    __syncthreads();
+    if (tid < CO) {
+      float a = 0.f, b = 0.f;
+      for (int q = 0; q < NPO; ++q) { a += S0[tid * NPO + q]; b += S1[tid * NPO + q]; }
+      sm[2 * tid] = a;
+      sm[2 * tid + 1] = b;
+    }
+    __syncthreads();
+    bn_sink_publish<CO, 256>(sink, sm);
   }
 }
 

@@ -8,6 +8,7 @@
 // loop.  T (36 x 804 floats = 116 KB) lives in LDS, one image at a time.
 #pragma once
 #include "conv_mfma.hpp"
+#include "bn_sink.hpp"
 
 namespace gp {
 namespace dec4 {
@@ -16,9 +17,10 @@ constexpr int CI = 64, CO = 32, NPI = 36, HI = 6, HO = 13, NPO = 169, KK = 25, N
 constexpr int TLD = NN + 4;                          // 804 = 36 mod 64: the four row groups of a tile store 16 banks apart
 constexpr int NOUT = (CO * NPO + 511) / 512;         // 11 output slots per thread (5408 outputs)
 
-template <bool HAS_BN>
+// STATS: the BatchNorm statistics of the output (decnn.5) are summed while it is stored (bn_sink.hpp)
+template <bool HAS_BN, bool STATS = false>
 __global__ __launch_bounds__(512, 2) void k_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                float* __restrict__ y, int B, const float* __restrict__ in_bn) {
+                                                float* __restrict__ y, int B, const float* __restrict__ in_bn, BnSink sink) {
   float* T = igemm_smem;                             // [36][TLD]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
@@ -41,6 +43,12 @@ __global__ __launch_bounds__(512, 2) void k_fwd(const float* __restrict__ x, con
         af[mt][ks] = HAS_BN ? bn_relu(v, sTF[4 * ks + lk]) : v;
       }
   };
+  // STATS: running sum (y - k), sum (y - k)^2 of every output slot (each owned by one thread) behind T and the table -- the
+  // registers are taken (112 of weight fragments)
+  float* S0 = T + NPI * TLD + 4 * CI;
+  float* S1 = S0 + CO * NPO;
+  if (STATS)
+    for (int e = tid; e < 2 * CO * NPO; e += 512) S0[e] = 0.f;
   if ((int)blockIdx.x < B) loadA(blockIdx.x);
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
 #pragma unroll
@@ -90,9 +98,25 @@ __global__ __launch_bounds__(512, 2) void k_fwd(const float* __restrict__ x, con
             v += ok ? tv[3 * a + c] : 0.f;
           }
         yb[o] = v;
+        if (STATS) {
+          const float d = v - bn_sink_shift(sink, co);
+          S0[o] += d;
+          S1[o] = fmaf(d, d, S1[o]);
+        }
       }
     }
     __syncthreads();                                 // every thread is done with T before the next image overwrites it
+  }
+  if constexpr (STATS) {
+    float* sm = T;                                   // the workgroup's [CO][2]  (T is free: last barrier above)
+    if (tid < CO) {
+      float a = 0.f, b = 0.f;
+      for (int q = 0; q < NPO; ++q) { a += S0[tid * NPO + q]; b += S1[tid * NPO + q]; }
+      sm[2 * tid] = a;
+      sm[2 * tid + 1] = b;
+    }
+    __syncthreads();
+    bn_sink_publish<CO, 512>(sink, sm);
   }
 }
 

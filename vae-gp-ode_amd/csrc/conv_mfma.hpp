@@ -27,6 +27,7 @@
 #include <cstdint>
 #include <type_traits>
 #include "bn_math.hpp"
+#include "bn_sink.hpp"
 
 namespace gp {
 
@@ -127,10 +128,10 @@ template <class L, int NCS_> struct BwdDataPolicy {
 template <class PL> constexpr bool igemm_tf_in_pad() { return PL::PS % 4 == 0 && (PL::HP * PL::HP + 3) / 4 * 4 + 4 <= PL::PS; }
 
 // All k-steps (tap x 4*KB source channels) of NG pixel tiles x NCJ channel tiles of one wavefront.
-template <class CG, int NG, int TG, int NCJ, int KC, int WROW, int PS>
+template <class CG, int NG, int TG, int NCJ, int KC, int WROW, int PS, int KBMAX = 8>
 __device__ __forceinline__ void igemm_tile_mma(const float* __restrict__ s_img, const float* __restrict__ sw, const int (&abase)[TG],
                                                int lk, int lr, f32x4 (&acc)[TG][NCJ]) {
-  constexpr int KB = (KC / 4) < 8 ? (KC / 4) : 8;   // MFMA k-steps per fetch batch
+  constexpr int KB = (KC / 4) < KBMAX ? (KC / 4) : KBMAX;   // MFMA k-steps per fetch batch
   constexpr int NB = KC / (4 * KB);                 // batches per tap
   constexpr int nsteps = CG::ntaps * NB;
   float bfA[KB][NCJ], afA[KB][NG], bfB[KB][NCJ], afB[KB][NG];
@@ -157,13 +158,27 @@ __device__ __forceinline__ void igemm_tile_mma(const float* __restrict__ s_img, 
   };
   fetch(0, bfA, afA);
   int s = 0;
-  while (true) {
-    if (s + 1 < nsteps) fetch(s + 1, bfB, afB);
-    mma(bfA, afA);
-    if (++s >= nsteps) break;
-    if (s + 1 < nsteps) fetch(s + 1, bfA, afA);
-    mma(bfB, afB);
-    if (++s >= nsteps) break;
+  if constexpr (KBMAX < 8) {
+    // three wavefronts per SIMD (168 registers): keep the k loop a loop -- unrolled over all taps the scheduler hoists the operand
+    // fetches of every step to the top and spills
+#pragma nounroll
+    while (true) {
+      if (s + 1 < nsteps) fetch(s + 1, bfB, afB);
+      mma(bfA, afA);
+      if (++s >= nsteps) break;
+      if (s + 1 < nsteps) fetch(s + 1, bfA, afA);
+      mma(bfB, afB);
+      if (++s >= nsteps) break;
+    }
+  } else {
+    while (true) {
+      if (s + 1 < nsteps) fetch(s + 1, bfB, afB);
+      mma(bfA, afA);
+      if (++s >= nsteps) break;
+      if (s + 1 < nsteps) fetch(s + 1, bfA, afA);
+      mma(bfB, afB);
+      if (++s >= nsteps) break;
+    }
   }
 }
 
@@ -173,23 +188,32 @@ extern __shared__ __attribute__((aligned(16))) float igemm_smem[];
 // NCJ: channel tiles per job.  PAIR: process the px = 0 / px = 1 classes of a row parity together and store float2
 // (stride-2 layers with an even output width: without it every 64-byte line of y is written twice, half each time --
 // measured 401 MB of HBM writes for a 205 MB output).
-template <class PL, int IPB, int TG, int NCJ, bool PAIR, int NTHR, bool DB = false>
+// PC (producer / consumer; NTHR = 768, double-buffered planes): wavefronts 0..7 only multiply and store -- wavefronts 8..11 (one per
+// SIMD, raised priority) fetch the next group from HBM and scatter it into the other plane buffer meanwhile; ONE barrier per group.
+// In the other forms all wavefronts walk through fetch, scatter, multiply and store in lockstep, and the matrix pipe idles in every
+// phase but one (tools/convt_probe.hip: the MFMA phase is 62 % of a decnn.7 forward wavefront's life and pipe-bound inside).
+// STATS: the BatchNorm statistics of the OUTPUT are summed while it is stored and finalised by the last workgroup (bn_sink.hpp).
+template <class PL, int IPB, int TG, int NCJ, bool PAIR, int NTHR, bool DB = false, bool PC = false, bool STATS = false>
 __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y, int B,
-                                                      const float* __restrict__ in_bn) {
+                                                      const float* __restrict__ in_bn, BnSink sink) {
   constexpr int KC = PL::KC, NC = PL::NC, NCS = PL::NCS, NCLS = PL::NCLS, SH = PL::SH, OH = PL::OH, HP = PL::HP, PS = PL::PS;
   constexpr int PADL = PL::PADL, WROW = PL::WROW, NWE = PL::NWE;
   static_assert(NCS % 16 == 0 && NC % NCS == 0 && KC % 4 == 0 && NTHR % 256 == 0, "MFMA tiling");
-  constexpr int NW = NTHR / 64;
+  static_assert(!PC || (NTHR == 768 && DB), "producer / consumer form: 8 + 4 wavefronts on double-buffered planes");
+  constexpr int NW = PC ? 8 : NTHR / 64;             // wavefronts that run the jobs
+  constexpr int PT = PC ? 256 : NTHR;                // threads that fetch and scatter the source images
+  constexpr int KBM = PC ? 4 : 8;                    // k-steps per operand fetch batch (PC: three wavefronts per SIMD, 168 registers)
   constexpr int NCO = NCS / 16;                      // channel tiles per pass
   static_assert(NCO % NCJ == 0, "channel tiles per job");
   constexpr int NJ = NCO / NCJ;                      // job columns per pixel tile
   static_assert(NJ == 1 || TG == 1, "tile groups share all channel tiles");
+  static_assert(!STATS || NJ == 1, "output statistics: a lane keeps the same channels in every job of a pass");
   constexpr int IMG = KC * PS;
   static_assert(IMG % 4 == 0, "float4 zero fill");
   constexpr int SRC = KC * SH * SH;                  // floats per source image
   static_assert(SRC % 4 == 0, "float4 source fetch");
-  constexpr int NLD = (IPB * SRC / 4 + NTHR - 1) / NTHR;   // float4 fetches per thread per group
+  constexpr int NLD = (IPB * SRC / 4 + PT - 1) / PT;       // float4 fetches per (fetching) thread per group
   constexpr int NBUF = DB ? 2 : 1;
   float* s_img = igemm_smem;                         // [NBUF][IPB][KC][PS] zero padded planes
   float* s_w = igemm_smem + NBUF * IPB * IMG;        // [cls][tap][KC][WROW]
@@ -201,10 +225,12 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
   // which is what lets two 256-thread workgroups of the decnn.7 forward share a CU (2 x 80 KB) -- otherwise behind the slabs.
   constexpr int TFO = (HP * HP + 3) / 4 * 4;
   constexpr bool TF_PAD = igemm_tf_in_pad<PL>();
+  float* s_sm = s_w + PL::WSLAB + (TF_PAD ? 0 : 4 * KC);       // STATS: this workgroup's [NC][2] sums, filled pass by pass
   float4* s_tf_tail = reinterpret_cast<float4*>(s_w + PL::WSLAB);
   auto tf_slot = [&](int ch) -> float4* { return TF_PAD ? reinterpret_cast<float4*>(s_img + ch * PS + TFO) : s_tf_tail + ch; };
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
+  const int ptid = PC ? tid - 512 : tid;             // index among the fetching threads (PC: negative in the consumers, unused there)
   const int ngroups = (B + IPB - 1) / IPB;
   const float4* x4 = reinterpret_cast<const float4*>(x);
   // wavefront w runs on SIMD w & 3: order the wavefronts SIMD-major so that each SIMD owns a contiguous cost range
@@ -216,6 +242,8 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
     if (TF_PAD) __syncthreads();                     // the zero fill above covers the slots
     for (int e = tid; e < KC; e += NTHR) *tf_slot(e) = reinterpret_cast<const float4*>(in_bn)[e];
   }
+  if (STATS)
+    for (int e = tid; e < 2 * NC; e += NTHR) s_sm[e] = 0.f;
 
   // NC / NCS passes over the output channels.  When the grid divides evenly the passes are spread over the workgroups
   // (each stages ONE slab and walks every image group with its share of the grid); otherwise every workgroup loops.
@@ -242,23 +270,33 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
     }
     PROBE_ADD(0, pt_w);
 
+    // STATS: shift and running sums of (y - k), (y - k)^2 for the channels this lane stores (the same in every job: NJ == 1)
+    float kshift[NCJ][4], bs[NCJ][4], bq[NCJ][4];
+#pragma unroll
+    for (int cc = 0; cc < NCJ; ++cc)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        kshift[cc][r] = STATS ? bn_sink_shift(sink, n0 + cc * 16 + 4 * lk + r) : 0.f;
+        bs[cc][r] = bq[cc][r] = 0.f;
+      }
     float4 pre[NLD];
-    auto prefetch = [&](int grp) {
+    auto prefetch = [&](int grp) __attribute__((always_inline)) {
       const int b0 = grp * IPB;
       const int nf4 = min(IPB, B - b0) * (SRC / 4);
       const float4* src = x4 + (size_t)b0 * (SRC / 4);
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
-        const int f = tid + NTHR * i;
-        if (f < nf4) pre[i] = src[f];
+        const int f = ptid + PT * i;
+        if (PC) pre[i] = src[min(f, nf4 - 1)];       // unconditional (clamped): no branch and no vmcnt(0) per load
+        else if (f < nf4) pre[i] = src[f];
       }
     };
     // the prefetched source group -> zero-padded planes (BatchNorm + ReLU on the way when in_bn)
-    auto scatter = [&](float* __restrict__ img, int nimg) {
+    auto scatter = [&](float* __restrict__ img, int nimg) __attribute__((always_inline)) {
       const int nf4 = nimg * (SRC / 4);
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
-        const int f = tid + NTHR * i;
+        const int f = ptid + PT * i;
         if (f < nf4) {
           const float v[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
           // one division per float4, then carries: plane / row / column of the following three elements
@@ -335,10 +373,10 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
           auto run = [&](auto gtag, const float* sw, const int (&ab)[TG], f32x4 (&ac)[TG][NCJ]) {
             using GG = typename decltype(gtag)::type;
             switch (ng) {                            // wave-uniform
-              case 1: igemm_tile_mma<GG, 1, TG, NCJ, KC, WROW, PS>(img, sw, ab, lk, lr, ac); break;
-              case 2: if constexpr (TG >= 2) igemm_tile_mma<GG, 2, TG, NCJ, KC, WROW, PS>(img, sw, ab, lk, lr, ac); break;
-              case 3: if constexpr (TG >= 3) igemm_tile_mma<GG, 3, TG, NCJ, KC, WROW, PS>(img, sw, ab, lk, lr, ac); break;
-              default: if constexpr (TG >= 4) igemm_tile_mma<GG, 4, TG, NCJ, KC, WROW, PS>(img, sw, ab, lk, lr, ac); break;
+              case 1: igemm_tile_mma<GG, 1, TG, NCJ, KC, WROW, PS, KBM>(img, sw, ab, lk, lr, ac); break;
+              case 2: if constexpr (TG >= 2) igemm_tile_mma<GG, 2, TG, NCJ, KC, WROW, PS, KBM>(img, sw, ab, lk, lr, ac); break;
+              case 3: if constexpr (TG >= 3) igemm_tile_mma<GG, 3, TG, NCJ, KC, WROW, PS, KBM>(img, sw, ab, lk, lr, ac); break;
+              default: if constexpr (TG >= 4) igemm_tile_mma<GG, 4, TG, NCJ, KC, WROW, PS, KBM>(img, sw, ab, lk, lr, ac); break;
             }
           };
           run(std::common_type<G>{}, swc + jc * NCJ * 16, abase, acc);
@@ -357,10 +395,15 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
               for (int cc = 0; cc < NCJ; ++cc)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                  if constexpr (PAIR)   // even column from the px = 1 class, the odd one next to it from px = 0
-                    *reinterpret_cast<float2*>(yp + (size_t)(cc * 16 + r) * (OH * OH)) = float2{acc1[g][cc][r] + bv[cc][r], acc[g][cc][r] + bv[cc][r]};
-                  else
-                    yp[(size_t)(cc * 16 + r) * (OH * OH)] = acc[g][cc][r] + bv[cc][r];
+                  const float v0 = acc[g][cc][r] + bv[cc][r];
+                  if constexpr (PAIR) { // even column from the px = 1 class, the odd one next to it from px = 0
+                    const float v1 = acc1[g][cc][r] + bv[cc][r];
+                    *reinterpret_cast<float2*>(yp + (size_t)(cc * 16 + r) * (OH * OH)) = float2{v1, v0};
+                    if (STATS) { const float d = v1 - kshift[cc][r]; bs[cc][r] += d; bq[cc][r] = fmaf(d, d, bq[cc][r]); }
+                  } else {
+                    yp[(size_t)(cc * 16 + r) * (OH * OH)] = v0;
+                  }
+                  if (STATS) { const float d = v0 - kshift[cc][r]; bs[cc][r] += d; bq[cc][r] = fmaf(d, d, bq[cc][r]); }
                 }
             }
           }
@@ -368,7 +411,33 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
         }
       });
     };
-    if constexpr (!DB) {
+    if constexpr (PC) {
+      const bool producer = wave >= 8;
+      int cur = 0;
+      if (producer) {
+        __builtin_amdgcn_s_setprio(3);               // the youngest wavefront of its SIMD: let it issue whenever it can
+        if (gfirst < ngroups) prefetch(gfirst);
+      }
+      __syncthreads();                               // zero fill, slabs, table
+      if (producer) {
+        if (gfirst < ngroups) scatter(s_img, min(IPB, B - gfirst * IPB));
+        if (gfirst + gstride < ngroups) prefetch(gfirst + gstride);
+      }
+      __syncthreads();
+      for (int grp = gfirst; grp < ngroups; grp += gstride) {
+        const int b0 = grp * IPB, nxt = grp + gstride;
+        if (producer) {
+          if (nxt < ngroups) {
+            scatter(s_img + (cur ^ 1) * (IPB * IMG), min(IPB, B - nxt * IPB));
+            if (nxt + gstride < ngroups) prefetch(nxt + gstride);
+          }
+        } else {
+          jobs(s_img + cur * (IPB * IMG), b0, min(IPB, B - b0));
+        }
+        __syncthreads();                             // next buffer complete; this one free for the group after next
+        cur ^= 1;
+      }
+    } else if constexpr (!DB) {
       if (gfirst < ngroups) prefetch(gfirst);
       for (int grp = gfirst; grp < ngroups; grp += gstride) {
         const int b0 = grp * IPB;
@@ -415,6 +484,31 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
         cur ^= 1;
       }
     }
+    if constexpr (STATS) {
+      // the pass's sums: over the 16 lanes of a row (one pixel each), then over the wavefronts through the (now idle) slab region
+      __syncthreads();
+      float* red = s_w;                              // [NW][NCS][2]
+#pragma unroll
+      for (int cc = 0; cc < NCJ; ++cc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = row_allreduce16(bs[cc][r]), b = row_allreduce16(bq[cc][r]);
+          if (lr == 0 && wave < NW) {
+            red[(wave * NCS + cc * 16 + 4 * lk + r) * 2] = a;
+            red[(wave * NCS + cc * 16 + 4 * lk + r) * 2 + 1] = b;
+          }
+        }
+      __syncthreads();
+      if (tid < 2 * NCS) {
+        float t = 0.f;
+        for (int wv = 0; wv < NW; ++wv) t += red[wv * NCS * 2 + tid];
+        s_sm[2 * n0 + tid] = t;
+      }
+    }
+  }
+  if constexpr (STATS) {
+    __syncthreads();
+    bn_sink_publish<NC, NTHR>(sink, s_sm);
   }
   PROBE_ADD(5, pt_all);
 }
@@ -654,8 +748,9 @@ static __global__ __launch_bounds__(1024) void k_sum_splits4(const float* __rest
   }
 }
 
-template <class PL, int IPB, bool DB = false> constexpr size_t igemm_lds_bytes() {   // planes + weight slabs (+ the input-transform table when it does not fit the plane tails)
-  return sizeof(float) * ((size_t)(DB ? 2 : 1) * IPB * PL::KC * PL::PS + (size_t)PL::WSLAB + (igemm_tf_in_pad<PL>() ? 0 : (size_t)4 * PL::KC));
+template <class PL, int IPB, bool DB = false, bool STATS = false> constexpr size_t igemm_lds_bytes() {   // planes + weight slabs (+ the input-transform table when it does not fit the plane tails) (+ the output-statistics sums)
+  return sizeof(float) * ((size_t)(DB ? 2 : 1) * IPB * PL::KC * PL::PS + (size_t)PL::WSLAB + (igemm_tf_in_pad<PL>() ? 0 : (size_t)4 * PL::KC) +
+                          (STATS ? (size_t)2 * PL::NC : 0));
 }
 
 }  // namespace gp

@@ -110,6 +110,11 @@ int cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, int nd, const fl
 // conv VAE blocks (vae_conv.hip)
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S,
                int P, int Ho, int Wo, hipStream_t st);
+size_t convT_fwd_stats_scratch(int Co_out);
+int convT_fwd_stats(const float* x, const float* x_bn, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K,
+                    int S, int P, int Ho, int Wo, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
+                    float* running_mean, float* running_var, long long* nbt, float momentum, float eps, float* table, float* scratch,
+                    int slot, hipStream_t st);
 int conv2d_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co, int K, int S,
                     int P, int Ho, int Wo, const float* gy_bn, hipStream_t st);
 size_t conv_wgrad_scratch(int B, int Ci, int Co, int K);

@@ -157,8 +157,7 @@ __global__ __launch_bounds__(256) void k_noise_fill(float* __restrict__ out, lon
       if (e0 + k < e1) out[e0 + k] = v[k];
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
+  if (threadIdx.x == 0) {                            // only the counter passes between workgroups: a device-scope atomic, no fence
     const unsigned long long ticket = atomicAdd(&state[1], 1ull);
     if (ticket == (unsigned long long)gridDim.x - 1) {
       state[1] = 0;

@@ -14,6 +14,7 @@
 // FLOP-dominant layers (decnn.4, decnn.7) is the next optimisation step.
 #include <hip/hip_runtime.h>
 #include "gp_launch.hpp"
+#include "bn_sink.hpp"
 #include "wave_reduce.hpp"
 
 namespace gp {
@@ -340,7 +341,7 @@ static inline int ew_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g
 int tiled_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S, int P,
               int Ho, int Wo, hipStream_t st);
 int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co, int K, int S,
-                   int P, int Ho, int Wo, const float* in_bn, hipStream_t st);
+                   int P, int Ho, int Wo, const float* in_bn, hipStream_t st, const BnSink* sink);
 int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch, int B, int Ci, int H, int W, int Co, int K, int S,
                      int P, int Ho, int Wo, const float* in_bn, hipStream_t st);
 
@@ -357,9 +358,31 @@ int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int 
 
 // gy_bn (optional, [Co][4] = mean, invstd, gamma, beta): gy is the raw output of the previous layer and the BatchNorm + ReLU
 // between the two layers is applied on the fly (matrix-core specialisations only)
+// ConvTranspose2d forward that also produces the training-mode BatchNorm statistics of its output (bn_sink.hpp): matrix-core
+// specialisations only.  scratch: convT_fwd_stats_scratch() floats; slot: which of the library's ticket counters this layer uses
+// (launches that may run concurrently need different slots).
+__device__ unsigned g_bn_sink_tickets[64];
+size_t convT_fwd_stats_scratch(int Co_out) { return (size_t)512 * Co_out * 2; }
+int convT_fwd_stats(const float* x, const float* x_bn, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K,
+                    int S, int P, int Ho, int Wo, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
+                    float* running_mean, float* running_var, long long* nbt, float momentum, float eps, float* table, float* scratch,
+                    int slot, hipStream_t st) {
+  static unsigned* tickets = nullptr;
+  if (!tickets) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_bn_sink_tickets)) != hipSuccess) return set_error("gpode_convT_fwd_stats: no ticket storage");
+    tickets = static_cast<unsigned*>(p);
+  }
+  if (slot < 0 || slot >= 64) return set_error("gpode_convT_fwd_stats: slot 0 .. 63");
+  BnSink sink{scratch, tickets + slot, gamma, beta, save_mean, save_invstd, running_mean, running_var, nbt, table, momentum, eps,
+              (float)B * (float)(H * W)};
+  const int r = tiled_bwd_data(x, w, bias, y, B, Ci, H, W, Co, K, S, P, Ho, Wo, x_bn, st, &sink);
+  return r < 0 ? set_error("gpode_convT_fwd_stats: no specialisation for this geometry") : r;
+}
+
 int conv2d_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co, int K, int S,
                     int P, int Ho, int Wo, const float* gy_bn, hipStream_t st) {
-  { const int r = tiled_bwd_data(gy, w, bias, gx, B, Ci, H, W, Co, K, S, P, Ho, Wo, gy_bn, st); if (r >= 0) return r; }
+  { const int r = tiled_bwd_data(gy, w, bias, gx, B, Ci, H, W, Co, K, S, P, Ho, Wo, gy_bn, st, nullptr); if (r >= 0) return r; }
   if (gy_bn) return set_error("gpode_conv2d_bwd_data_bn: no matrix-core specialisation for this geometry");
   ConvDims d{B, Ci, H, W, Co, P, Ho, Wo};
   const size_t total = (size_t)B * Ci * H * W;
@@ -818,9 +841,10 @@ __global__ void k_adam_multi(float* const* __restrict__ params, const float* con
   if (step_dev) {
     // every workgroup has read step_dev[0] before it takes a ticket, so the last one may advance it (no separate launch for the
     // counter: one graph node less on the tail of every step)
+    // (no memory fence: nothing but the counter is handed between workgroups, and the ticket is a device-scope atomic; a
+    // __threadfence() here writes the L2 back -- measured 15 us on this 22 us kernel)
     __syncthreads();
     if (threadIdx.x == 0) {
-      __threadfence();
       if (atomicAdd(&step_dev[1], 1) == (int)gridDim.x - 1) {
         step_dev[1] = 0;
         step_dev[0] = step;
@@ -850,9 +874,9 @@ int adam_multi(float* const* params, const float* const* grads, float* const* m1
                int ntensors, long long total, float lr, float beta1, float beta2, float eps, int step, int* step_dev, hipStream_t st) {
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   // with the device-side count every workgroup takes a ticket on ONE address (the last one publishes the count): keep them few --
-  // 550 tickets of the 140k-parameter model serialised into 16 us at the L2, 64 workgroups of grid-stride loops take 1-2 us
+  // at most 128 workgroups of grid-stride loops
   unsigned grid = ew_grid((size_t)total);
-  if (step_dev && grid > 64) grid = 64;
+  if (step_dev && grid > 128) grid = 128;
   hipLaunchKernelGGL(k_adam_multi, grid, 256, 0, st, params, grads, m1, m2, offs, ntensors, total, lr, beta1, beta2, eps, bc1, bc2,
                      step_dev);
   return check_launch("adam_multi");

@@ -370,22 +370,32 @@ static bool use_mfma() {
 // matrix-core path (conv_mfma.hpp): persistent grid of one 512-thread workgroup per CU
 // NTHR = 256 with a footprint <= 80 KB: TWO independent 4-wavefront workgroups per CU, whose scatter / store phases interleave
 // with each other's MFMA phases instead of idling the matrix pipe in lockstep
-template <class PL, int IPB, int TG, int NCJ, bool PAIR = false, int NTHR = 512, bool DB = false>
+// workgroups a BnSink's partial sums must have room for (every statistics-producing launch below stays within it)
+constexpr int kSinkMaxWg = 512;
+
+template <class PL, int IPB, int TG, int NCJ, bool PAIR = false, int NTHR = 512, bool DB = false, bool PC = false, bool STATS = false>
 static int launch_igemm(const float* x, const float* w, const float* bias, float* y, int B, hipStream_t st, const char* what,
-                        const float* in_bn = nullptr) {
-  constexpr size_t lds = igemm_lds_bytes<PL, IPB, DB>();
-  static_assert(lds <= (NTHR == 512 ? 160 : 80) * 1024, "LDS budget");
-  auto km = k_conv_igemm<PL, IPB, TG, NCJ, PAIR, NTHR, DB>;
+                        const float* in_bn = nullptr, const BnSink* sink = nullptr) {
+  constexpr size_t lds = igemm_lds_bytes<PL, IPB, DB, STATS>();
+  static_assert(lds <= (NTHR >= 512 ? 160 : 80) * 1024, "LDS budget");
+  auto km = k_conv_igemm<PL, IPB, TG, NCJ, PAIR, NTHR, DB, PC, STATS>;
   if (set_max_lds((const void*)km, lds)) return 1;
   const int ngroups = (B + IPB - 1) / IPB;
-  const int cap = num_cus() * (512 / NTHR);
-  hipLaunchKernelGGL(km, ngroups < cap ? ngroups : cap, NTHR, lds, st, x, w, bias, y, B, in_bn);
+  const int cap = num_cus() * (NTHR >= 512 ? 1 : 2);
+  if (STATS && cap > kSinkMaxWg) return set_error("%s: more workgroups than the statistics scratch holds", what);
+  hipLaunchKernelGGL(km, ngroups < cap ? ngroups : cap, NTHR, lds, st, x, w, bias, y, B, in_bn, STATS ? *sink : BnSink{});
   return check_launch(what);
+}
+
+static bool conv_pc_enabled() {     // A/B only (GPODE_CONV_PC=1): see launch_T1
+  static const bool on = [] { const char* e = getenv("GPODE_CONV_PC"); return e && e[0] == '1'; }();
+  return on;
 }
 
 // IPB: images per workgroup of the VALU kernel; IPBM / COS: images per group and output channels per pass of the MFMA kernel
 template <class L, int IPB, int IPBM, int COS>
-static int launch_T1(const float* x, const float* w, const float* bias, float* y, int B, hipStream_t st, const float* in_bn) {
+static int launch_T1(const float* x, const float* w, const float* bias, float* y, int B, hipStream_t st, const float* in_bn,
+                     const BnSink* sink = nullptr) {
   constexpr int MAXTAPS = ((L::K + L::S - 1) / L::S) * ((L::K + L::S - 1) / L::S);
   const size_t lds = sizeof(float) * ((size_t)IPB * L::CI * L::HP * L::HP + (size_t)MAXTAPS * L::CI * L::CO);
   if (use_mfma() && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
@@ -399,9 +409,18 @@ static int launch_T1(const float* x, const float* w, const float* bias, float* y
       // the kernel to begin with -- the idle matrix-pipe cycles are not in the phases the second buffer overlaps.
       static const bool db = [] { const char* e = getenv("GPODE_DEC7_FWD_DB"); return e && e[0] == '1'; }();
       if (db) return launch_igemm<FwdPolicy<L, COS>, 1, TG, COS / 16, PAIR, 512, true>(x, w, bias, y, B, st, "convT_fwd_mfma", in_bn);
+      // GPODE_CONV_PC=1 (A/B only): producer / consumer wavefronts (conv_mfma.hpp, PC) -- one image per buffer, 8 multiplying + 4
+      // fetching wavefronts, one barrier per image.  Measured SLOWER as a port of this engine's job loop (4096 images: 0.274 vs
+      // 0.241 ms): three wavefronts per SIMD leave 168 registers, which the tile-group loop (16 copies of the k loop after the
+      // compiler's unswitching) only fits with one pixel tile per job -- two LDS operand reads per MFMA and conditional prefetches.
+      // The weight-gradient engine (conv_wgrad_v2.hpp) got its gain from a loop written FOR that budget; this one would need the same.
+      if (conv_pc_enabled() && B > 2 * num_cus() && !sink)
+        return launch_igemm<FwdPolicy<L, COS>, 1, 1, COS / 16, PAIR, 768, true, true>(x, w, bias, y, B, st, "convT_fwd_mfma_pc", in_bn);
     }
+    if (sink) return launch_igemm<FwdPolicy<L, COS>, IPBM, TG, COS / 16, PAIR, 512, false, false, true>(x, w, bias, y, B, st, "convT_fwd_mfma_stats", in_bn, sink);
     return launch_igemm<FwdPolicy<L, COS>, IPBM, TG, COS / 16, PAIR>(x, w, bias, y, B, st, "convT_fwd_mfma", in_bn);
   }
+  if (sink) return set_error("convT forward with output statistics needs the matrix-core path (16-byte aligned input, GPODE_CONV_VALU unset)");
   if (in_bn) return set_error("convT forward with a fused BatchNorm input needs the matrix-core path (16-byte aligned input, GPODE_CONV_VALU unset)");
   auto kern = k_convT_fwd<L, IPB>;
   if (set_max_lds((const void*)kern, lds)) return 1;
@@ -475,30 +494,38 @@ static int launch_T3(const float* x, const float* gy, float* gw, float* scratch,
 
 // ConvTranspose2d forward (called with the conv geometry of its adjoint, as conv2d_bwd_data is)
 int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx, int B, int Ci, int H, int W, int Co, int K, int S,
-                   int P, int Ho, int Wo, const float* in_bn, hipStream_t st) {
+                   int P, int Ho, int Wo, const float* in_bn, hipStream_t st, const BnSink* sink) {
   if (H != W || Ho != Wo) return -1;
-  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec7, 3, 2, 16>(gy, w, bias, gx, B, st, in_bn);
+  if (sink && !(use_mfma() && (matches<Dec7>(Ci, Co, H, Ho, K, S, P) || matches<Dec4>(Ci, Co, H, Ho, K, S, P) ||
+                               (matches<Dec1>(Ci, Co, H, Ho, K, S, P) && !in_bn))))
+    return set_error("gpode_convT_fwd_stats: no specialisation for this geometry");
+  if (matches<Dec7>(Ci, Co, H, Ho, K, S, P)) return launch_T1<Dec7, 3, 2, 16>(gy, w, bias, gx, B, st, in_bn, sink);
   if (matches<Dec4>(Ci, Co, H, Ho, K, S, P)) {
     // taps-as-columns form (conv_dec4_mfma.hpp): 48.5 vs 59.7 us for the stage at 512 images (no weight slabs to stage before the first
     // image), 276 vs 267 us at 4096 -- so it takes the small batches (configs[0]: 512 images); GPODE_DEC4_TAPCOLS=0 / 1 forces one
     static const int tapcols = [] { const char* e = getenv("GPODE_DEC4_TAPCOLS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     if ((tapcols == 1 || (tapcols < 0 && B <= 4 * num_cus())) && use_mfma()) {
-      const size_t lds = sizeof(float) * (dec4::NPI * dec4::TLD + 4 * dec4::CI);
-      if (set_max_lds((const void*)dec4::k_fwd<true>, lds) || set_max_lds((const void*)dec4::k_fwd<false>, lds)) return 1;
+      const size_t lds = sizeof(float) * (dec4::NPI * dec4::TLD + 4 * dec4::CI + (sink ? 2 * dec4::CO * dec4::NPO : 0));
+      if (set_max_lds((const void*)dec4::k_fwd<true>, lds) || set_max_lds((const void*)dec4::k_fwd<false>, lds) ||
+          set_max_lds((const void*)dec4::k_fwd<true, true>, lds) || set_max_lds((const void*)dec4::k_fwd<false, true>, lds)) return 1;
       const int nwg = B < num_cus() ? B : num_cus();
-      if (in_bn) hipLaunchKernelGGL(dec4::k_fwd<true>, nwg, 512, lds, st, gy, w, bias, gx, B, in_bn);
-      else hipLaunchKernelGGL(dec4::k_fwd<false>, nwg, 512, lds, st, gy, w, bias, gx, B, in_bn);
+      const BnSink sk = sink ? *sink : BnSink{};
+      if (sink && in_bn) hipLaunchKernelGGL((dec4::k_fwd<true, true>), nwg, 512, lds, st, gy, w, bias, gx, B, in_bn, sk);
+      else if (sink) hipLaunchKernelGGL((dec4::k_fwd<false, true>), nwg, 512, lds, st, gy, w, bias, gx, B, in_bn, sk);
+      else if (in_bn) hipLaunchKernelGGL((dec4::k_fwd<true>), nwg, 512, lds, st, gy, w, bias, gx, B, in_bn, sk);
+      else hipLaunchKernelGGL((dec4::k_fwd<false>), nwg, 512, lds, st, gy, w, bias, gx, B, in_bn, sk);
       return check_launch("dec4_fwd_tapcols");
     }
-    return launch_T1<Dec4, 3, 2, 16>(gy, w, bias, gx, B, st, in_bn);
+    return launch_T1<Dec4, 3, 2, 16>(gy, w, bias, gx, B, st, in_bn, sink);
   }
   if (matches<Dec1>(Ci, Co, H, Ho, K, S, P)) {
     static const bool old = [] { const char* e = getenv("GPODE_DEC1_ENGINE"); return e && e[0] == '1'; }();
-    if (!in_bn && use_mfma() && !old) {              // taps folded into the GEMM's columns, weights resident in registers
+    if (!in_bn && use_mfma() && (!old || sink)) {    // taps folded into the GEMM's columns, weights resident in registers
       const size_t lds = sizeof(float) * 2 * dec1::NPI * dec1::TLD;
-      if (set_max_lds((const void*)dec1::k_fwd, lds)) return 1;
+      if (set_max_lds((const void*)dec1::k_fwd<false>, lds) || set_max_lds((const void*)dec1::k_fwd<true>, lds)) return 1;
       const int cap = 2 * num_cus();                 // 74 KB of LDS per workgroup
-      hipLaunchKernelGGL(dec1::k_fwd, B < cap ? B : cap, 256, lds, st, gy, w, bias, gx, B);
+      if (sink) hipLaunchKernelGGL(dec1::k_fwd<true>, B < cap ? B : cap, 256, lds, st, gy, w, bias, gx, B, *sink);
+      else hipLaunchKernelGGL(dec1::k_fwd<false>, B < cap ? B : cap, 256, lds, st, gy, w, bias, gx, B, BnSink{});
       return check_launch("dec1_fwd_mfma");
     }
     return launch_T1<Dec1, 8, 8, 64>(gy, w, bias, gx, B, st, in_bn);

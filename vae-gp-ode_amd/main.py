@@ -235,8 +235,6 @@ def main(argv=None):
     meters = {k: RunningAverage(10) for k in ('elbo', 'nll', 'reg_kl', 'inducing_kl')}
     bn_sync = None
     optimizer = HipAdam(model.parameters(), lr=args.lr, bucketed='gather' if dist is not None else False)
-    from . import vae_ops as _vae_ops
-    _vae_ops.set_deferred_reductions(optimizer.allows_deferred_reductions)   # one launch for all final reductions of a backward pass
     sync = None
     if dist is not None:
         from .parallel import GradAllReduce, shard_batch

@@ -57,8 +57,6 @@ def vae_train(args, images, epochs, output_model_path, log=print):
     vae = VAE(device=args.device, latent_dim=args.latent_dim).to(args.device)
     vae.print_summary()
     opt = HipAdam(list(vae.encoder.parameters()) + list(vae.decoder.parameters()), lr=args.lr, bucketed=False)
-    from . import vae_ops as _vae_ops
-    _vae_ops.set_deferred_reductions(opt.allows_deferred_reductions)
     loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(images), batch_size=args.batch, shuffle=True)
     meters = {k: RunningAverage(10) for k in ('elbo', 'nll', 'reg_kl')}
     begin = time.time()

@@ -119,9 +119,10 @@ class Decoder(nn.Module):
         if self.training and all(d[i].training for i in (2, 5, 8)):
             # training mode: each BatchNorm + ReLU is folded into the input staging of the transposed convolution that
             # consumes it -- the normalised activations (332 MB per step at the benchmark size) never go through HBM
-            c = V.conv_transpose2d(h, d[1].weight, d[1].bias, 1, 0)                                   # 4 -> 6
-            c = V.bn_relu_conv_transpose2d(c, d[2], d[4].weight, d[4].bias, 2, 1)                     # 6 -> 13
-            c = V.bn_relu_conv_transpose2d(c, d[5], d[7].weight, d[7].bias, 2, 1, 1)                  # 13 -> 28
+            # (stats_for: the statistics of each output are summed by the convolution that stores it, for the BatchNorm behind it)
+            c = V.conv_transpose2d(h, d[1].weight, d[1].bias, 1, 0, stats_for=d[2])                   # 4 -> 6
+            c = V.bn_relu_conv_transpose2d(c, d[2], d[4].weight, d[4].bias, 2, 1, stats_for=d[5])     # 6 -> 13
+            c = V.bn_relu_conv_transpose2d(c, d[5], d[7].weight, d[7].bias, 2, 1, 1, stats_for=d[8])  # 13 -> 28
             return out(V.bn_relu_conv_transpose2d(c, d[8], d[10].weight, d[10].bias, 1, 2))
         h = _bn(V.conv_transpose2d(h, d[1].weight, d[1].bias, 1, 0), d[2], relu=True)     # 4 -> 6
         h = _bn(V.conv_transpose2d(h, d[4].weight, d[4].bias, 2, 1), d[5], relu=True)     # 6 -> 13

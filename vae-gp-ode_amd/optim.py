@@ -41,6 +41,8 @@ class HipAdam:
         # pass has ended: the backward kernels' final reductions of workgroup partials may then all run in ONE launch at the end of
         # the pass (vae_ops.set_deferred_reductions).  With persistent views autograd adds every gradient as it arrives -- too early.
         self.allows_deferred_reductions = not self.bucketed
+        from . import vae_ops
+        vae_ops.set_deferred_reductions(self.allows_deferred_reductions)   # the optimiser in charge decides (process-wide switch)
         self._zero = {}
         offs, tot = [], 0
         for p in self.params:

@@ -32,8 +32,8 @@ def _bn_scratch(B, C, like):
 # chain).  Sound only when nothing reads those tensors earlier, and autograd does read in two cases: it CLONES an incoming
 # gradient that has a second owner, and it ADDS to ``p.grad`` when that exists.  Hence: on only with an optimiser that drops the
 # gradients in zero_grad and takes over the tensors autograd hands it (optim.HipAdam(bucketed=False | 'gather'):
-# ``allows_deferred_reductions``) -- the training loops of this package (main.py, main_vae.py, bench.py) switch it on there; the
-# default is off.  configs[0]: 14 reduction launches -> 1.
+# ``allows_deferred_reductions``): creating a HipAdam sets the switch for its kind (the optimiser in charge of the step decides);
+# the default, and the setting for any other consumer of ``.grad``, is off.  configs[0]: 14 reduction launches -> 1.
 _deferred = {'on': False, 'keep': [], 'queued': False}
 _DEFER_ALLOWED = os.environ.get('GPODE_EAGER_REDUCTIONS', '0') != '1'
 
@@ -258,18 +258,59 @@ class _Conv2d(torch.autograd.Function):
         return gx, gw, gb, None, None
 
 
+# ---- BatchNorm statistics produced by the convolution in front of it (include/gpode.h: gpode_convT_fwd_stats) ----------------------
+# The decoder's transposed convolutions decnn.1/4/7 are each followed by a BatchNorm2d in training mode (vae.py:107-120).  When the
+# caller names that module (``stats_for``), the convolution sums the statistics of its output while storing it and its last workgroup
+# finalises them: the output tensor then carries (mean, invstd, table) as ``_gpode_bnstats`` and the consuming _BnReluConvT takes them
+# instead of launching the statistics pass + table kernel (two graph nodes and one read of the tensor per layer).
+_STATS_GEOMS = {(32, 64, 3, 1, 0, 4), (64, 32, 5, 2, 1, 6), (32, 16, 5, 2, 1, 13)}      # (Cin, Cout, K, stride, pad, Hi) of decnn.1/4/7
+_fused_stats = os.environ.get('GPODE_BN_STATS_PASS', '0') != '1'
+_FUSED_STATS_MIN_IMAGES = int(os.environ.get('GPODE_BN_STATS_FUSED_MIN', '1024'))
+_slots = {'next': 0}
+
+
+def _stats_slot(bn):
+    s = getattr(bn, '_gpode_slot', None)
+    if s is None:
+        s = bn._gpode_slot = _slots['next'] % 64
+        _slots['next'] += 1
+    return s
+
+
+def _can_fuse_stats(bn, x, Cin, Cout, K, stride, pad, Hi):
+    # from 1024 images on: below that the statistics pass is a few microseconds and the per-workgroup hand-over at the end of the
+    # convolution costs as much (configs[0], 512 images: 0.754 vs 0.745 ms per step fused vs separate; configs[1], 4096: 2.751 vs 2.767)
+    return (_fused_stats and bn is not None and bn.training and _bn_sync is None and (Cin, Cout, K, stride, pad, Hi) in _STATS_GEOMS
+            and x.shape[0] >= _FUSED_STATS_MIN_IMAGES and x.data_ptr() % 16 == 0 and os.environ.get('GPODE_CONV_VALU', '0') != '1')
+
+
+def _convT_fwd_stats(x, table_in, w, b, y, geom, bn):
+    """y = convT(x [after BatchNorm + ReLU by table_in], w) + b and the statistics of y for the BatchNorm module ``bn`` behind it."""
+    B, Cout, Ht, Wt, Cin, K, stride, pad, Hi, Wi = geom
+    mean, invstd, table = _new((Cout,), x), _new((Cout,), x), _new((Cout, 4), x)
+    scratch = _scratch(_lib.load().gpode_convT_fwd_stats_scratch(Cout), x)
+    _lib.call('gpode_convT_fwd_stats', _ptr(x), _ptr(table_in), _ptr(w), _ptr(b), _ptr(y), B, Cout, Ht, Wt, Cin, K, stride, pad, Hi, Wi,
+              _ptr(_chk(bn.weight, 'gamma')), _ptr(_chk(bn.bias, 'beta')), _ptr(mean), _ptr(invstd), _ptr(bn.running_mean),
+              _ptr(bn.running_var), _ptr(bn.num_batches_tracked), ctypes.c_float(bn.momentum), ctypes.c_float(bn.eps), _ptr(table),
+              _ptr(scratch), _stats_slot(bn), _stream())
+    y._gpode_bnstats = (bn, mean, invstd, table)
+
+
 class _ConvT2d(torch.autograd.Function):
     """nn.ConvTranspose2d as the adjoint of the convolution that shares its weight buffer."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, out_pad):
+    def forward(ctx, x, w, b, stride, pad, out_pad, stats_for=None):
         x, w = _chk(x, 'x'), _chk(w, 'weight')
         B, Cin, Hi, Wi = x.shape
         _, Cout, K, _ = w.shape
         Ht, Wt = (Hi - 1) * stride - 2 * pad + K + out_pad, (Wi - 1) * stride - 2 * pad + K + out_pad
         y = _new((B, Cout, Ht, Wt), x)
         # conv geometry: "input" (B,Ci=Cout,H=Ht,W=Wt), "output" (B,Co=Cin,Ho=Hi,Wo=Wi)
-        _lib.call('gpode_conv2d_bwd_data', _ptr(x), _ptr(w), _ptr(b), _ptr(y), B, Cout, Ht, Wt, Cin, K, stride, pad, Hi, Wi, _stream())
+        if _can_fuse_stats(stats_for, x, Cin, Cout, K, stride, pad, Hi):
+            _convT_fwd_stats(x, None, w, b, y, (B, Cout, Ht, Wt, Cin, K, stride, pad, Hi, Wi), stats_for)
+        else:
+            _lib.call('gpode_conv2d_bwd_data', _ptr(x), _ptr(w), _ptr(b), _ptr(y), B, Cout, Ht, Wt, Cin, K, stride, pad, Hi, Wi, _stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (B, Cout, Ht, Wt, Cin, K, stride, pad, Hi, Wi, b is not None)
         return y
@@ -293,7 +334,7 @@ class _ConvT2d(torch.autograd.Function):
                 if gb is None:
                     gb, bs = _new((Cout,), x), _bn_scratch(B, Cout, x)
                     _bwd_call('gpode_chan_sum', _ptr(gy), _ptr(gb), B, Cout, Ht * Wt, _ptr(bs), _stream(), keep=(bs,))
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 class _BnReluConvT(torch.autograd.Function):
@@ -303,13 +344,16 @@ class _BnReluConvT(torch.autograd.Function):
     BatchNorm backward on c.  Training mode only; the eval-mode path keeps the separate ops."""
 
     @staticmethod
-    def forward(ctx, c, gamma, beta, running_mean, running_var, nbt, momentum, eps, w, b, stride, pad, out_pad):
+    def forward(ctx, c, gamma, beta, running_mean, running_var, nbt, momentum, eps, w, b, stride, pad, out_pad, bn=None, stats_for=None):
+        pre = getattr(c, '_gpode_bnstats', None)     # the convolution that produced c summed its statistics for module ``bn`` already
         c, w = _chk(c, 'c'), _chk(w, 'weight')
         B, Cin, Hi, Wi = c.shape
         _, Cout, K, _ = w.shape
         Ht, Wt = (Hi - 1) * stride - 2 * pad + K + out_pad, (Wi - 1) * stride - 2 * pad + K + out_pad
         ctx.sync = _bn_sync
-        if _bn_sync is not None:
+        if pre is not None and pre[0] is bn and bn is not None and _bn_sync is None:
+            _, mean, invstd, table = pre
+        elif _bn_sync is not None:
             mean, invstd, table = _bn_global_stats(c, gamma, beta, running_mean, running_var, nbt, momentum, eps, _bn_scratch(B, Cin, c))
         else:
             mean, invstd, table = _new((Cin,), c), _new((Cin,), c), _new((Cin, 4), c)
@@ -317,8 +361,11 @@ class _BnReluConvT(torch.autograd.Function):
                       _ptr(running_mean), _ptr(running_var), _ptr(nbt), ctypes.c_float(momentum), ctypes.c_float(eps), _ptr(table),
                       B, Cin, Hi * Wi, _ptr(_bn_scratch(B, Cin, c)), _stream())
         y = _new((B, Cout, Ht, Wt), c)
-        _lib.call('gpode_conv2d_bwd_data_bn', _ptr(c), _ptr(table), _ptr(w), _ptr(b), _ptr(y), B, Cout, Ht, Wt, Cin, K, stride, pad, Hi, Wi,
-                  _stream())
+        if _can_fuse_stats(stats_for, c, Cin, Cout, K, stride, pad, Hi):
+            _convT_fwd_stats(c, table, w, b, y, (B, Cout, Ht, Wt, Cin, K, stride, pad, Hi, Wi), stats_for)
+        else:
+            _lib.call('gpode_conv2d_bwd_data_bn', _ptr(c), _ptr(table), _ptr(w), _ptr(b), _ptr(y), B, Cout, Ht, Wt, Cin, K, stride, pad, Hi, Wi,
+                      _stream())
         ctx.save_for_backward(c, gamma, beta, mean, invstd, table, w)
         ctx.geom = (B, Cout, Ht, Wt, Cin, K, stride, pad, Hi, Wi, b is not None)
         return y
@@ -343,7 +390,7 @@ class _BnReluConvT(torch.autograd.Function):
             # the decoder's last stage: the gradient w.r.t. the normalised activation is recomputed inside both BatchNorm passes
             gc, gg, gbeta, cs = _dec10_bn_bwd(ctx.sync, c, gy, w, gamma, beta, mean, invstd)
             gc._gpode_chansum = cs
-            return gc, gg, gbeta, None, None, None, None, None, gw, gb, None, None, None
+            return gc, gg, gbeta, None, None, None, None, None, gw, gb, None, None, None, None, None
         # gradient w.r.t. the (never materialised) normalised activation, then through the BatchNorm to c
         ga = _new(c.shape, c)
         _lib.call('gpode_conv2d_fwd', _ptr(gy), _ptr(w), _ptr(None), _ptr(ga), B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, _stream())
@@ -355,7 +402,7 @@ class _BnReluConvT(torch.autograd.Function):
             _bwd_call('gpode_bn_bwd', _ptr(c), _ptr(ga), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(gc), _ptr(gg), _ptr(gbeta),
                       _ptr(cs), B, Cin, Hi * Wi, 1, _ptr(bs), _stream(), keep=(bs,))
         gc._gpode_chansum = cs
-        return gc, gg, gbeta, None, None, None, None, None, gw, gb, None, None, None
+        return gc, gg, gbeta, None, None, None, None, None, gw, gb, None, None, None, None, None
 
 
 class _BatchNormTrain(torch.autograd.Function):
@@ -678,8 +725,9 @@ def conv2d(x, w, b, stride, pad):
     return _Conv2d.apply(x, w, b, stride, pad)
 
 
-def conv_transpose2d(x, w, b, stride, pad, out_pad=0):
-    return _ConvT2d.apply(x, w, b, stride, pad, out_pad)
+def conv_transpose2d(x, w, b, stride, pad, out_pad=0, stats_for=None):
+    """``stats_for``: the nn.BatchNorm2d (training mode) that follows -- its batch statistics are then summed by this convolution."""
+    return _ConvT2d.apply(x, w, b, stride, pad, out_pad, stats_for)
 
 
 def batch_norm_train(x, bn, relu):
@@ -690,10 +738,11 @@ def batch_norm_train(x, bn, relu):
                                  bn.num_batches_tracked if bn.training else None)
 
 
-def bn_relu_conv_transpose2d(c, bn, w, b, stride, pad, out_pad=0):
-    """conv_transpose2d(relu(bn(c)), w, b) for a BatchNorm2d module in training mode, fused (see _BnReluConvT)."""
+def bn_relu_conv_transpose2d(c, bn, w, b, stride, pad, out_pad=0, stats_for=None):
+    """conv_transpose2d(relu(bn(c)), w, b) for a BatchNorm2d module in training mode, fused (see _BnReluConvT).  ``stats_for``: the
+    BatchNorm2d that follows THIS convolution (see conv_transpose2d)."""
     return _BnReluConvT.apply(c, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps,
-                              w, b, stride, pad, out_pad)
+                              w, b, stride, pad, out_pad, bn, stats_for)
 
 
 def batch_norm_eval(x, bn, relu):
