@@ -236,6 +236,121 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   }
 }
 
+// ---- small batches: ONE workgroup per channel walks all images twice (statistics / sums, then apply) -- a launch instead of two
+// where the tensor is a few hundred KB and each launch is a graph node of ~5 us on the step's critical chain (configs[0]) ----------
+__device__ __forceinline__ void block_sum2(float a, float b, float& sa, float& sb) {
+  __shared__ float red2[4][2];
+  const float in2[2] = {a, b};
+  float out2[2];
+  wave_sum_multi<2>(in2, out2);
+  __syncthreads();                                   // red2 may still be read from a previous call
+  if ((threadIdx.x & 63) == 0) { red2[threadIdx.x >> 6][0] = out2[0]; red2[threadIdx.x >> 6][1] = out2[1]; }
+  __syncthreads();
+  sa = (red2[0][0] + red2[1][0]) + (red2[2][0] + red2[3][0]);
+  sb = (red2[0][1] + red2[1][1]) + (red2[2][1] + red2[3][1]);
+}
+
+// y == nullptr: statistics + table only (the consumer applies the normalisation itself)
+__global__ __launch_bounds__(256) void k_bn_fwd_small(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float count, float eps, float momentum, float* __restrict__ save_mean,
+                                                       float* __restrict__ save_invstd, float* __restrict__ running_mean,
+                                                       float* __restrict__ running_var, long long* __restrict__ num_batches_tracked,
+                                                       float* __restrict__ y, float* __restrict__ table, int B, int C, int HW, int relu) {
+  const int c = blockIdx.x;
+  const float k = chan_shift(x, HW, c);
+  float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
+  chan_slab(C, HW, c, 0, B,
+            [&](size_t i) {
+              const float4 v = *reinterpret_cast<const float4*>(x + i);
+              const float a = v.x - k, b = v.y - k, d = v.z - k, e = v.w - k;
+              s0 += a; t0 += b; s0 += d; t0 += e;
+              s1 = fmaf(a, a, s1); t1 = fmaf(b, b, t1); s1 = fmaf(d, d, s1); t1 = fmaf(e, e, t1);
+            },
+            [&](size_t i) {
+              const float a = x[i] - k;
+              s0 += a;
+              s1 = fmaf(a, a, s1);
+            });
+  float sa, sb;
+  block_sum2(s0 + t0, s1 + t1, sa, sb);
+  const float d = sa / count;
+  const float m = k + d;
+  const float var = fmaxf(sb / count - d * d, 0.f);
+  const float is = rsqrtf(var + eps);
+  const float g = gamma[c], bt = beta[c];
+  if (threadIdx.x == 0) {
+    save_mean[c] = m;
+    save_invstd[c] = is;
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count / (count - 1.f));
+    }
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (table) { table[4 * c + 0] = m; table[4 * c + 1] = is; table[4 * c + 2] = g; table[4 * c + 3] = bt; }
+  }
+  if (!y) return;
+  const float lo = relu ? 0.f : -INFINITY;
+  chan_slab(C, HW, c, 0, B,
+            [&](size_t i) {
+              const float4 v = *reinterpret_cast<const float4*>(x + i);
+              float4 o;
+              o.x = fmaxf(bn_affine(v.x, m, is, g, bt), lo); o.y = fmaxf(bn_affine(v.y, m, is, g, bt), lo);
+              o.z = fmaxf(bn_affine(v.z, m, is, g, bt), lo); o.w = fmaxf(bn_affine(v.w, m, is, g, bt), lo);
+              *reinterpret_cast<float4*>(y + i) = o;
+            },
+            [&](size_t i) { y[i] = fmaxf(bn_affine(x[i], m, is, g, bt), lo); });
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_small(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, float count, float* __restrict__ ggamma,
+                                                       float* __restrict__ gbeta, float* __restrict__ gx, float* __restrict__ gx_chansum,
+                                                       int B, int C, int HW, int relu) {
+  const int c = blockIdx.x;
+  const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+  float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
+  auto acc = [&](float xv, float gv, float& a0, float& a1) {
+    const float xh = bn_xhat(xv, m, is);
+    if (relu && !(__fmaf_rn(xh, g, bt) > 0.f)) gv = 0.f;
+    a0 += gv;
+    a1 = fmaf(gv, xh, a1);
+  };
+  chan_slab(C, HW, c, 0, B,
+            [&](size_t i) {
+              const float4 v = *reinterpret_cast<const float4*>(x + i), w = *reinterpret_cast<const float4*>(gy + i);
+              acc(v.x, w.x, s0, s1); acc(v.y, w.y, t0, t1); acc(v.z, w.z, s0, s1); acc(v.w, w.w, t0, t1);
+            },
+            [&](size_t i) { acc(x[i], gy[i], s0, s1); });
+  float sa, sb;
+  block_sum2(s0 + t0, s1 + t1, sa, sb);
+  if (threadIdx.x == 0) { gbeta[c] = sa; ggamma[c] = sb; }
+  const float ic = 1.f / count, ca = sa * ic, cb = sb * ic, sc = g * is;
+  auto one = [&](float xv, float gv) {
+    const float xh = bn_xhat(xv, m, is);
+    if (relu && !(__fmaf_rn(xh, g, bt) > 0.f)) gv = 0.f;
+    return sc * (gv - ca - xh * cb);
+  };
+  float u0 = 0.f, u1 = 0.f;                          // channel sum of gx = the bias gradient of the layer that produced x
+  chan_slab(C, HW, c, 0, B,
+            [&](size_t i) {
+              const float4 v = *reinterpret_cast<const float4*>(x + i), w = *reinterpret_cast<const float4*>(gy + i);
+              float4 o;
+              o.x = one(v.x, w.x); o.y = one(v.y, w.y); o.z = one(v.z, w.z); o.w = one(v.w, w.w);
+              *reinterpret_cast<float4*>(gx + i) = o;
+              u0 += o.x; u1 += o.y; u0 += o.z; u1 += o.w;
+            },
+            [&](size_t i) {
+              const float o = one(x[i], gy[i]);
+              gx[i] = o;
+              u0 += o;
+            });
+  if (gx_chansum) {
+    float ua, ub;
+    block_sum2(u0 + u1, 0.f, ua, ub);
+    if (threadIdx.x == 0) gx_chansum[c] = ua;
+  }
+}
+
 // evaluation mode (module.eval(): the --pretrained path of main.py:157-163 freezes the VAE this way): running statistics,
 // y = relu?((x - rm) rsqrt(rv + eps) gamma + beta); backward w.r.t. x only (gx = g gamma invstd under the same mask)
 __global__ __launch_bounds__(256) void k_bn_eval(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ gamma,
@@ -365,6 +480,14 @@ inline Split pick(int B) {
   return s;
 }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// elements per channel up to which ONE workgroup per channel does the whole layer in one launch (GPODE_BN_ONE_LAUNCH=0: never)
+// (configs[0], us, one launch vs two: forward 18k elements per channel 6.0 vs 9.9, 6k 5.6 vs 9.1, 1.5k 5.3 vs 8.2, but 86k 41.8 vs 10;
+//  backward 1.5k 5.1 vs 9.9, 6k 12.7 vs 10.3, 18k 11.5 vs 11 -- a lone workgroup streams at a few GB/s)
+constexpr size_t kBnSmallFwd = 20000, kBnSmallBwd = 2048;
+inline bool bn_small(size_t per_channel, size_t limit) {
+  static const bool off = [] { const char* e = getenv("GPODE_BN_ONE_LAUNCH"); return e && e[0] == '0'; }();
+  return !off && per_channel <= limit;
+}
 
 }  // namespace
 
@@ -375,6 +498,11 @@ int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, floa
            float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, int B, int C, int HW,
            int relu, float* scratch, hipStream_t st) {
   if ((HW & 3) == 0 && !(aligned16(x) && aligned16(y))) return set_error("gpode_bn_fwd: x / y must be 16-byte aligned");
+  if (bn_small((size_t)B * HW, kBnSmallFwd)) {
+    hipLaunchKernelGGL(k_bn_fwd_small, C, 256, 0, st, x, gamma, beta, (float)B * HW, eps, momentum, save_mean, save_invstd, running_mean, running_var,
+                       num_batches_tracked, y, (float*)nullptr, B, C, HW, relu);
+    return check_launch("bn_fwd (one launch)");
+  }
   const Split sp = pick(B);
   float* shift = scratch + (size_t)sp.ns * C * 2 + (size_t)C * 2;
   hipLaunchKernelGGL(k_bn_stats, dim3(C, sp.used), 256, 0, st, x, B, C, HW, sp.bps, scratch, shift);
@@ -387,6 +515,11 @@ int bn_stats(const float* x, const float* gamma, const float* beta, float* save_
              float* running_var, long long* num_batches_tracked, float momentum, float eps, float* table, int B, int C, int HW,
              float* scratch, hipStream_t st) {
   if ((HW & 3) == 0 && !aligned16(x)) return set_error("gpode_bn_stats: x must be 16-byte aligned");
+  if (bn_small((size_t)B * HW, kBnSmallFwd)) {
+    hipLaunchKernelGGL(k_bn_fwd_small, C, 256, 0, st, x, gamma, beta, (float)B * HW, eps, momentum, save_mean, save_invstd, running_mean, running_var,
+                       num_batches_tracked, (float*)nullptr, table, B, C, HW, 0);
+    return check_launch("bn_stats (one launch)");
+  }
   const Split sp = pick(B);
   float* shift = scratch + (size_t)sp.ns * C * 2 + (size_t)C * 2;
   hipLaunchKernelGGL(k_bn_stats, dim3(C, sp.used), 256, 0, st, x, B, C, HW, sp.bps, scratch, shift);
@@ -400,6 +533,11 @@ int bn_bwd(const float* x, const float* gy, const float* gamma, const float* bet
            const float* save_invstd, float* gx, float* ggamma, float* gbeta, float* gx_chansum, int B, int C, int HW, int relu,
            float* scratch, hipStream_t st) {
   if ((HW & 3) == 0 && !(aligned16(x) && aligned16(gy) && aligned16(gx))) return set_error("gpode_bn_bwd: x / gy / gx must be 16-byte aligned");
+  if (bn_small((size_t)B * HW, kBnSmallBwd)) {
+    hipLaunchKernelGGL(k_bn_bwd_small, C, 256, 0, st, x, gy, gamma, beta, save_mean, save_invstd, (float)B * HW, ggamma, gbeta, gx, gx_chansum, B, C,
+                       HW, relu);
+    return check_launch("bn_bwd (one launch)");
+  }
   const Split sp = pick(B);
   hipLaunchKernelGGL(k_bn_bwd_sums, dim3(C, sp.used), 256, 0, st, x, gy, gamma, beta, save_mean, save_invstd, B, C, HW, sp.bps, relu, scratch);
   float* part_gx = gx_chansum ? scratch + (size_t)sp.ns * C * 2 + (size_t)C * 3 : nullptr;
