@@ -312,7 +312,9 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
       }
     };
     // all (class, pixel tile, channel-tile column) jobs of this wavefront for the group staged in `img`
-    auto jobs = [&](const float* __restrict__ img, int b0, int nimg) {
+    // pf_grp >= 0: the fetch of that group is issued after this wavefront's first job (right behind the barrier it would queue
+    // behind the previous group's output stores: tools/convt_probe.hip, 4.3k cycles per group)
+    auto jobs = [&](const float* __restrict__ img, int b0, int nimg, int pf_grp = -1) {
       PROBE_T(pt_rng);
       // cost (k-steps) of all jobs of the group, and this wavefront's share [lo, hi) of it
       int wtot = 0;
@@ -380,6 +382,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
             }
           };
           run(std::common_type<G>{}, swc + jc * NCJ * 16, abase, acc);
+          if (pf_grp >= 0) { prefetch(pf_grp); pf_grp = -1; }
           if constexpr (PAIR) run(std::common_type<G1>{}, swc1 + jc * NCJ * 16, abase1, acc1);
           PROBE_ADD(3, pt_mm);
           PROBE_T(pt_st);
@@ -410,6 +413,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
           PROBE_ADD(4, pt_st);
         }
       });
+      if (pf_grp >= 0) prefetch(pf_grp);             // a wavefront without a job in this group
     };
     if constexpr (PC) {
       const bool producer = wave >= 8;
@@ -450,9 +454,8 @@ __global__ __launch_bounds__(NTHR, NTHR == 256 ? 2 : 1) void k_conv_igemm(const 
         __syncthreads();
         PROBE_ADD(2, pt_sc);
         PROBE_T(pt_pf);
-        if (grp + gstride < ngroups) prefetch(grp + gstride);
         PROBE_ADD(7, pt_pf);
-        jobs(s_img, b0, nimg);
+        jobs(s_img, b0, nimg, grp + gstride < ngroups ? grp + gstride : -1);
       }
     } else {
       // Double-buffered planes, ONE barrier per group: while a group is multiplied out of one buffer the next one is

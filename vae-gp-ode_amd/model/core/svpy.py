@@ -158,14 +158,23 @@ class SVGP_Layer(torch.nn.Module):
         nz, params = self._cache_inputs(draws=draws)
         side = ops.fork_side_stream()
         with ops.launch_on(side):
-            self._prebuilt = self._launch_cache_build(nz, params)
+            self._prebuilt = cache = self._launch_cache_build(nz, params)
+        # the flow waits for THIS point of the side stream only; the gradient-independent half of the cache backward (L^-1 from the
+        # factor) then follows on the same stream, behind the build it depends on -- one fork of the step's graph instead of two
+        # (every fork / join of the captured step costs tens of microseconds at replay)
+        self._prebuilt_ready = torch.cuda.Event()
+        self._prebuilt_ready.record(side)
+        cache.prepared = None
+        if ops.PREPARE_WITH_PREBUILD and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            with ops.launch_on(side):
+                cache.prepared = ops.cache_bwd_prepare(cache)
 
     def take_prebuilt_cache(self):
         cache = getattr(self, '_prebuilt', None)
         if cache is None:
             return None
         self._prebuilt = None
-        torch.cuda.current_stream().wait_stream(ops.side_stream())
+        torch.cuda.current_stream().wait_event(self._prebuilt_ready)
         if self.width_pad is not None:
             # the unpadded attribute slices are torch-native gathers of the cache's tensors: they launch on the current stream,
             # so they are taken here, after the join, not next to the side-stream kernels that write those tensors

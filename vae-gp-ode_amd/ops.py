@@ -115,6 +115,26 @@ def defer_kl_grads(params, grads):
     return True
 
 
+PREPARE_WITH_PREBUILD = os.environ.get('GPODE_PREPARE_FORK', '0') != '1'
+_HEARTBEAT = os.environ.get('GPODE_SIDE_HEARTBEAT', '0') == '1'
+
+
+def side_heartbeat():
+    """EXPERIMENT (GPODE_SIDE_HEARTBEAT=1): a trivial kernel on the side stream that waits for the current point of the main
+    stream.  The side branch of the backward pass starts 60-115 us after the kernel it depends on has finished, and the longer
+    the side queue has sat blocked the longer that takes; heartbeats keep its waits short."""
+    if not (_HEARTBEAT and _overlap['on']):
+        return
+    side = side_stream()
+    side.wait_stream(torch.cuda.current_stream())
+    d = _overlap.get('hb')
+    if d is None:
+        d = _overlap['hb'] = torch.zeros(1, dtype=torch.float32, device='cuda')
+    with torch.cuda.stream(side):
+        d.zero_()
+    _overlap['forked'] = True
+
+
 def join_side_stream():
     """Current stream waits for the side stream; deferred parameter gradients are accumulated."""
     if not _overlap['forked'] and not _overlap['pending'] and _overlap['kl'] is None:
@@ -145,7 +165,7 @@ class GPCache:
     """Per-draw cache: the lane-major ``pack`` the kernels consume, plus the attributes the reference
     caches on ``kern`` (kernels.py:134-137,172)."""
     __slots__ = ('kernel', 'Di', 'Do', 'M', 'S', 'pack', 'ws', 'ell', 'var', 'omega', 'phase', 'u', 'Lu', 'nu',
-                 'u_prior', 'noise', 'inputs', 'nd', 'stacked')
+                 'u_prior', 'noise', 'inputs', 'nd', 'stacked', 'prepared')
 
     @property
     def lead(self):
@@ -525,8 +545,8 @@ class _Flow(torch.autograd.Function):
             raise _lib.GpodeError('the prebuilt cache holds %s draws, the flow was asked for %s' % (cache.lead or 'one', draws))
         ctx.params = (raw_ell, raw_var, Z, Um, Us)
         need = any(ctx.needs_input_grad)
-        ctx.prepared = None
-        if _overlap['on'] and any(ctx.needs_input_grad[2:7]):
+        ctx.prepared = getattr(cache, 'prepared', None)      # overlap mode: started behind the cache build already (svpy.prebuild_cache)
+        if ctx.prepared is None and _overlap['on'] and any(ctx.needs_input_grad[2:7]):
             # L^-1 for the cache backward depends on the forward factor only: start it now on the side stream, where it
             # runs under the rollout / decoder instead of at the exposed end of the backward pass
             side = fork_side_stream()
