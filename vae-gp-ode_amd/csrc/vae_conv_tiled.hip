@@ -415,7 +415,7 @@ static int launch_T1(const float* x, const float* w, const float* bias, float* y
       // compiler's unswitching) only fits with one pixel tile per job -- two LDS operand reads per MFMA and conditional prefetches.
       // The weight-gradient engine (conv_wgrad_v2.hpp) got its gain from a loop written FOR that budget; this one would need the same.
       if (conv_pc_enabled() && B > 2 * num_cus() && !sink)
-        return launch_igemm<FwdPolicy<L, COS>, 1, 1, COS / 16, PAIR, 768, true, true>(x, w, bias, y, B, st, "convT_fwd_mfma_pc", in_bn);
+        return launch_igemm<FwdPolicy<L, COS>, 1, 2, COS / 16, PAIR, 768, true, true>(x, w, bias, y, B, st, "convT_fwd_mfma_pc", in_bn);
     }
     if (sink) return launch_igemm<FwdPolicy<L, COS>, IPBM, TG, COS / 16, PAIR, 512, false, false, true>(x, w, bias, y, B, st, "convT_fwd_mfma_stats", in_bn, sink);
     return launch_igemm<FwdPolicy<L, COS>, IPBM, TG, COS / 16, PAIR>(x, w, bias, y, B, st, "convT_fwd_mfma", in_bn);

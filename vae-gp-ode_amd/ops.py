@@ -99,6 +99,8 @@ def _main_marker():
     backward replays 0.07-0.15 ms slower (configs[1] 3.19 -> 3.12 ms, configs[0] 1.07 -> 0.93 ms; the first three nodes of
     the following replay then start ~55 us apart -- profiles/r02b_notes.txt).  Measured, not understood: a property of how the
     graph executor lays branches onto hardware queues."""
+    if _NO_MARKER:
+        return
     d = _overlap.get('marker')
     if d is None or d.device != torch.device('cuda', torch.cuda.current_device()):
         d = _overlap['marker'] = torch.zeros(1, dtype=torch.float32, device='cuda')
@@ -115,6 +117,7 @@ def defer_kl_grads(params, grads):
     return True
 
 
+_NO_MARKER = os.environ.get('GPODE_NO_MARKER', '0') == '1'
 PREPARE_WITH_PREBUILD = os.environ.get('GPODE_PREPARE_FORK', '0') != '1'
 _HEARTBEAT = os.environ.get('GPODE_SIDE_HEARTBEAT', '0') == '1'
 
@@ -127,6 +130,7 @@ def side_heartbeat():
         return
     side = side_stream()
     side.wait_stream(torch.cuda.current_stream())
+    _main_marker()                                   # the main branch's node is created first: it keeps the parent's queue
     d = _overlap.get('hb')
     if d is None:
         d = _overlap['hb'] = torch.zeros(1, dtype=torch.float32, device='cuda')
