@@ -213,6 +213,13 @@ int gpode_conv2d_bwd_data(const float* gy, const float* w, const float* bias, fl
  * specialisations only (decnn.4/7/10); other geometries return an error. */
 int gpode_conv2d_bwd_data_bn(const float* gy, const float* gy_bn, const float* w, const float* bias, float* gx, int B, int Ci, int H,
                              int W, int Co, int K, int S, int P, int Ho, int Wo, void* stream);
+/* gpode_conv2d_fwd / gpode_conv2d_bwd_weight on a BATCH-STRIDED input: image b starts x_batch_stride floats after image b - 1 and is
+ * dense in itself -- the encoder reads frame 0 (or the first frames, order 2) of every sequence of the minibatch X (N,T,1,28,28) in place
+ * (odegpvae.py:55-63: `X[:, 0]`), where torch would first copy the slice.  Generic kernels only (input channels not a multiple of 4). */
+int gpode_conv2d_fwd_bs(const float* x, size_t x_batch_stride, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co,
+                        int K, int S, int P, int Ho, int Wo, void* stream);
+int gpode_conv2d_bwd_weight_bs(const float* x, size_t x_batch_stride, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci,
+                               int H, int W, int Co, int K, int S, int P, int Ho, int Wo, void* stream);
 /* ConvTranspose2d forward (geometry arguments as gpode_conv2d_bwd_data: the convolution it is the adjoint of; x_bn = NULL or the
  * input's BatchNorm + ReLU table as above) that ALSO produces what the nn.BatchNorm2d in training mode BEHIND it needs (vae.py:107-120:
  * ConvTranspose2d -> BatchNorm2d): batch mean / invstd of the output y, the running-statistics update (momentum; unbiased variance;
@@ -311,6 +318,13 @@ int gpode_linear_fwd(const float* x, const float* w, const float* bias, float* y
 size_t gpode_linear_bwd_scratch(int B, int In, int Out);
 int gpode_linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out,
                      float* scratch, void* stream);
+/* nn.Linear on relu(x) with the ReLU folded into the layer (the encoder's Conv2d -> ReLU -> Flatten -> Linear, vae.py:58-61, 72-74): x is
+ * the RAW convolution output (B, In); forward y = relu(x) W^T + b, backward gx = (x > 0) (gy W), gw = gy^T relu(x), gb = sum gy.  No
+ * activation tensor and no ReLU launches in either direction.  Wide fan-in (In >= 128) only; other shapes return an error. */
+int gpode_linear_relu_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, void* stream);
+int gpode_linear_relu_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out,
+                          void* stream);
+
 /* Decoder.log_prob (vae.py:136-153): ll = log(z) X + log(1-z)(1-X), X broadcast over the leading L copies
  * (nX = numel(X)).  rowsum: the sum([2,3,4,5]) of create_model.py:52-53 fused, rows = L*N, inner = T*C*H*W. */
 int gpode_loglik_fwd(const float* X, const float* z, float* ll, size_t n, size_t nX, void* stream);

@@ -45,6 +45,32 @@ def test_encoder_convs(B):
         check(lambda x, w, b: V.conv2d(x, w, b, 2, 2), lambda x, w, b: F.conv2d(x, w, b, stride=2, padding=2), (B, ci, h, h), (co, ci, 5, 5), (co,))
 
 
+@pytest.mark.parametrize('frames', [1, 5])
+def test_encoder_first_conv_reads_the_minibatch_slice_in_place(frames):
+    """encoder(X[:, 0]) / encoder_v(X[:, 0:5]) (odegpvae.py:55-63): the batch-strided slice of X (N,T,1,28,28) goes to the kernel as it is
+    (gpode_conv2d_fwd_bs / _bwd_weight_bs) -- same output and weight / bias gradients as on a contiguous copy, against torch in fp64."""
+    from vae_gp_ode_amd import vae_ops as V
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(9, 7, 1, 28, 28, generator=g)
+    w, b = torch.randn(8, frames, 5, 5, generator=g) * 0.2, torch.randn(8, generator=g) * 0.1
+    Xd = X.cuda()
+    x = Xd[:, 0] if frames == 1 else torch.squeeze(Xd[:, 0:frames])
+    assert not x.is_contiguous() and V._batch_strided(x) == 7 * 784
+    a = [t.cuda().requires_grad_(True) for t in (w, b)]
+    y = V.conv2d(x, a[0], a[1], 2, 2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.cuda())
+    a64 = [t.double().requires_grad_(True) for t in (w, b)]
+    x64 = (X[:, 0] if frames == 1 else torch.squeeze(X[:, 0:frames])).double()
+    y64 = F.conv2d(x64, a64[0], a64[1], stride=2, padding=2)
+    y64.backward(gy.double())
+    assert relerr(y, y64) < TOL and relerr(a[0].grad, a64[0].grad) < TOL and relerr(a[1].grad, a64[1].grad) < TOL
+    a2 = [t.cuda().requires_grad_(True) for t in (w, b)]
+    y2 = V.conv2d(x.contiguous(), a2[0], a2[1], 2, 2)
+    y2.backward(gy.cuda())
+    assert torch.equal(y, y2) and torch.equal(a[0].grad, a2[0].grad) and torch.equal(a[1].grad, a2[1].grad)
+
+
 @pytest.mark.parametrize('shape', [(4, 8, 14, 14), (40, 64, 6, 6), (130, 32, 13, 13), (65, 16, 28, 28), (70, 5, 7, 7), (9, 3, 1, 3)])
 def test_batchnorm_train_relu(shape):
     from vae_gp_ode_amd import vae_ops as V
@@ -93,6 +119,8 @@ def test_linear_act_loglik(B):
     check(V.linear, F.linear, (2048 + B, 8), (256, 8), (256,))
     check(V.linear, F.linear, (B, 12), (192, 12), (192,))
     check(V.linear, F.linear, (B, 512), (12, 512), (12,))
+    check(V.linear_relu_in, lambda x, w, b: F.linear(F.relu(x), w, b), (B, 512), (12, 512), (12,))   # ReLU folded into the layer (encoder fc)
+    check(V.linear_relu_in, lambda x, w, b: F.linear(F.relu(x), w, b), (B, 64), (12, 64), (12,))     # narrow fan-in: separate ReLU
     check(V.relu, F.relu, (B, 33))
     check(V.sigmoid, torch.sigmoid, (B, 33))
     g = torch.Generator().manual_seed(1)

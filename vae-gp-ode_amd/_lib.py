@@ -60,6 +60,8 @@ _vp = ctypes.c_void_p
 SIGNATURES.update({
     'gpode_conv2d_fwd': (_i, [_c_float_p] * 4 + [_i] * 10 + [_vp]),
     'gpode_conv2d_bwd_data': (_i, [_c_float_p] * 4 + [_i] * 10 + [_vp]),
+    'gpode_conv2d_fwd_bs': (_i, [_c_float_p, _sz] + [_c_float_p] * 3 + [_i] * 10 + [_vp]),
+    'gpode_conv2d_bwd_weight_bs': (_i, [_c_float_p, _sz] + [_c_float_p] * 4 + [_i] * 10 + [_vp]),
     'gpode_convT_fwd_stats_scratch': (_sz, [_i]),
     'gpode_convT_fwd_stats': (_i, [_c_float_p] * 5 + [_i] * 10 + [_c_float_p] * 6 + [_vp, _f, _f, _c_float_p, _c_float_p, _i, _vp]),
     'gpode_conv_wgrad_scratch': (_sz, [_i, _i, _i, _i]),
@@ -87,6 +89,8 @@ SIGNATURES.update({
     'gpode_linear_fwd': (_i, [_c_float_p] * 4 + [_i, _i, _i, _vp]),
     'gpode_linear_bwd_scratch': (_sz, [_i, _i, _i]),
     'gpode_linear_bwd': (_i, [_c_float_p] * 6 + [_i, _i, _i, _c_float_p, _vp]),
+    'gpode_linear_relu_fwd': (_i, [_c_float_p] * 4 + [_i, _i, _i, _vp]),
+    'gpode_linear_relu_bwd': (_i, [_c_float_p] * 6 + [_i, _i, _i, _vp]),
     'gpode_loglik_fwd': (_i, [_c_float_p] * 3 + [_sz, _sz, _vp]),
     'gpode_loglik_bwd': (_i, [_c_float_p] * 4 + [_sz, _sz, _vp]),
     'gpode_loglik_rowsum_fwd': (_i, [_c_float_p] * 3 + [_sz, _sz, _sz, _vp]),

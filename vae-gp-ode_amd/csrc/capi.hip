@@ -246,6 +246,18 @@ int gpode_conv2d_bwd_data_bn(const float* gy, const float* gy_bn, const float* w
   if (!gy || !gy_bn || !w || !gx) return gp::set_error("gpode_conv2d_bwd_data_bn: null pointer");
   return gp::conv2d_bwd_data(gy, w, bias, gx, B, Ci, H, W, Co, K, S, P, Ho, Wo, gy_bn, GP_ST);
 }
+int gpode_conv2d_fwd_bs(const float* x, size_t x_batch_stride, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co,
+                        int K, int S, int P, int Ho, int Wo, void* stream) {
+  if (!x || !w || !y) return gp::set_error("gpode_conv2d_fwd_bs: null pointer");
+  if (x_batch_stride < (size_t)Ci * H * W) return gp::set_error("gpode_conv2d_fwd_bs: images overlap");
+  return gp::conv2d_fwd(x, w, bias, y, B, Ci, H, W, Co, K, S, P, Ho, Wo, GP_ST, x_batch_stride);
+}
+int gpode_conv2d_bwd_weight_bs(const float* x, size_t x_batch_stride, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci,
+                               int H, int W, int Co, int K, int S, int P, int Ho, int Wo, void* stream) {
+  if (!x || !gy || !gw || !scratch) return gp::set_error("gpode_conv2d_bwd_weight_bs: null pointer");
+  if (x_batch_stride < (size_t)Ci * H * W) return gp::set_error("gpode_conv2d_bwd_weight_bs: images overlap");
+  return gp::conv2d_bwd_weight(x, gy, gw, gbias, scratch, B, Ci, H, W, Co, K, S, P, Ho, Wo, nullptr, GP_ST, x_batch_stride);
+}
 size_t gpode_convT_fwd_stats_scratch(int Cout) { return gp::convT_fwd_stats_scratch(Cout); }
 int gpode_convT_fwd_stats(const float* x, const float* x_bn, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co,
                           int K, int S, int P, int Ho, int Wo, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
@@ -357,6 +369,15 @@ int gpode_linear_bwd(const float* x, const float* w, const float* gy, float* gx,
                      float* scratch, void* stream) {
   if (!x || !w || !gy) return gp::set_error("gpode_linear_bwd: null pointer");
   return gp::linear_bwd(x, w, gy, gx, gw, gb, B, In, Out, scratch, GP_ST);
+}
+int gpode_linear_relu_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, void* stream) {
+  if (!x || !w || !y) return gp::set_error("gpode_linear_relu_fwd: null pointer");
+  return gp::linear_relu_fwd(x, w, bias, y, B, In, Out, GP_ST);
+}
+int gpode_linear_relu_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out,
+                          void* stream) {
+  if (!x || !w || !gy) return gp::set_error("gpode_linear_relu_bwd: null pointer");
+  return gp::linear_relu_bwd(x, w, gy, gx, gw, gb, B, In, Out, GP_ST);
 }
 int gpode_loglik_fwd(const float* X, const float* z, float* ll, size_t n, size_t nX, void* stream) { return gp::loglik_fwd(X, z, ll, n, nX, GP_ST); }
 int gpode_loglik_bwd(const float* X, const float* z, const float* g, float* gz, size_t n, size_t nX, void* stream) {

@@ -109,7 +109,7 @@ int cache_bwd_prepare(int kernel, int Di, int Do, int M, int S, int nd, const fl
 
 // conv VAE blocks (vae_conv.hip)
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S,
-               int P, int Ho, int Wo, hipStream_t st);
+               int P, int Ho, int Wo, hipStream_t st, size_t xbs = 0);
 size_t convT_fwd_stats_scratch(int Co_out);
 int convT_fwd_stats(const float* x, const float* x_bn, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K,
                     int S, int P, int Ho, int Wo, const float* gamma, const float* beta, float* save_mean, float* save_invstd,
@@ -119,7 +119,7 @@ int conv2d_bwd_data(const float* gy, const float* w, const float* bias, float* g
                     int P, int Ho, int Wo, const float* gy_bn, hipStream_t st);
 size_t conv_wgrad_scratch(int B, int Ci, int Co, int K);
 int conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci, int H, int W, int Co,
-                      int K, int S, int P, int Ho, int Wo, const float* gy_bn, hipStream_t st);
+                      int K, int S, int P, int Ho, int Wo, const float* gy_bn, hipStream_t st, size_t xbs = 0);
 size_t bn_scratch(int B, int C);
 int bn_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean, float* save_invstd,
            float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, int B, int C, int HW,
@@ -161,6 +161,8 @@ int act_bwd(const float* y, const float* gy, float* gx, size_t n, int mode, hipS
 int linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, hipStream_t st);
 int linear_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out, float* scratch, hipStream_t st);
 size_t linear_bwd_scratch(int B, int In, int Out);
+int linear_relu_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, hipStream_t st);
+int linear_relu_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out, hipStream_t st);
 int loglik_fwd(const float* X, const float* z, float* ll, size_t n, size_t nX, hipStream_t st);
 int loglik_bwd(const float* X, const float* z, const float* g, float* gz, size_t n, size_t nX, hipStream_t st);
 int loglik_rowsum_fwd(const float* X, const float* z, float* out, size_t rows, size_t inner, size_t nX, hipStream_t st);

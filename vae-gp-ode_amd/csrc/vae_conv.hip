@@ -19,7 +19,7 @@
 
 namespace gp {
 
-struct ConvDims { int B, Ci, H, W, Co, P, Ho, Wo; };
+struct ConvDims { int B, Ci, H, W, Co, P, Ho, Wo; size_t xbs; };   // xbs: floats between consecutive images of x (dense: Ci * H * W)
 int chan_sum(const float* v, float* out, int B, int C, int HW, float* scratch, hipStream_t st);
 
 template <int K, int S>
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd(const float* __restrict__ x, c
     const int b = (int)(e / ((size_t)d.Wo * d.Ho * d.Co));
     float acc = bias ? bias[co] : 0.f;
     const int iy0 = oy * S - d.P, ix0 = ox * S - d.P;
-    const float* xb = x + (size_t)b * d.Ci * d.H * d.W;
+    const float* xb = x + (size_t)b * d.xbs;
     const float* wc = w + (size_t)co * d.Ci * K * K;
     for (int ci = 0; ci < d.Ci; ++ci) {
       const float* xc = xb + (size_t)ci * d.H * d.W;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_conv_bwd_weight(const float* __restrict
     const int b = b0 + (int)(e / npix), p = (int)(e % npix);
     const int oy = p / d.Wo, ox = p % d.Wo;
     const float g = gy[((size_t)b * d.Co + co) * npix + p];
-    const float* xc = x + ((size_t)b * d.Ci + ci) * d.H * d.W;
+    const float* xc = x + (size_t)b * d.xbs + (size_t)ci * d.H * d.W;
     const int iy0 = oy * S - d.P, ix0 = ox * S - d.P;
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
@@ -164,22 +164,28 @@ __global__ void k_linear_fwd(const float* __restrict__ x, const float* __restric
   for (int i = 0; i < In; ++i) acc = fmaf(xr[i], wr[i], acc);
   y[e] = acc;
 }
-__global__ void k_linear_bwd_x(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx, int B, int In, int Out) {
+// xpre != nullptr: the layer's input was relu(xpre) (applied on load by the forward) -- the gradient passes where xpre > 0
+__global__ void k_linear_bwd_x(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx, int B, int In, int Out,
+                               const float* __restrict__ xpre) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)B * In) return;
   const int b = (int)(e / In), i = (int)(e % In);
   float acc = 0.f;
   for (int o = 0; o < Out; ++o) acc = fmaf(gy[(size_t)b * Out + o], w[(size_t)o * In + i], acc);
-  gx[e] = acc;
+  gx[e] = (xpre && !(xpre[e] > 0.f)) ? 0.f : acc;
 }
 // gw[o,i] = sum_b gy[b,o] x[b,i]; gb[o] = sum_b gy[b,o].  One wave per (o,i) (i == In -> bias).
 __global__ __launch_bounds__(256) void k_linear_bwd_w(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gw,
-                                                       float* __restrict__ gb, int B, int In, int Out) {
+                                                       float* __restrict__ gb, int B, int In, int Out, int relu_in) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (wave >= Out * (In + 1)) return;
   const int o = wave / (In + 1), i = wave % (In + 1);
   float acc = 0.f;
-  for (int b = lane; b < B; b += 64) acc = fmaf(gy[(size_t)b * Out + o], i < In ? x[(size_t)b * In + i] : 1.f, acc);
+  for (int b = lane; b < B; b += 64) {
+    float xv = i < In ? x[(size_t)b * In + i] : 1.f;
+    if (relu_in && i < In) xv = fmaxf(xv, 0.f);
+    acc = fmaf(gy[(size_t)b * Out + o], xv, acc);
+  }
   float in1[1] = {acc}, out1[1];
   wave_sum_multi<1>(in1, out1);
   if (lane == 0) { if (i < In) gw[(size_t)o * In + i] = out1[0]; else if (gb) gb[o] = out1[0]; }
@@ -221,7 +227,8 @@ __global__ __launch_bounds__(256) void k_linear_bwd_w_cols(const float* __restri
 // ---- wide fan-in, few outputs (the encoder's fc layer, 512 -> 2q on the minibatch, vae.py:62): one wavefront per output
 //      element, lanes along the reduction
 __global__ __launch_bounds__(256) void k_linear_fwd_fanin(const float* __restrict__ x, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, float* __restrict__ y, int B, int In, int Out) {
+                                                           const float* __restrict__ bias, float* __restrict__ y, int B, int In, int Out,
+                                                           int relu_in) {
   const int lane = threadIdx.x & 63;
   const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (e >= B * Out) return;
@@ -229,7 +236,8 @@ __global__ __launch_bounds__(256) void k_linear_fwd_fanin(const float* __restric
   const float* xr = x + (size_t)b * In;
   const float* wr = w + (size_t)o * In;
   float acc = 0.f;
-  for (int i = lane; i < In; i += 64) acc = fmaf(xr[i], wr[i], acc);
+  if (relu_in) { for (int i = lane; i < In; i += 64) acc = fmaf(fmaxf(xr[i], 0.f), wr[i], acc); }
+  else { for (int i = lane; i < In; i += 64) acc = fmaf(xr[i], wr[i], acc); }
   const float in1[1] = {acc};
   float out1[1];
   wave_sum_multi<1>(in1, out1);
@@ -345,10 +353,13 @@ int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx
 int tiled_bwd_weight(const float* x, const float* gy, float* gw, float* scratch, int B, int Ci, int H, int W, int Co, int K, int S,
                      int P, int Ho, int Wo, const float* in_bn, hipStream_t st);
 
+// xbs != 0: x is batch-strided (xbs floats between images, each image dense) -- generic kernels only
 int conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Ci, int H, int W, int Co, int K, int S,
-               int P, int Ho, int Wo, hipStream_t st) {
-  { const int r = tiled_fwd(x, w, bias, y, B, Ci, H, W, Co, K, S, P, Ho, Wo, st); if (r >= 0) return r; }
-  ConvDims d{B, Ci, H, W, Co, P, Ho, Wo};
+               int P, int Ho, int Wo, hipStream_t st, size_t xbs) {
+  if (xbs == (size_t)Ci * H * W) xbs = 0;
+  if (!xbs) { const int r = tiled_fwd(x, w, bias, y, B, Ci, H, W, Co, K, S, P, Ho, Wo, st); if (r >= 0) return r; }
+  else if (Ci % 4 == 0) return set_error("gpode_conv2d_fwd_bs: batch-strided input is for the generic kernels (input channels not a multiple of 4)");
+  ConvDims d{B, Ci, H, W, Co, P, Ho, Wo, xbs ? xbs : (size_t)Ci * H * W};
   const size_t total = (size_t)B * Co * Ho * Wo;
 #define X(k, s) if (K == k && S == s) { hipLaunchKernelGGL((k_conv_fwd<k, s>), ew_grid(total), 256, 0, st, x, w, bias, y, d); return check_launch("conv_fwd"); }
   GP_CONV_KS(X)
@@ -384,7 +395,7 @@ int conv2d_bwd_data(const float* gy, const float* w, const float* bias, float* g
                     int P, int Ho, int Wo, const float* gy_bn, hipStream_t st) {
   { const int r = tiled_bwd_data(gy, w, bias, gx, B, Ci, H, W, Co, K, S, P, Ho, Wo, gy_bn, st, nullptr); if (r >= 0) return r; }
   if (gy_bn) return set_error("gpode_conv2d_bwd_data_bn: no matrix-core specialisation for this geometry");
-  ConvDims d{B, Ci, H, W, Co, P, Ho, Wo};
+  ConvDims d{B, Ci, H, W, Co, P, Ho, Wo, (size_t)Ci * H * W};
   const size_t total = (size_t)B * Ci * H * W;
 #define X(k, s) if (K == k && S == s) { hipLaunchKernelGGL((k_conv_bwd_data<k, s>), ew_grid(total), 256, 0, st, gy, w, bias, gx, d); return check_launch("conv_bwd_data"); }
   GP_CONV_KS(X)
@@ -409,8 +420,10 @@ size_t conv_wgrad_scratch(int B, int Ci, int Co, int K) {
 }
 
 int conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, float* scratch, int B, int Ci, int H, int W, int Co,
-                      int K, int S, int P, int Ho, int Wo, const float* gy_bn, hipStream_t st) {
-  {
+                      int K, int S, int P, int Ho, int Wo, const float* gy_bn, hipStream_t st, size_t xbs) {
+  if (xbs == (size_t)Ci * H * W) xbs = 0;
+  if (xbs && Ci % 4 == 0) return set_error("gpode_conv2d_bwd_weight_bs: batch-strided input is for the generic kernels");
+  if (!xbs) {
     const int r = tiled_bwd_weight(x, gy, gw, scratch, B, Ci, H, W, Co, K, S, P, Ho, Wo, gy_bn, st);
     if (r > 0) return r;
     if (r == 0) {
@@ -421,7 +434,7 @@ int conv2d_bwd_weight(const float* x, const float* gy, float* gw, float* gbias, 
     }
   }
   if (gy_bn) return set_error("gpode_conv2d_bwd_weight_bn: no matrix-core specialisation for this geometry");
-  ConvDims d{B, Ci, H, W, Co, P, Ho, Wo};
+  ConvDims d{B, Ci, H, W, Co, P, Ho, Wo, xbs ? xbs : (size_t)Ci * H * W};
   const int nsplit = pick_split(B, Co * Ci);
   const int bps = (B + nsplit - 1) / nsplit;
   const int used = (B + bps - 1) / bps;
@@ -452,7 +465,7 @@ int linear_fwd(const float* x, const float* w, const float* bias, float* y, int 
     return check_launch("linear_fwd_fanout");
   }
   if (In >= 128 && (size_t)B * Out <= (size_t)1 << 22) {
-    hipLaunchKernelGGL(k_linear_fwd_fanin, (unsigned)(((size_t)B * Out + 3) / 4), 256, 0, st, x, w, bias, y, B, In, Out);
+    hipLaunchKernelGGL(k_linear_fwd_fanin, (unsigned)(((size_t)B * Out + 3) / 4), 256, 0, st, x, w, bias, y, B, In, Out, 0);
     return check_launch("linear_fwd_fanin");
   }
   hipLaunchKernelGGL(k_linear_fwd, (unsigned)(((size_t)B * Out + 255) / 256), 256, 0, st, x, w, bias, y, B, In, Out);
@@ -480,14 +493,28 @@ int linear_bwd(const float* x, const float* w, const float* gy, float* gx, float
         const RedJob jobs[2] = {RedJob{partW, gw, used, Out * In, 0, 0, 0, 0}, RedJob{partB, gb, used, Out, 0, 0, 0, 0}};
         if (reduce_jobs(jobs, gb ? 2 : 1, st)) return 1;
       } else {
-        hipLaunchKernelGGL(k_linear_bwd_w, (unsigned)(((size_t)Out * (In + 1) * 64 + 255) / 256), 256, 0, st, x, gy, gw, gb, B, In, Out);
+        hipLaunchKernelGGL(k_linear_bwd_w, (unsigned)(((size_t)Out * (In + 1) * 64 + 255) / 256), 256, 0, st, x, gy, gw, gb, B, In, Out, 0);
       }
     }
     return check_launch("linear_bwd_fanout");
   }
-  if (gx) hipLaunchKernelGGL(k_linear_bwd_x, (unsigned)(((size_t)B * In + 255) / 256), 256, 0, st, gy, w, gx, B, In, Out);
-  if (gw) hipLaunchKernelGGL(k_linear_bwd_w, (unsigned)(((size_t)Out * (In + 1) * 64 + 255) / 256), 256, 0, st, x, gy, gw, gb, B, In, Out);
+  if (gx) hipLaunchKernelGGL(k_linear_bwd_x, (unsigned)(((size_t)B * In + 255) / 256), 256, 0, st, gy, w, gx, B, In, Out, (const float*)nullptr);
+  if (gw) hipLaunchKernelGGL(k_linear_bwd_w, (unsigned)(((size_t)Out * (In + 1) * 64 + 255) / 256), 256, 0, st, x, gy, gw, gb, B, In, Out, 0);
   return check_launch("linear_bwd");
+}
+
+// y = relu(x) W^T + b and its backward with the ReLU of the INPUT folded in (the encoder's cnn.6 -> ReLU -> Flatten -> fc,
+// vae.py:58-61, 72-74): x is the convolution's raw output; no activation tensor, no separate ReLU launches.  Wide fan-in only.
+int linear_relu_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, hipStream_t st) {
+  if (In < 128 || (size_t)B * Out > ((size_t)1 << 22)) return set_error("gpode_linear_relu_fwd: built for wide fan-in layers (In >= 128)");
+  hipLaunchKernelGGL(k_linear_fwd_fanin, (unsigned)(((size_t)B * Out + 3) / 4), 256, 0, st, x, w, bias, y, B, In, Out, 1);
+  return check_launch("linear_relu_fwd");
+}
+int linear_relu_bwd(const float* x, const float* w, const float* gy, float* gx, float* gw, float* gb, int B, int In, int Out, hipStream_t st) {
+  if (In < 128) return set_error("gpode_linear_relu_bwd: built for wide fan-in layers (In >= 128)");
+  if (gx) hipLaunchKernelGGL(k_linear_bwd_x, (unsigned)(((size_t)B * In + 255) / 256), 256, 0, st, gy, w, gx, B, In, Out, x);
+  if (gw) hipLaunchKernelGGL(k_linear_bwd_w, (unsigned)(((size_t)Out * (In + 1) * 64 + 255) / 256), 256, 0, st, x, gy, gw, gb, B, In, Out, 1);
+  return check_launch("linear_relu_bwd");
 }
 
 int loglik_fwd(const float* X, const float* z, float* ll, size_t n, size_t nX, hipStream_t st) {

@@ -39,12 +39,12 @@ class Encoder(nn.Module):
 
     def forward(self, x):
         c = self.cnn
-        h = V.conv2d(x.contiguous(), c[0].weight, c[0].bias, 2, 2)
+        h = V.conv2d(x, c[0].weight, c[0].bias, 2, 2)        # (a batch-strided slice of the minibatch is read in place)
         h = _bn(h, c[1], relu=True)
         h = V.conv2d(h, c[3].weight, c[3].bias, 2, 2)
         h = _bn(h, c[4], relu=True)
-        h = V.relu(V.conv2d(h, c[6].weight, c[6].bias, 2, 2))
-        z = V.linear(h.flatten(1), self.fc.weight, self.fc.bias)
+        h = V.conv2d(h, c[6].weight, c[6].bias, 2, 2)
+        z = V.linear_relu_in(h.flatten(1), self.fc.weight, self.fc.bias)   # nn.ReLU + nn.Flatten + fc: the ReLU rides in the layer's loads
         return z.chunk(2, dim=-1)
 
     @staticmethod

@@ -224,17 +224,35 @@ def _fused_chansum(gy, C):
     return cs
 
 
+def _batch_strided(x):
+    """x (B,C,H,W) with dense images at a constant distance (e.g. X[:, 0] of a minibatch X (N,T,1,28,28), odegpvae.py:55-63) and a
+    channel count the generic convolution kernels take: floats between images, else 0."""
+    if x.dim() != 4 or x.is_contiguous() or x.dtype != torch.float32 or not x.is_cuda or x.shape[1] % 4 == 0 or x.shape[0] < 2:
+        return 0
+    B, C, H, W = x.shape
+    if x.stride()[1:] != (H * W, W, 1) or x.stride(0) < C * H * W:
+        return 0
+    return x.stride(0)
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad):
-        x, w = _chk(x, 'x'), _chk(w, 'weight')
+        xbs = _batch_strided(x)                      # read in place: no contiguous copy of the slice (a launch on the step's first chain)
+        if not xbs:
+            x = _chk(x, 'x')
+        w = _chk(w, 'weight')
         B, Ci, H, W = x.shape
         Co, _, K, _ = w.shape
         Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
         y = _new((B, Co, Ho, Wo), x)
-        _lib.call('gpode_conv2d_fwd', _ptr(x), _ptr(w), _ptr(b), _ptr(y), B, Ci, H, W, Co, K, stride, pad, Ho, Wo, _stream())
+        if xbs:
+            _lib.call('gpode_conv2d_fwd_bs', _ptr(x), xbs, _ptr(w), _ptr(b), _ptr(y), B, Ci, H, W, Co, K, stride, pad, Ho, Wo, _stream())
+        else:
+            _lib.call('gpode_conv2d_fwd', _ptr(x), _ptr(w), _ptr(b), _ptr(y), B, Ci, H, W, Co, K, stride, pad, Ho, Wo, _stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (B, Ci, H, W, Co, K, stride, pad, Ho, Wo, b is not None)
+        ctx.xbs = xbs
         return y
 
     @staticmethod
@@ -251,8 +269,12 @@ class _Conv2d(torch.autograd.Function):
             pre = _fused_chansum(gy, Co) if has_b else None     # bias gradient already produced by the BatchNorm backward
             gb = _new((Co,), x) if (has_b and pre is None) else None
             ws = _wgrad_scratch(B, Ci, Co, K, x)
-            _bwd_call('gpode_conv2d_bwd_weight', _ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), _ptr(ws),
-                      B, Ci, H, W, Co, K, S, P, Ho, Wo, _stream(), keep=(ws, gy))
+            if ctx.xbs:
+                _bwd_call('gpode_conv2d_bwd_weight_bs', _ptr(x), ctx.xbs, _ptr(gy), _ptr(gw), _ptr(gb), _ptr(ws),
+                          B, Ci, H, W, Co, K, S, P, Ho, Wo, _stream(), keep=(ws, gy))
+            else:
+                _bwd_call('gpode_conv2d_bwd_weight', _ptr(x), _ptr(gy), _ptr(gw), _ptr(gb), _ptr(ws),
+                          B, Ci, H, W, Co, K, S, P, Ho, Wo, _stream(), keep=(ws, gy))
             if pre is not None:
                 gb = pre
         return gx, gw, gb, None, None
@@ -517,6 +539,33 @@ class _Linear(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _LinearReluIn(torch.autograd.Function):
+    """linear(relu(x), w, b) with the ReLU folded into the layer's loads in both directions (gpode_linear_relu_fwd / _bwd): the
+    encoder's Conv2d -> ReLU -> Flatten -> Linear (vae.py:58-61, 72-74) without the activation tensor and its two launches."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _chk(x, 'x'), _chk(w, 'weight')
+        B, In = x.shape
+        Out = w.shape[0]
+        y = _new((B, Out), x)
+        _lib.call('gpode_linear_relu_fwd', _ptr(x), _ptr(w), _ptr(b), _ptr(y), B, In, Out, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        B, In = x.shape
+        Out = w.shape[0]
+        gx = _new(x.shape, x) if ctx.needs_input_grad[0] else None
+        gw = _new(w.shape, x) if ctx.needs_input_grad[1] else None
+        gb = _new((Out,), x) if (ctx.has_b and gw is not None) else None
+        _lib.call('gpode_linear_relu_bwd', _ptr(x), _ptr(w), _ptr(gy.contiguous()), _ptr(gx), _ptr(gw), _ptr(gb), B, In, Out, _stream())
+        return gx, gw, gb
+
+
 class _LogLik(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, z):
@@ -761,6 +810,13 @@ def sigmoid(x):
 
 def linear(x, w, b):
     return _Linear.apply(x, w, b)
+
+
+def linear_relu_in(x, w, b):
+    """linear(relu(x), w, b); the ReLU is folded into the layer for wide fan-in (>= 128 inputs), applied separately otherwise."""
+    if x.dim() == 2 and x.shape[1] >= 128 and x.shape[0] * w.shape[0] <= (1 << 22):
+        return _LinearReluIn.apply(x, w, b)
+    return _Linear.apply(relu(x), w, b)
 
 
 def bernoulli_loglik(X, z):
