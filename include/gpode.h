@@ -130,6 +130,15 @@ int gpode_rollout_fwd_n(int kernel, int order, int method, int Di, int Do, int M
 int gpode_rollout_bwd_n(int kernel, int order, int method, int Di, int Do, int M, int S, int ndraws,
                         const float* pack, const float* xstage, const float* gzt, const float* ts, int N, int T,
                         float* gz0, float* astage, void* stream);
+/* gpode_rollout_bwd_n and gpode_param_grad_n in ONE pass: the reverse sweep visits every (stage input, adjoint) row anyway, so the
+ * rows' parameter-gradient terms are accumulated on the way and come out as gpack (ndraws, pack_floats) -- what the two calls
+ * produce together, with one launch and one pass over the rows less.  slab: ndraws * nchunk * pack_floats floats of scratch with
+ * nchunk = gpode_rollout_bwd_pgrad_chunks(...) -- 0 means this shape has no fused form (streamed teams, second-order models,
+ * midpoint rule): call the two entry points then.  gz0 / astage as gpode_rollout_bwd_n. */
+int gpode_rollout_bwd_pgrad_chunks(int kernel, int order, int method, int Di, int Do, int M, int S, int N);
+int gpode_rollout_bwd_pgrad_n(int kernel, int order, int method, int Di, int Do, int M, int S, int ndraws,
+                              const float* pack, const float* xstage, const float* gzt, const float* ts, int N, int T,
+                              float* gz0, float* astage, float* slab, int nchunk, float* gpack, void* stream);
 int gpode_param_grad_n(int kernel, int Di, int Do, int M, int S, int ndraws, const float* pack,
                        const float* x, const float* a, int R, float* slab, int nchunk, float* gpack, int accumulate,
                        void* stream);

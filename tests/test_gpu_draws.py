@@ -158,3 +158,35 @@ def test_model_step_with_batched_draws_matches_the_oracle(kernel, order, overlap
     assert max(worst.values()) < 2e-3, worst
     # the attributes the reference leaves on `kern` after its loop are those of the LAST draw
     assert torch.equal(gp.kern.rff_weights, nzs[-1]['rff_w'].cuda())
+
+
+@pytest.mark.parametrize('D,M,S,N,T,L,method', [(6, 100, 256, 32, 16, 1, 'rk4'), (6, 100, 256, 9, 5, 3, 'euler'), (4, 40, 100, 300, 4, 1, 'rk4'),
+                                                (3, 20, 64, 7, 6, 2, 'rk4'), (2, 16, 32, 2500, 3, 1, 'euler')])
+def test_reverse_sweep_with_parameter_sums_equals_the_two_launches(D, M, S, N, T, L, method):
+    """gpode_rollout_bwd_pgrad_n (the reverse sweep accumulating the rows' parameter-gradient terms on the way) against
+    gpode_rollout_bwd_n + gpode_param_grad_n: same gz0 and stage adjoints bit for bit, the pack-layout sums to summation order
+    (one chunk per trajectory instead of chunks of consecutive rows); shapes without a fused form report 0 chunks."""
+    from vae_gp_ode_amd import ops
+    dev = torch.device('cuda:0')
+    p = {k: v.to(dev) for k, v in _params('RBF', D, D, M, 3).items()}
+    nz = {k: (v if L > 1 else v[0]).contiguous().to(dev) for k, v in _noise('RBF', D, D, M, S, L, 4).items()}
+    g = torch.Generator().manual_seed(6)
+    z0 = torch.randn(N, D, generator=g).to(dev)
+    ts = (0.1 * torch.arange(T, dtype=torch.float)).to(dev)
+    lead = (L,) if L > 1 else ()
+    wgt = torch.randn(lead + (N, T, D), generator=g).to(dev)
+    c = _build(ops, 'RBF', p, nz)
+    c.noise = nz
+    zt, xs = ops.rollout(c, z0, ts, 1, method, save_stages=True)
+    gz0, ast = ops.rollout_bwd(c, xs, wgt, ts, 1, method)
+    gp = ops.param_grad(c, xs.reshape(lead + (-1, D)), ast.reshape(lead + (-1, D)))
+    nch = ops.pgrad_chunks(c, N, 1, method, force=True)
+    assert nch == min(N, 2048)
+    gz0f, astf, gpf = ops.rollout_bwd_pgrad(c, xs, wgt, ts, 1, method, nch)
+    assert torch.equal(gz0, gz0f) and torch.equal(ast, astf)
+    used = c.pack.shape[-1] - (-(D * D) % 4)
+    assert relerr(gpf[..., :used], gp[..., :used].double()) < 2e-5, relerr(gpf[..., :used], gp[..., :used].double())
+    assert ops.pgrad_chunks(c, N, 1, 'midpoint', force=True) == 0                       # no fused form: the caller uses the two launches
+    pd = {k: v.to(dev) for k, v in _params('DF', 6, 6, 20, 3).items()}
+    nd = {k: v[0].contiguous().to(dev) for k, v in _noise('DF', 6, 6, 20, 32, 1, 4).items()}
+    assert ops.pgrad_chunks(_build(ops, 'DF', pd, nd), N, 1, 'rk4', force=True) == 0

@@ -42,6 +42,8 @@ SIGNATURES = {
     'gpode_cache_build_fwd_n': (_i, [_i] * 6 + [_c_float_p] * 20),
     'gpode_rollout_fwd_n': (_i, [_i] * 8 + [_c_float_p, _c_float_p, _c_float_p, _i, _i, _c_float_p, _c_float_p, ctypes.c_void_p]),
     'gpode_rollout_bwd_n': (_i, [_i] * 8 + [_c_float_p] * 4 + [_i, _i, _c_float_p, _c_float_p, ctypes.c_void_p]),
+    'gpode_rollout_bwd_pgrad_chunks': (_i, [_i] * 8),
+    'gpode_rollout_bwd_pgrad_n': (_i, [_i] * 8 + [_c_float_p] * 4 + [_i, _i, _c_float_p, _c_float_p, _c_float_p, _i, _c_float_p, ctypes.c_void_p]),
     'gpode_param_grad_n': (_i, [_i] * 6 + [_c_float_p, _c_float_p, _c_float_p, _i, _c_float_p, _i, _c_float_p, _i, ctypes.c_void_p]),
     'gpode_cache_bwd_sizes_n': (_i, [_i] * 6 + [_sz_p]),
     'gpode_cache_build_bwd_n': (_i, [_i] * 6 + [_c_float_p] * 13 + [_i, ctypes.c_void_p]),

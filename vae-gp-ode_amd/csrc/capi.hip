@@ -112,6 +112,20 @@ int gpode_rollout_bwd_n(int kernel, int order, int method, int Di, int Do, int M
   return gp::rollout_bwd(kernel, order, method, Di, Do, M, S, pack, xstage, gzt, ts, N, T, gz0, astage, (hipStream_t)stream,
                          draws_of(ndraws, pf, rows * Di, (size_t)N * Di, (size_t)N * T * Di, rows * Do));
 }
+int gpode_rollout_bwd_pgrad_chunks(int kernel, int order, int method, int Di, int Do, int M, int S, int N) {
+  return gp::rollout_bwd_pgrad_chunks(kernel, order, method, Di, Do, M, S, N);
+}
+int gpode_rollout_bwd_pgrad_n(int kernel, int order, int method, int Di, int Do, int M, int S, int ndraws,
+                              const float* pack, const float* xstage, const float* gzt, const float* ts, int N, int T,
+                              float* gz0, float* astage, float* slab, int nchunk, float* gpack, void* stream) {
+  if (N < 1 || T < 2 || ndraws < 1 || ndraws > 65535) return gp::set_error("gpode_rollout_bwd_pgrad: N=%d T=%d draws=%d", N, T, ndraws);
+  if (!pack || !gzt || !ts || !gz0 || !xstage || !astage || !slab || !gpack) return gp::set_error("gpode_rollout_bwd_pgrad: null pointer");
+  size_t pf = 0;
+  if (gp::cache_sizes(kernel, Di, Do, M, S, &pf, nullptr)) return 1;
+  const size_t rows = (size_t)N * (T - 1) * stage_count(method);
+  return gp::rollout_bwd_pgrad(kernel, order, method, Di, Do, M, S, pack, xstage, gzt, ts, N, T, gz0, astage, slab, nchunk, gpack,
+                               (hipStream_t)stream, draws_of(ndraws, pf, rows * Di, (size_t)N * Di, (size_t)N * T * Di, rows * Do));
+}
 int gpode_rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S,
                       const float* pack, const float* xstage, const float* gzt, const float* ts, int N, int T,
                       float* gz0, float* astage, void* stream) {

@@ -32,26 +32,39 @@ template <int DI> __device__ __forceinline__ void store_vec(float* __restrict__ 
 
 // ODE-level VJP (flow.py:27-45): order 1: dy = f(y); order 2: dy = [y[q:], f(y)].
 // a (DI) = adjoint of dy  ->  gx (DI) = (d dy / d y)^T a ;  af (DO) = the part that multiplies J_f.
-template <class EV, int DI, int DO, int ORDER>
-__device__ __forceinline__ void ode_vjp(EV& ev, const float (&x)[DI], const float (&a)[DI], float (&gx)[DI], float (&af)[DO]) {
-  if (ORDER == 1) {
+template <int DI, int DO, int NJ>
+__device__ __forceinline__ void store_grads_rbf(const typename RbfTeamEval<DI, DO, NJ>::Grads& G, float* __restrict__ out, int M, int S,
+                                                int wave, int lane, float (*sInd)[64][4 * RbfLayout<DI, DO>::RQ2],
+                                                float (*sUni)[((DO + 1) / 2) * DI]);
+template <int D, int NJ>
+__device__ __forceinline__ void store_grads_df(const typename DfTeamEval<D, NJ>::Grads& G, float* __restrict__ out, int M, int S, int wave,
+                                               int lane, float (*sInd)[64][4 * DfLayout<D>::RQ2],
+                                               float (*sUni)[2 * D * ((D + 1) / 2) + (D + 1) / 2]);
+struct NoGrads {};
+template <class EV, int DI, int DO, int ORDER, class GR = NoGrads>
+__device__ __forceinline__ void ode_vjp(EV& ev, const float (&x)[DI], const float (&a)[DI], float (&gx)[DI], float (&af)[DO], GR* G = nullptr) {
 #pragma unroll
-    for (int i = 0; i < DO; ++i) af[i] = a[i];
-    ev.vjp(x, af, gx);
-  } else {
-#pragma unroll
-    for (int i = 0; i < DO; ++i) af[i] = a[DO + i];
-    ev.vjp(x, af, gx);
+  for (int i = 0; i < DO; ++i) af[i] = ORDER == 1 ? a[i] : a[DO + i];
+  if constexpr (std::is_same<GR, NoGrads>::value) ev.vjp(x, af, gx);
+  else ev.vjp_grad(x, af, gx, *G);                  // the row's parameter-gradient terms ride along (PGRAD form of the reverse sweep)
+  if (ORDER != 1) {
 #pragma unroll
     for (int i = 0; i < DO; ++i) gx[DO + i] += a[i];
   }
 }
 
-template <class EV, int DI, int DO, int ORDER, int METHOD>
+template <class EV, bool PG> struct GradsOf { using type = NoGrads; };
+template <class EV> struct GradsOf<EV, true> { using type = typename EV::Grads; };
+
+// PG (register-resident team evaluators only): the parameter-gradient sums of the rows this workgroup walks are accumulated in
+// the same pass (EV::vjp_grad) and written to slab[blockIdx.x] in pack layout -- what param_grad_{rbf,df}_kernel computes from the
+// stored (x, a) rows in a launch of its own, the first node of the backward pass's side branch.
+template <class EV, int DI, int DO, int ORDER, int METHOD, bool PG = false>
 __global__ __launch_bounds__(64 * EV::kTeam) void rollout_bwd_team_kernel(const float* __restrict__ pack, int M, int S,
                                                                 const float* __restrict__ xstage, const float* __restrict__ gzt,
                                                                 const float* __restrict__ ts, int N, int T,
-                                                                float* __restrict__ gz0, float* __restrict__ astage, Draws dw) {
+                                                                float* __restrict__ gz0, float* __restrict__ astage, Draws dw,
+                                                                float* __restrict__ slab = nullptr, size_t pack_floats = 0) {
   constexpr int NS = METHOD == 0 ? 1 : (METHOD == 1 ? 4 : 2);
   __shared__ float slots[2 * EV::kTeam * TeamCombine::DP];
   // blockIdx.y = Monte-Carlo draw
@@ -59,6 +72,9 @@ __global__ __launch_bounds__(64 * EV::kTeam) void rollout_bwd_team_kernel(const 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   EV ev;
   ev.init(pack, M, S, slots, wave, lane);
+  using GR = typename GradsOf<EV, PG>::type;
+  GR G;
+  if constexpr (PG) G.zero();
   const float third = (float)(1.0 / 3.0);
   for (int n = blockIdx.x; n < N; n += gridDim.x) {
     const float* gz = gzt + (size_t)n * T * DI;
@@ -76,7 +92,7 @@ __global__ __launch_bounds__(64 * EV::kTeam) void rollout_bwd_team_kernel(const 
         float a1[DI];
 #pragma unroll
         for (int i = 0; i < DI; ++i) { a1[i] = dt * lam[i]; x[i] = xt[i]; }
-        ode_vjp<EV, DI, DO, ORDER>(ev, x, a1, g, af);
+        ode_vjp<EV, DI, DO, ORDER, GR>(ev, x, a1, g, af, &G);
         if (wave == 0) store_vec<DO>(at, af, lane);
 #pragma unroll
         for (int i = 0; i < DI; ++i) lam[i] += g[i];
@@ -85,11 +101,11 @@ __global__ __launch_bounds__(64 * EV::kTeam) void rollout_bwd_team_kernel(const 
         float a1[DI], a2[DI], ay[DI];
 #pragma unroll
         for (int i = 0; i < DI; ++i) { a2[i] = dt * lam[i]; x[i] = xt[DI + i]; }
-        ode_vjp<EV, DI, DO, ORDER>(ev, x, a2, g, af);
+        ode_vjp<EV, DI, DO, ORDER, GR>(ev, x, a2, g, af, &G);
         if (wave == 0) store_vec<DO>(at + DO, af, lane);
 #pragma unroll
         for (int i = 0; i < DI; ++i) { ay[i] = lam[i] + g[i]; a1[i] = 0.5f * dt * g[i]; x[i] = xt[i]; }
-        ode_vjp<EV, DI, DO, ORDER>(ev, x, a1, g, af);
+        ode_vjp<EV, DI, DO, ORDER, GR>(ev, x, a1, g, af, &G);
         if (wave == 0) store_vec<DO>(at, af, lane);
 #pragma unroll
         for (int i = 0; i < DI; ++i) lam[i] = ay[i] + g[i];
@@ -103,25 +119,25 @@ __global__ __launch_bounds__(64 * EV::kTeam) void rollout_bwd_team_kernel(const 
         }
 #pragma unroll
         for (int i = 0; i < DI; ++i) x[i] = xt[3 * DI + i];
-        ode_vjp<EV, DI, DO, ORDER>(ev, x, a4, g, af);
+        ode_vjp<EV, DI, DO, ORDER, GR>(ev, x, a4, g, af, &G);
         if (wave == 0) store_vec<DO>(at + 3 * DO, af, lane);
 #pragma unroll
         for (int i = 0; i < DI; ++i) { ay[i] += g[i]; a1[i] += dt * g[i]; a2[i] -= dt * g[i]; a3[i] += dt * g[i]; }
 #pragma unroll
         for (int i = 0; i < DI; ++i) x[i] = xt[2 * DI + i];
-        ode_vjp<EV, DI, DO, ORDER>(ev, x, a3, g, af);
+        ode_vjp<EV, DI, DO, ORDER, GR>(ev, x, a3, g, af, &G);
         if (wave == 0) store_vec<DO>(at + 2 * DO, af, lane);
 #pragma unroll
         for (int i = 0; i < DI; ++i) { ay[i] += g[i]; a2[i] += dt * g[i]; a1[i] -= dt * third * g[i]; }
 #pragma unroll
         for (int i = 0; i < DI; ++i) x[i] = xt[1 * DI + i];
-        ode_vjp<EV, DI, DO, ORDER>(ev, x, a2, g, af);
+        ode_vjp<EV, DI, DO, ORDER, GR>(ev, x, a2, g, af, &G);
         if (wave == 0) store_vec<DO>(at + 1 * DO, af, lane);
 #pragma unroll
         for (int i = 0; i < DI; ++i) { ay[i] += g[i]; a1[i] += dt * third * g[i]; }
 #pragma unroll
         for (int i = 0; i < DI; ++i) x[i] = xt[i];
-        ode_vjp<EV, DI, DO, ORDER>(ev, x, a1, g, af);
+        ode_vjp<EV, DI, DO, ORDER, GR>(ev, x, a1, g, af, &G);
         if (wave == 0) store_vec<DO>(at, af, lane);
 #pragma unroll
         for (int i = 0; i < DI; ++i) lam[i] = ay[i] + g[i];
@@ -130,6 +146,21 @@ __global__ __launch_bounds__(64 * EV::kTeam) void rollout_bwd_team_kernel(const 
       for (int i = 0; i < DI; ++i) lam[i] += gz[(size_t)t * DI + i];
     }
     if (wave == 0) store_vec<DI>(gz0 + (size_t)n * DI, lam, lane);
+  }
+  if constexpr (PG) {
+    float* out = slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * pack_floats;
+    if constexpr (std::is_same<EV, RbfTeamEval<DI, DO, 1>>::value) {
+      using L = RbfLayout<DI, DO>;
+      __shared__ __attribute__((aligned(16))) float sInd[2][64][4 * L::RQ2];
+      __shared__ float sUni[TEAM][((DO + 1) / 2) * DI];
+      store_grads_rbf<DI, DO, 1>(G, out, M, S, wave, lane, sInd, sUni);
+    } else {
+      using L = DfLayout<DO>;
+      constexpr int DH = (DO + 1) / 2;
+      __shared__ __attribute__((aligned(16))) float sInd[2][64][4 * L::RQ2];
+      __shared__ float sUni[TEAM][2 * DO * DH + DH];
+      store_grads_df<DO, 1>(G, out, M, S, wave, lane, sInd, sUni);
+    }
   }
 }
 
@@ -161,35 +192,13 @@ __device__ __forceinline__ void st4(float* __restrict__ base, size_t f4_index, c
   reinterpret_cast<float4*>(base)[f4_index] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// this workgroup's gradient sums -> its slab (pack layout); shared by the parameter-sum kernel and the PGRAD reverse sweep
 template <int DI, int DO, int NJ>
-__global__ __launch_bounds__(256) void param_grad_rbf_kernel(const float* __restrict__ pack, int M, int S,
-                                                              const float* __restrict__ xr, const float* __restrict__ ar,
-                                                              int R, int rows_per_chunk, float* __restrict__ slab,
-                                                              size_t pack_floats, int prior_only, Draws dw, int slab_chunks) {
-  // blockIdx.y = Monte-Carlo draw: its pack, its rows, its chunk slabs
-  pack += blockIdx.y * dw.pack; xr += blockIdx.y * dw.in; ar += blockIdx.y * dw.in2; slab += (size_t)blockIdx.y * slab_chunks * pack_floats;
-  using EV = RbfTeamEval<DI, DO, NJ>;
+__device__ __forceinline__ void store_grads_rbf(const typename RbfTeamEval<DI, DO, NJ>::Grads& G, float* __restrict__ out, int M, int S,
+                                                int wave, int lane, float (*sInd)[64][4 * RbfLayout<DI, DO>::RQ2],
+                                                float (*sUni)[((DO + 1) / 2) * DI]) {
   using L = RbfLayout<DI, DO>;
   constexpr int DH = (DO + 1) / 2;
-  __shared__ float slots[2 * TEAM * TeamCombine::DP];
-  __shared__ __attribute__((aligned(16))) float sInd[2][64][4 * L::RQ2];
-  __shared__ float sUni[TEAM][DH * DI];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  EV ev;
-  ev.init(pack, M, S, slots, wave, lane);
-  typename EV::Grads G;
-  G.zero();
-  const int r0 = blockIdx.x * rows_per_chunk;
-  const int r1 = min(R, r0 + rows_per_chunk);
-  for (int r = r0; r < r1; ++r) {
-    float x[DI], a[DO];
-#pragma unroll
-    for (int i = 0; i < DI; ++i) x[i] = xr[(size_t)r * DI + i];
-#pragma unroll
-    for (int i = 0; i < DO; ++i) a[i] = ar[(size_t)r * DO + i];
-    ev.grad_row(x, a, G, prior_only != 0);
-  }
-  float* out = slab + (size_t)blockIdx.x * pack_floats;
   const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
 #pragma unroll
   for (int jn = 0; jn < NJ; ++jn) {
@@ -235,20 +244,19 @@ __global__ __launch_bounds__(256) void param_grad_rbf_kernel(const float* __rest
   }
 }
 
-template <int D, int NJ>
-__global__ __launch_bounds__(256) void param_grad_df_kernel(const float* __restrict__ pack, int M, int S,
-                                                             const float* __restrict__ xr, const float* __restrict__ ar,
-                                                             int R, int rows_per_chunk, float* __restrict__ slab,
-                                                             size_t pack_floats, int prior_only, Draws dw, int slab_chunks) {
+template <int DI, int DO, int NJ>
+__global__ __launch_bounds__(256) void param_grad_rbf_kernel(const float* __restrict__ pack, int M, int S,
+                                                              const float* __restrict__ xr, const float* __restrict__ ar,
+                                                              int R, int rows_per_chunk, float* __restrict__ slab,
+                                                              size_t pack_floats, int prior_only, Draws dw, int slab_chunks) {
   // blockIdx.y = Monte-Carlo draw: its pack, its rows, its chunk slabs
   pack += blockIdx.y * dw.pack; xr += blockIdx.y * dw.in; ar += blockIdx.y * dw.in2; slab += (size_t)blockIdx.y * slab_chunks * pack_floats;
-  using EV = DfTeamEval<D, NJ>;
-  using L = DfLayout<D>;
-  constexpr int DH = (D + 1) / 2;
-  constexpr int NU = 2 * D * DH + DH;  // gwab, gil2, gvar partials of one wave
+  using EV = RbfTeamEval<DI, DO, NJ>;
+  using L = RbfLayout<DI, DO>;
+  constexpr int DH = (DO + 1) / 2;
   __shared__ float slots[2 * TEAM * TeamCombine::DP];
   __shared__ __attribute__((aligned(16))) float sInd[2][64][4 * L::RQ2];
-  __shared__ float sUni[TEAM][NU];
+  __shared__ float sUni[TEAM][DH * DI];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   EV ev;
   ev.init(pack, M, S, slots, wave, lane);
@@ -257,12 +265,23 @@ __global__ __launch_bounds__(256) void param_grad_df_kernel(const float* __restr
   const int r0 = blockIdx.x * rows_per_chunk;
   const int r1 = min(R, r0 + rows_per_chunk);
   for (int r = r0; r < r1; ++r) {
-    float x[D], a[D];
+    float x[DI], a[DO];
 #pragma unroll
-    for (int i = 0; i < D; ++i) { x[i] = xr[(size_t)r * D + i]; a[i] = ar[(size_t)r * D + i]; }
+    for (int i = 0; i < DI; ++i) x[i] = xr[(size_t)r * DI + i];
+#pragma unroll
+    for (int i = 0; i < DO; ++i) a[i] = ar[(size_t)r * DO + i];
     ev.grad_row(x, a, G, prior_only != 0);
   }
-  float* out = slab + (size_t)blockIdx.x * pack_floats;
+  store_grads_rbf<DI, DO, NJ>(G, slab + (size_t)blockIdx.x * pack_floats, M, S, wave, lane, sInd, sUni);
+}
+
+template <int D, int NJ>
+__device__ __forceinline__ void store_grads_df(const typename DfTeamEval<D, NJ>::Grads& G, float* __restrict__ out, int M, int S, int wave,
+                                               int lane, float (*sInd)[64][4 * DfLayout<D>::RQ2],
+                                               float (*sUni)[2 * D * ((D + 1) / 2) + (D + 1) / 2]) {
+  using L = DfLayout<D>;
+  constexpr int DH = (D + 1) / 2;
+  constexpr int NU = 2 * D * DH + DH;
   const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
 #pragma unroll
   for (int jn = 0; jn < NJ; ++jn) {
@@ -317,6 +336,36 @@ __global__ __launch_bounds__(256) void param_grad_df_kernel(const float* __restr
       uni_out[2 * D * D + t] = sUni[h][2 * D * DH + bb] + sUni[h + 2][2 * D * DH + bb];
     }
   }
+}
+
+template <int D, int NJ>
+__global__ __launch_bounds__(256) void param_grad_df_kernel(const float* __restrict__ pack, int M, int S,
+                                                             const float* __restrict__ xr, const float* __restrict__ ar,
+                                                             int R, int rows_per_chunk, float* __restrict__ slab,
+                                                             size_t pack_floats, int prior_only, Draws dw, int slab_chunks) {
+  // blockIdx.y = Monte-Carlo draw: its pack, its rows, its chunk slabs
+  pack += blockIdx.y * dw.pack; xr += blockIdx.y * dw.in; ar += blockIdx.y * dw.in2; slab += (size_t)blockIdx.y * slab_chunks * pack_floats;
+  using EV = DfTeamEval<D, NJ>;
+  using L = DfLayout<D>;
+  constexpr int DH = (D + 1) / 2;
+  constexpr int NU = 2 * D * DH + DH;  // gwab, gil2, gvar partials of one wave
+  __shared__ float slots[2 * TEAM * TeamCombine::DP];
+  __shared__ __attribute__((aligned(16))) float sInd[2][64][4 * L::RQ2];
+  __shared__ float sUni[TEAM][NU];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  EV ev;
+  ev.init(pack, M, S, slots, wave, lane);
+  typename EV::Grads G;
+  G.zero();
+  const int r0 = blockIdx.x * rows_per_chunk;
+  const int r1 = min(R, r0 + rows_per_chunk);
+  for (int r = r0; r < r1; ++r) {
+    float x[D], a[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { x[i] = xr[(size_t)r * D + i]; a[i] = ar[(size_t)r * D + i]; }
+    ev.grad_row(x, a, G, prior_only != 0);
+  }
+  store_grads_df<D, NJ>(G, slab + (size_t)blockIdx.x * pack_floats, M, S, wave, lane, sInd, sUni);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -661,6 +710,51 @@ int rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S,
 #undef X
   }
   return set_error("gpode_rollout_bwd: no specialisation for kernel=%d Di=%d Do=%d", kernel, Di, Do);
+}
+
+// ---- reverse sweep + parameter sums in one pass (rollout_bwd_team_kernel<..., PG = true>) --------------------------------------
+// Built for the first-order register-resident teams of the widths below and the Euler / 3-8-rule solvers; pgrad_chunks() = 0 for
+// every other shape: the caller then runs rollout_bwd and param_grad separately.
+// (RBF widths up to 6: 376 registers at q = 6 with the 3/8 rule.  q = 8 spills 181 registers, and the divergence-free kernel, whose
+//  parameter-sum kernel alone takes 432, spills 945 -- besides, at configs[1] its sums (168 us) sit on the side branch, and moving them
+//  into the main branch's sweep lengthens the chain the encoder's backward follows by about what the side branch gets shorter)
+#define GP_PGRAD_RBF_DIMS(X) X(6) X(4) X(2) X(3)
+int rollout_bwd_pgrad_chunks(int kernel, int order, int method, int Di, int Do, int M, int S, int N) {
+  if (order != 1 || Di != Do || (method != 0 && method != 1) || N < 1) return 0;
+  if (kernel == 0) {
+#define X(d) if (Do == d) return rbf_team_ok<d, d>(M, S) ? team_grid_b(N) : 0;
+    GP_PGRAD_RBF_DIMS(X)
+#undef X
+  }
+  return 0;
+}
+int rollout_bwd_pgrad(int kernel, int order, int method, int Di, int Do, int M, int S, const float* pack, const float* xstage,
+                      const float* gzt, const float* ts, int N, int T, float* gz0, float* astage, float* slab, int nchunk,
+                      float* gpack, hipStream_t st, Draws dw) {
+  const int grid = rollout_bwd_pgrad_chunks(kernel, order, method, Di, Do, M, S, N);
+  if (grid == 0) return set_error("gpode_rollout_bwd_pgrad: no fused form for kernel=%d order=%d method=%d Di=%d Do=%d M=%d S=%d", kernel, order,
+                                  method, Di, Do, M, S);
+  if (nchunk != grid) return set_error("gpode_rollout_bwd_pgrad: slab for %d chunks, the launch has %d", nchunk, grid);
+  size_t pf = 0;
+  if (cache_sizes(kernel, Di, Do, M, S, &pf, nullptr)) return 1;
+  bool done = false;
+  if (kernel == 0) {
+#define X(d)                                                                                                                         \
+  if (Do == d) {                                                                                                                     \
+    if (method == 0) hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfTeamEval<d, d, 1>, d, d, 1, 0, true>), dim3(grid, dw.nd), 256, 0, st, \
+                                        pack, M, S, xstage, gzt, ts, N, T, gz0, astage, dw, slab, pf);                               \
+    else hipLaunchKernelGGL((rollout_bwd_team_kernel<RbfTeamEval<d, d, 1>, d, d, 1, 1, true>), dim3(grid, dw.nd), 256, 0, st,        \
+                            pack, M, S, xstage, gzt, ts, N, T, gz0, astage, dw, slab, pf);                                           \
+    done = true;                                                                                                                     \
+  }
+    GP_PGRAD_RBF_DIMS(X)
+#undef X
+  }
+  if (!done) return set_error("gpode_rollout_bwd_pgrad: width %d not built", Do);
+  if (check_launch("rollout_bwd_pgrad")) return 1;
+  // the chunk slabs -> the pack-layout gradient of every draw (dw.out2 is astage's draw stride; gpack is dense per draw)
+  hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((pf + 63) / 64), dw.nd), 1024, 0, st, slab, grid, pf, gpack, 0, pf, grid);
+  return check_launch("reduce_slab");
 }
 
 template <int DI, int DO>

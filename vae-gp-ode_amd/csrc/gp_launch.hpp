@@ -72,6 +72,10 @@ int rollout_fwd(int kernel, int order, int method, int Di, int Do, int M, int S,
                 const float* z0, const float* ts, int N, int T, float* zt, float* xstage, hipStream_t st, Draws dw = Draws{});
 int rollout_bwd(int kernel, int order, int method, int Di, int Do, int M, int S, const float* pack, const float* xstage,
                 const float* gzt, const float* ts, int N, int T, float* gz0, float* astage, hipStream_t st, Draws dw = Draws{});
+int rollout_bwd_pgrad_chunks(int kernel, int order, int method, int Di, int Do, int M, int S, int N);
+int rollout_bwd_pgrad(int kernel, int order, int method, int Di, int Do, int M, int S, const float* pack, const float* xstage,
+                      const float* gzt, const float* ts, int N, int T, float* gz0, float* astage, float* slab, int nchunk,
+                      float* gpack, hipStream_t st, Draws dw = Draws{});
 int rhs_vjp(int kernel, int Di, int Do, int M, int S, const float* pack, const float* x, const float* a, int R, float* gx,
             int prior_only, hipStream_t st, Draws dw = Draws{});
 int param_grad(int kernel, int Di, int Do, int M, int S, const float* pack, const float* xr, const float* ar, int R,

@@ -126,6 +126,19 @@ template <int DI, int DO, int NJ> struct RbfTeamEval {
     for (int r = 0; r < NJ * DO; ++r) rbf_rff_bwd<DI, DO, true>(rff[r], x, a[r % DO], gx, G.rff[r]);
     if (!prior_only) rbf_ind_half_bwd<DI, DO, true>(ind, x, wl, half, a, gx, G.ind, G.gwl);
   }
+  // vjp() and grad_row() in one pass over the records: the reverse sweep of the integrator visits every (x, a) row anyway, and
+  // the parameter sums need nothing else (one launch, and one pass over the rows, less)
+  __device__ __forceinline__ void vjp_grad(const float (&x)[DI], const float (&a)[DO], float (&gx)[DI], Grads& G) {
+    float acc[DI];
+#pragma unroll
+    for (int i = 0; i < DI; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < NJ * DO; ++r) rbf_rff_bwd<DI, DO, true>(rff[r], x, a[r % DO], acc, G.rff[r]);
+    rbf_ind_half_bwd<DI, DO, true>(ind, x, wl, half, a, acc, G.ind, G.gwl);
+    float part[DI];
+    wave_sum_all<DI>(acc, part);
+    comb.run<DI>(part, gx);
+  }
 };
 
 template <int D, int NJ> struct DfTeamEval {
@@ -208,6 +221,17 @@ template <int D, int NJ> struct DfTeamEval {
 #pragma unroll
     for (int r = 0; r < NJ * D; ++r) df_rff_bwd<D, true>(rff[r], x, a, gx, G.rff[r]);
     if (!prior_only) df_ind_half_bwd<D, true>(ind, x, uni, half, a, gx, G.ind, G.gwab, G.gil2, G.gvar);
+  }
+  __device__ __forceinline__ void vjp_grad(const float (&x)[D], const float (&a)[D], float (&gx)[D], Grads& G) {
+    float acc[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < NJ * D; ++r) df_rff_bwd<D, true>(rff[r], x, a, acc, G.rff[r]);
+    df_ind_half_bwd<D, true>(ind, x, uni, half, a, acc, G.ind, G.gwab, G.gil2, G.gvar);
+    float part[D];
+    wave_sum_all<D>(acc, part);
+    comb.run<D>(part, gx);
   }
 };
 

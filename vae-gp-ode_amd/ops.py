@@ -348,6 +348,39 @@ def rollout_bwd(cache, xstage, gzt, ts, order, method):
     return gz0, ast
 
 
+# The fused form is OFF by default (GPODE_FUSED_PGRAD=1 switches it on): measured at configs[0] it LENGTHENS the step, 0.737 -> 0.757 ms
+# -- the sweep is a latency-bound chain of one workgroup per trajectory, and the parameter terms (376 registers at q = 6) add more to
+# every one of its 60 dependent rows than the parameter-sum kernel costs on the side branch; configs[3] (256 trajectories): no difference.
+_FUSED_PGRAD = os.environ.get('GPODE_FUSED_PGRAD', '0') == '1'
+
+
+def pgrad_chunks(cache, N, order, method, force=False):
+    """Chunk slabs the fused reverse sweep + parameter sums would use for N trajectories; 0: this shape has no fused form (or the
+    fused form is switched off and ``force`` is not set)."""
+    if not (_FUSED_PGRAD or force):
+        return 0
+    return _lib.load().gpode_rollout_bwd_pgrad_chunks(KERNEL_ID[cache.kernel], order, METHOD_ID[method], cache.Di, cache.Do, cache.M,
+                                                      cache.S, int(N))
+
+
+def rollout_bwd_pgrad(cache, xstage, gzt, ts, order, method, nchunk, keep=None):
+    """rollout_bwd() and param_grad() in one pass over the rows (gpode_rollout_bwd_pgrad_n): -> gz0, astage, gpack ([L,] pack_floats)."""
+    gzt = _chk(gzt, 'gzt'); xstage = _chk(xstage, 'xstage'); ts = _chk(ts, 'ts')
+    lead = cache.lead
+    N, T, D = gzt.shape[-3:]
+    pf = cache.pack.shape[-1]
+    gz0 = torch.empty(lead + (N, D), dtype=torch.float32, device=gzt.device)
+    ast = torch.empty(lead + (N, T - 1, NSTAGE[method], cache.Do), dtype=torch.float32, device=gzt.device)
+    slab = torch.empty(cache.nd * nchunk * pf, dtype=torch.float32, device=gzt.device)
+    gpack = torch.empty(lead + (pf,), dtype=torch.float32, device=gzt.device)
+    _lib.call('gpode_rollout_bwd_pgrad_n', KERNEL_ID[cache.kernel], order, METHOD_ID[method], cache.Di, cache.Do, cache.M, cache.S,
+              cache.nd, _ptr(cache.pack), _ptr(xstage), _ptr(gzt), _ptr(ts), N, T, _ptr(gz0), _ptr(ast), _ptr(slab), nchunk, _ptr(gpack),
+              _stream())
+    if keep is not None:
+        keep.append(slab)
+    return gz0, ast, gpack
+
+
 def rhs_vjp(cache, x, a):
     """gx = J_f(x)^T a for rows x (R,Di), a (R,Do)."""
     x = _chk(x, 'x'); a = _chk(a, 'a')
@@ -569,10 +602,18 @@ class _Flow(torch.autograd.Function):
         ts, xs, raw_ell, raw_var, Z = ctx.saved_tensors
         c = ctx.cache
         lead = c.lead
-        gz0, ast = rollout_bwd(c, xs, gzt.contiguous(), ts, ctx.order, ctx.method)
+        want_p = any(ctx.needs_input_grad[2:7])
+        # the reverse sweep visits every (stage input, adjoint) row: where a fused form exists the rows' parameter-gradient terms are
+        # summed on the way, and the side branch below starts with the pack gradient instead of with a pass over the rows
+        nch = pgrad_chunks(c, gzt.shape[-3], ctx.order, ctx.method) if want_p else 0
+        gpack_f = None
+        if nch:
+            gz0, ast, gpack_f = rollout_bwd_pgrad(c, xs, gzt.contiguous(), ts, ctx.order, ctx.method, nch)
+        else:
+            gz0, ast = rollout_bwd(c, xs, gzt.contiguous(), ts, ctx.order, ctx.method)
         if c.stacked:
             gz0 = gz0.sum(0)                         # every draw starts from the same z0 (odegpvae.py:42)
-        if not any(ctx.needs_input_grad[2:7]):
+        if not want_p:
             return (gz0,) + (None,) * 10
         leaves = all(p.is_leaf and p.requires_grad for p in ctx.params) and all(ctx.needs_input_grad[2:7])
         if _overlap['on'] and leaves:
@@ -584,7 +625,8 @@ class _Flow(torch.autograd.Function):
             if kl is not None and kl[0][0].data_ptr() == ctx.params[3].data_ptr() and kl[0][1].data_ptr() == ctx.params[4].data_ptr():
                 add_to, _overlap['kl'] = kl[1], None  # the KL gradients of (Um, Us): the cache backward adds the flow's to them
             with launch_on(side):
-                gpack = param_grad(c, xs.reshape(lead + (-1, c.Di)), ast.reshape(lead + (-1, c.Do)), keep=scratch)
+                gpack = gpack_f if gpack_f is not None else param_grad(c, xs.reshape(lead + (-1, c.Di)), ast.reshape(lead + (-1, c.Do)),
+                                                                        keep=scratch)
                 g = cache_build_bwd(c, raw_ell, raw_var, Z, gpack, prepared=ctx.prepared, add_to=add_to)
             grads = [g['raw_ell'], g['raw_var'], g['Z'], g['Um'], g['Us']]
             # every buffer a side-stream kernel touches stays referenced until join_side_stream(): the allocator would
@@ -594,7 +636,7 @@ class _Flow(torch.autograd.Function):
             return (gz0,) + (None,) * 10
         if ctx.prepared is not None:
             torch.cuda.current_stream().wait_stream(side_stream())
-        gpack = param_grad(c, xs.reshape(lead + (-1, c.Di)), ast.reshape(lead + (-1, c.Do)))
+        gpack = gpack_f if gpack_f is not None else param_grad(c, xs.reshape(lead + (-1, c.Di)), ast.reshape(lead + (-1, c.Do)))
         g = cache_build_bwd(c, raw_ell, raw_var, Z, gpack, prepared=ctx.prepared)
         return (gz0, None, g['raw_ell'], g['raw_var'], g['Z'], g['Um'], g['Us'], None, None, None, None)
 
