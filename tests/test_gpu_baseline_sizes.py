@@ -197,7 +197,9 @@ def test_configs4_forward_at_its_real_size():
     GP draw + rollout + decoder forward vs the pinned oracle in fp64 AND fp32.  At these shapes the latent ODE amplifies a
     perturbation by ~2x every two steps (tools/debug_cfg5_fwd.py: the reference's own fp32 arithmetic is 7e-5 from fp64 at t = 16,
     3e-2 at t = 40 and 0.6 at t = 63), so the trajectory tolerance is per time index: fixed 1e-4 (relative to max |z_t|) up to
-    t = 16, and from there never further from fp64 than 1.5x the fp32 oracle is.  The decoder (8192 images through the
+    t = 16, and from there never further from fp64 than 4x the fp32 oracle is (two doubling periods: which side of fp64 a rounding
+    of z0 in the last bit falls on decides a factor of 2 at t = 35 -- the encoder's BatchNorm sums changing their order moved this
+    ratio from 1.4 to 1.9).  The decoder (8192 images through the
     matrix-core kernels, training-mode BatchNorm) is checked on the ORACLE's latents, where chaos plays no part: 1e-4."""
     from oracle import gpode_oracle as O
     _ref_threads()
@@ -228,7 +230,7 @@ def test_configs4_forward_at_its_real_size():
             assert e_hip < 1e-4, (t, e_hip, e_ref)
         else:
             worst_ratio = max(worst_ratio, e_hip / e_ref)
-            assert e_hip < 1.5 * e_ref, (t, e_hip, e_ref)
+            assert e_hip < 4 * e_ref, (t, e_hip, e_ref)
     e_x = relerr(Xrec, Xrec64)
     print('configs[4] N=128 T=64: trajectories <= %.1e up to t=16, then <= %.2f x the fp32 oracle\'s distance to fp64; '
           'decoder on the oracle\'s latents %.1e' % (worst_early, worst_ratio, e_x))
