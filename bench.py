@@ -399,12 +399,21 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
     #     gradient all-reduce and Adam eager between replays; off launches everything eagerly).
     #   N > 1 over gloo (rehearsal on one card): gloo's collectives are host code and cannot be captured -- forward + backward
     #     are replayed when they hold no collective (--no-sync-bn), otherwise the step runs eagerly.
+    # what one step asks of the interconnect: count and payload of its collectives.  Counted while the step function runs as Python
+    # anyway (GraphedStep's warm-up steps and its capture pass, or the first eager step) -- NOT in an eager step of its own on the
+    # default stream ahead of the capture: that pins autograd's AccumulateGrad nodes to the default stream, the captured backward
+    # then synchronises with it, and hipStreamEndCapture dies on the unjoined stream (a segmentation fault, not an error).
     coll = None
-    if sync is not None:                             # what one step asks of the interconnect: count and payload of its collectives
+    n_counted = [0]
+    if sync is not None:
         from vae_gp_ode_amd import parallel
-        with parallel.stats.step():
-            eager_step()
-        coll = parallel.stats.summary()
+        parallel.stats.per_step, parallel.stats.on = {}, True
+
+    def counted(fn):
+        def run():
+            n_counted[0] += 1
+            return fn()
+        return run if sync is not None else fn
     step, graphed, mode = eager_step, False, 'eager'
     if not a.no_graph:
         if sync is None:
@@ -418,12 +427,12 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
             from vae_gp_ode_amd.graph import GraphedStep, device_generators
             gens = device_generators(model)
             if mode == 'whole':
-                g = GraphedStep(whole_step if sync is None else dp_step, generators=gens, warmup=2)
+                g = GraphedStep(counted(whole_step if sync is None else dp_step), generators=gens, warmup=2)
 
                 def step():
                     last['loss'] = g()
             else:
-                g = GraphedStep(fwd_bwd, generators=gens, warmup=2, grad_params=opt.params)
+                g = GraphedStep(counted(fwd_bwd), generators=gens, warmup=2, grad_params=opt.params)
 
                 def step():
                     last['loss'] = g()
@@ -436,6 +445,16 @@ def run_elbo(a, w, dev, rank, n_gpus, dist, barrier):
             print('[bench] HIP graph capture failed (%s); running the step eagerly' % type(e).__name__, file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             step, mode = eager_step, 'eager (capture failed)'
+    if sync is not None:
+        from vae_gp_ode_amd import parallel
+        if n_counted[0] == 0:                        # no graph: the first eager step is the counted one
+            eager_step()
+            n_counted[0] = 1
+        parallel.stats.on = False
+        coll = {k: {'count': v['count'] // n_counted[0], 'payload_bytes': v['payload_bytes'] // n_counted[0]}
+                for k, v in parallel.stats.summary().items()}
+        if mode == 'fwdbwd':                         # the gradient all-reduce stays between the replays: one per step
+            coll.setdefault('all_reduce', {'count': 1, 'payload_bytes': int(opt.flat_grads.flat.numel() * 4)})
     for _ in range(a.warmup):
         step()
     barrier()
