@@ -202,18 +202,26 @@ __device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int
   }
 }
 
-template <int IPB, int MODE>
+// WGRAD (MODE 0 only): the layer's WEIGHT gradient rides in the sums pass -- it reads the same c (as relu(bn(c)), the layer's input) and
+// the same gy plane, in the same lane layout k_wgrad uses (A = the lane's four pixels of channel lr, B = the gy window of tap 16 c + lr):
+// 8 more MFMAs per tile in a pass that waits for HBM, instead of a pass of its own over c.  part_w[workgroup][CI * KK].
+template <int IPB, int MODE, bool WGRAD = false>
 __global__ __launch_bounds__(512, 4) void k_bwd_data_bn(const float* __restrict__ gy, const float* __restrict__ w, const float* __restrict__ x,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd, int B,
                                                         float* __restrict__ part,                       // MODE 0: out; MODE 1: in
                                                         int nsplit, float count, const float* __restrict__ gathered,
                                                         const float* __restrict__ wts, int W, float* __restrict__ ggamma,
-                                                        float* __restrict__ gbeta, float* __restrict__ gx, float* __restrict__ part_gx) {
+                                                        float* __restrict__ gbeta, float* __restrict__ gx, float* __restrict__ part_gx,
+                                                        float* __restrict__ part_w = nullptr) {
+  static_assert(!WGRAD || MODE == 0, "the weight gradient rides in the sums pass");
   float* s_g = igemm_smem;                           // [IPB][32][32], index = o + 2, zero borders
   float* s_red = s_g + IPB * PLANE;                  // [8][4][CI][2]
   float* s_A = s_red + 8 * 4 * CI * 2;               // [CI] sum g  (MODE 1)
   float* s_B = s_A + CI;                             // [CI] sum g xhat
+  float* s_wred = s_B + CI;                          // WGRAD: [8][CI][32] (the launch adds the room)
+  int toffw[2];                                      // WGRAD: window offset of tap 16 c + lr (taps >= 25 alias tap 24, dropped at the end)
+  f32x4 accw[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
   constexpr int NKS = (KK + 3) / 4;
@@ -231,6 +239,11 @@ __global__ __launch_bounds__(512, 4) void k_bwd_data_bn(const float* __restrict_
     toff[ks] = tap < KK ? (tap / 5) * WP + tap % 5 : 0;
   }
   const float cm = mean[lr], cis = invstd[lr], cg = gamma[lr], cbt = beta[lr], sc = cg * cis;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int tap = min(16 * c + lr, KK - 1);
+    toffw[c] = (tap / 5) * WP + tap % 5;
+  }
   float ca = 0.f, cb = 0.f;
   if (MODE == 1) {
     reduce_parts(part, nsplit, s_A, s_B);
@@ -316,6 +329,17 @@ __global__ __launch_bounds__(512, 4) void k_bwd_data_bn(const float* __restrict_
           }
           if (MODE == 1)
             *reinterpret_cast<float4*>(gx + ((size_t)(b0 + im) * CI + lr) * NP + (t % NTILE) * 16 + 4 * lk) = float4{o[0], o[1], o[2], o[3]};
+          if constexpr (WGRAD) {
+            // gw[ci = lr][tap] += relu(bn(c))[ci][pixel] gy[window(pixel, tap)]: MFMA i takes the lane's i-th pixel as its k-slot
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int p = (t % NTILE) * 16 + 4 * lk + i;
+              const float* gq = s_g + im * PLANE + (p / H) * WP + p % H;
+              const float av = fmaxf(__fmaf_rn(bn_xhat(xs[i], cm, cis), cg, cbt), 0.f);
+              accw[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, gq[toffw[0]], accw[0], 0, 0, 0);
+              accw[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, gq[toffw[1]], accw[1], 0, 0, 0);
+            }
+          }
         }
       }
     }
@@ -330,6 +354,21 @@ __global__ __launch_bounds__(512, 4) void k_bwd_data_bn(const float* __restrict_
 #pragma unroll
     for (int q = 0; q < 32; ++q) v += s_red[q * CI * 2 + tid];
     outp[(size_t)blockIdx.x * CI * 2 + tid] = v;
+  }
+  if constexpr (WGRAD) {
+    // D[m = ci][n = tap]: lane holds tap 16 c + lr, ci = 4 lk + r; the 8 wavefronts in a fixed order (as k_wgrad)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_wred[(wave * CI + 4 * lk + r) * 32 + 16 * c + lr] = accw[c][r];
+    __syncthreads();
+    for (int e = tid; e < CI * KK; e += 512) {
+      const int ci = e / KK, tap = e % KK;
+      float v = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 8; ++wv) v += s_wred[(wv * CI + ci) * 32 + tap];
+      part_w[(size_t)blockIdx.x * (CI * KK) + e] = v;
+    }
   }
 }
 

@@ -608,10 +608,10 @@ __global__ __launch_bounds__(512) void k_dec10_parts_reduce(const float* __restr
   else if (tid < dec10::CI) out[tid] = sA[tid];
 }
 
-template <int IPB, int MODE, typename... A>
+template <int IPB, int MODE, bool WGRAD = false, typename... A>
 static int launch_dec10_bn(int B, hipStream_t st, A... args) {
-  const size_t lds = sizeof(float) * ((size_t)IPB * dec10::PLANE + 8 * 4 * dec10::CI * 2 + 2 * dec10::CI);
-  auto kern = dec10::k_bwd_data_bn<IPB, MODE>;
+  const size_t lds = sizeof(float) * ((size_t)IPB * dec10::PLANE + 8 * 4 * dec10::CI * 2 + 2 * dec10::CI + (WGRAD ? 8 * dec10::CI * 32 : 0));
+  auto kern = dec10::k_bwd_data_bn<IPB, MODE, WGRAD>;
   if (set_max_lds((const void*)kern, lds)) return 1;
   const int ngroups = (B + IPB - 1) / IPB, cap = 2 * num_cus() < kDec10BnMaxWg ? 2 * num_cus() : kDec10BnMaxWg;
   hipLaunchKernelGGL(kern, ngroups < cap ? ngroups : cap, 512, lds, st, args...);
@@ -623,16 +623,23 @@ static int dec10_bn_nwg(int B, int& ipb) {
   return ngroups < cap ? ngroups : cap;
 }
 
+// gw != nullptr: the layer's weight gradient (16 x 25) is produced by the same pass (wscratch: dec10_bn_wgrad_scratch_floats() floats)
+int dec10_bn_wgrad_scratch_floats() { return kDec10BnMaxWg * dec10::CI * dec10::KK; }
 int dec10_bn_bwd_sums(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* mean,
-                      const float* invstd, float* sums, int B, float* scratch, hipStream_t st) {
+                      const float* invstd, float* sums, int B, float* scratch, hipStream_t st, float* gw, float* wscratch) {
   if (((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(c)) & 15) != 0) return set_error("gpode_dec10_bn_bwd_sums: c / gy must be 16-byte aligned");
+  if (gw && !wscratch) return set_error("gpode_dec10_bn_bwd_sums_wgrad: scratch for the weight-gradient partials missing");
   int ipb;
   const int nwg = dec10_bn_nwg(B, ipb);
   float* np_ = nullptr;
   const float* cnp = nullptr;
   int rc;
-  if (ipb == 4) rc = launch_dec10_bn<4, 0>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, 0, 0.f, cnp, cnp, 0, np_, np_, np_, np_);
-  else rc = launch_dec10_bn<2, 0>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, 0, 0.f, cnp, cnp, 0, np_, np_, np_, np_);
+  if (gw) {
+    if (ipb == 4) rc = launch_dec10_bn<4, 0, true>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, 0, 0.f, cnp, cnp, 0, np_, np_, np_, np_, wscratch);
+    else rc = launch_dec10_bn<2, 0, true>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, 0, 0.f, cnp, cnp, 0, np_, np_, np_, np_, wscratch);
+    if (!rc && reduce_job(RedJob{wscratch, gw, nwg, dec10::CI * dec10::KK, 0, 0, 0, 0}, st)) return 1;
+  } else if (ipb == 4) rc = launch_dec10_bn<4, 0>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, 0, 0.f, cnp, cnp, 0, np_, np_, np_, np_, np_);
+  else rc = launch_dec10_bn<2, 0>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, 0, 0.f, cnp, cnp, 0, np_, np_, np_, np_, np_);
   if (rc) return rc;
   if (sums) hipLaunchKernelGGL(k_dec10_parts_reduce, 1, 512, 0, st, scratch, nwg, sums, 1);
   return check_launch("dec10_bn_bwd_sums");
@@ -649,8 +656,8 @@ int dec10_bn_bwd_apply(const float* c, const float* gy, const float* w, const fl
   float* part_gx = gc_chansum ? scratch + (size_t)kDec10BnMaxWg * dec10::CI * 2 : nullptr;
   const float count = gathered ? count_all : (float)B * dec10::NP;
   int rc;
-  if (ipb == 4) rc = launch_dec10_bn<4, 1>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, nwg, count, gathered, wts, W, ggamma, gbeta, gc, part_gx);
-  else rc = launch_dec10_bn<2, 1>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, nwg, count, gathered, wts, W, ggamma, gbeta, gc, part_gx);
+  if (ipb == 4) rc = launch_dec10_bn<4, 1>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, nwg, count, gathered, wts, W, ggamma, gbeta, gc, part_gx, (float*)nullptr);
+  else rc = launch_dec10_bn<2, 1>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, nwg, count, gathered, wts, W, ggamma, gbeta, gc, part_gx, (float*)nullptr);
   if (rc) return rc;
   if (gc_chansum && reduce_job(RedJob{part_gx, gc_chansum, nwg, dec10::CI, 2, 0, 0, 0}, st)) return 1;
   return check_launch("dec10_bn_bwd_apply");

@@ -189,20 +189,27 @@ def batch_norm_train_pair(x1, bn1, x2, bn2, relu):
 _dec10_fused = os.environ.get('GPODE_DEC10_BN_UNFUSED', '0') != '1'
 
 
-def _dec10_bn_bwd(sync, c, gy, w, gamma, beta, mean, invstd):
+_DEC10_WGRAD_FUSED = os.environ.get('GPODE_DEC10_WGRAD_PASS', '0') != '1'
+
+
+def _dec10_bn_bwd(sync, c, gy, w, gamma, beta, mean, invstd, gw=None):
     """decnn.10's input gradient + the BatchNorm/ReLU backward in front of it in two passes over c (include/gpode.h,
-    gpode_dec10_bn_bwd_*): (gc, ggamma, gbeta, channel sums of gc)."""
+    gpode_dec10_bn_bwd_*): (gc, ggamma, gbeta, channel sums of gc).  ``gw`` (a tensor to fill): the layer's weight gradient rides
+    in the first pass (gpode_dec10_bn_bwd_sums_wgrad)."""
     B = c.shape[0]
     scratch = _scratch(_lib.load().gpode_dec10_bn_scratch_floats(), c)
     gc, gg, gb, cs = _new(c.shape, c), _new((16,), c), _new((16,), c), _new((16,), c)
     head = (_ptr(c), _ptr(gy), _ptr(w), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(invstd))
+    sums = _new((32,), c) if sync is not None else None
+    if gw is not None:
+        ws = _scratch(_lib.load().gpode_dec10_bn_wgrad_scratch_floats(), c)
+        _bwd_call('gpode_dec10_bn_bwd_sums_wgrad', *head, _ptr(sums), _ptr(gw), B, _ptr(scratch), _ptr(ws), _stream(), keep=(ws, scratch))
+    else:
+        _lib.call('gpode_dec10_bn_bwd_sums', *head, _ptr(sums), B, _ptr(scratch), _stream())
     if sync is None:
-        _lib.call('gpode_dec10_bn_bwd_sums', *head, _ptr(None), B, _ptr(scratch), _stream())
         _bwd_call('gpode_dec10_bn_bwd_apply', *head, _ptr(None), _ptr(None), 0, ctypes.c_float(0.0), _ptr(gc), _ptr(gg), _ptr(gb), _ptr(cs),
                   B, _ptr(scratch), _stream(), keep=(scratch,))
     else:
-        sums = _new((32,), c)
-        _lib.call('gpode_dec10_bn_bwd_sums', *head, _ptr(sums), B, _ptr(scratch), _stream())
         gathered = sync.gather(sums)
         _bwd_call('gpode_dec10_bn_bwd_apply', *head, _ptr(gathered), _ptr(sync.weights(c.device)), sync.world,
                   ctypes.c_float(sync.count_all(B * 784)), _ptr(gc), _ptr(gg), _ptr(gb), _ptr(cs), B, _ptr(scratch), _stream(), keep=(scratch,))
@@ -399,19 +406,22 @@ class _BnReluConvT(torch.autograd.Function):
         ops.side_heartbeat()
         gy = gy.contiguous()
         gw = gb = None
+        last_stage = _dec10_fused and (Cout, Cin, K, S, P, Hi, Wi, Ht, Wt) == (1, 16, 5, 1, 2, 28, 28, 28, 28)
+        gw_rides = last_stage and _DEC10_WGRAD_FUSED and ctx.needs_input_grad[8] and c.data_ptr() % 16 == 0
         if ctx.needs_input_grad[8]:
             gw = _new(w.shape, c)
-            ws = _wgrad_scratch(B, Cout, Cin, K, c)
-            _bwd_call('gpode_conv2d_bwd_weight_bn', _ptr(gy), _ptr(c), _ptr(table), _ptr(gw), _ptr(None),
-                      _ptr(ws), B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, _stream(), keep=(ws,))
+            if not gw_rides:                         # (the last stage's weight gradient rides in its BatchNorm sums pass below)
+                ws = _wgrad_scratch(B, Cout, Cin, K, c)
+                _bwd_call('gpode_conv2d_bwd_weight_bn', _ptr(gy), _ptr(c), _ptr(table), _ptr(gw), _ptr(None),
+                          _ptr(ws), B, Cout, Ht, Wt, Cin, K, S, P, Hi, Wi, _stream(), keep=(ws,))
             if has_b:
                 gb = _fused_chansum(gy, Cout)
                 if gb is None:
                     gb, bs = _new((Cout,), c), _bn_scratch(B, Cout, c)
                     _bwd_call('gpode_chan_sum', _ptr(gy), _ptr(gb), B, Cout, Ht * Wt, _ptr(bs), _stream(), keep=(bs,))
-        if _dec10_fused and (Cout, Cin, K, S, P, Hi, Wi, Ht, Wt) == (1, 16, 5, 1, 2, 28, 28, 28, 28):
+        if last_stage:
             # the decoder's last stage: the gradient w.r.t. the normalised activation is recomputed inside both BatchNorm passes
-            gc, gg, gbeta, cs = _dec10_bn_bwd(ctx.sync, c, gy, w, gamma, beta, mean, invstd)
+            gc, gg, gbeta, cs = _dec10_bn_bwd(ctx.sync, c, gy, w, gamma, beta, mean, invstd, gw=gw if gw_rides else None)
             gc._gpode_chansum = cs
             return gc, gg, gbeta, None, None, None, None, None, gw, gb, None, None, None, None, None
         # gradient w.r.t. the (never materialised) normalised activation, then through the BatchNorm to c
