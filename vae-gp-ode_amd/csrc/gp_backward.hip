@@ -36,7 +36,7 @@ template <int DI, int DO, int NJ>
 __device__ __forceinline__ void store_grads_rbf(const typename RbfTeamEval<DI, DO, NJ>::Grads& G, float* __restrict__ out, int M, int S,
                                                 int wave, int lane, float (*sInd)[64][4 * RbfLayout<DI, DO>::RQ2],
                                                 float (*sUni)[((DO + 1) / 2) * DI]);
-template <int D, int NJ>
+template <int D, int NJ, int PART = 0>
 __device__ __forceinline__ void store_grads_df(const typename DfTeamEval<D, NJ>::Grads& G, float* __restrict__ out, int M, int S, int wave,
                                                int lane, float (*sInd)[64][4 * DfLayout<D>::RQ2],
                                                float (*sUni)[2 * D * ((D + 1) / 2) + (D + 1) / 2]);
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void param_grad_rbf_kernel(const float* __rest
   store_grads_rbf<DI, DO, NJ>(G, slab + (size_t)blockIdx.x * pack_floats, M, S, wave, lane, sInd, sUni);
 }
 
-template <int D, int NJ>
+template <int D, int NJ, int PART>
 __device__ __forceinline__ void store_grads_df(const typename DfTeamEval<D, NJ>::Grads& G, float* __restrict__ out, int M, int S, int wave,
                                                int lane, float (*sInd)[64][4 * DfLayout<D>::RQ2],
                                                float (*sUni)[2 * D * ((D + 1) / 2) + (D + 1) / 2]) {
@@ -283,16 +283,19 @@ __device__ __forceinline__ void store_grads_df(const typename DfTeamEval<D, NJ>:
   constexpr int DH = (D + 1) / 2;
   constexpr int NU = 2 * D * DH + DH;
   const int SJ = cdiv(S, 64), MJ = cdiv(M, 64);
+  if constexpr (PART != 2) {
 #pragma unroll
-  for (int jn = 0; jn < NJ; ++jn) {
-    const int j = wave + TEAM * jn;
-    if (j < SJ) {
+    for (int jn = 0; jn < NJ; ++jn) {
+      const int j = wave + TEAM * jn;
+      if (j < SJ) {
 #pragma unroll
-      for (int i = 0; i < D; ++i)
+        for (int i = 0; i < D; ++i)
 #pragma unroll
-        for (int q = 0; q < L::RQ; ++q) st4(out, (size_t)((j * D + i) * L::RQ + q) * 64 + lane, &G.rff[jn * D + i][4 * q]);
+          for (int q = 0; q < L::RQ; ++q) st4(out, (size_t)((j * D + i) * L::RQ + q) * 64 + lane, &G.rff[jn * D + i][4 * q]);
+      }
     }
   }
+  if constexpr (PART == 1) return;                   // the inducing records and the uniform tail are another workgroup's
   const int j = wave >> 1, half = wave & 1;
   if (half == 1) {
 #pragma unroll
@@ -366,6 +369,45 @@ __global__ __launch_bounds__(256) void param_grad_df_kernel(const float* __restr
     ev.grad_row(x, a, G, prior_only != 0);
   }
   store_grads_df<D, NJ>(G, slab + (size_t)blockIdx.x * pack_floats, M, S, wave, lane, sInd, sUni);
+}
+
+// The same sums with the PACK split over two workgroups per chunk of rows (blockIdx.z: 0 = the Fourier-feature records, 1 = the
+// inducing records and the uniform tail): either half keeps under 256 registers, so the two share a CU -- the unsplit kernel's 432
+// registers allow one wavefront per SIMD, whose every dependent instruction waits out its full latency (168 us at configs[1], the
+// first and longest node of the backward pass's side branch).
+template <int D, int PART>
+__device__ __forceinline__ void pgrad_df_part(const float* __restrict__ pack, int M, int S, const float* __restrict__ xr,
+                                              const float* __restrict__ ar, int r0, int r1, float* __restrict__ out, int prior_only) {
+  using EV = DfTeamEval<D, 1>;
+  using L = DfLayout<D>;
+  constexpr int DH = (D + 1) / 2;
+  constexpr int NU = 2 * D * DH + DH;
+  __shared__ float slots[2 * TEAM * TeamCombine::DP];
+  __shared__ __attribute__((aligned(16))) float sInd[2][64][4 * L::RQ2];
+  __shared__ float sUni[TEAM][NU];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  EV ev;
+  ev.init(pack, M, S, slots, wave, lane);
+  typename EV::Grads G;
+  G.zero();
+  for (int r = r0; r < r1; ++r) {
+    float x[D], a[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { x[i] = xr[(size_t)r * D + i]; a[i] = ar[(size_t)r * D + i]; }
+    ev.template grad_row_part<PART>(x, a, G, prior_only != 0);
+  }
+  store_grads_df<D, 1, PART>(G, out, M, S, wave, lane, sInd, sUni);
+}
+template <int D>
+__global__ __launch_bounds__(256, 2) void param_grad_df_split_kernel(const float* __restrict__ pack, int M, int S,
+                                                                      const float* __restrict__ xr, const float* __restrict__ ar,
+                                                                      int R, int rows_per_chunk, float* __restrict__ slab,
+                                                                      size_t pack_floats, int prior_only, Draws dw, int slab_chunks) {
+  pack += blockIdx.y * dw.pack; xr += blockIdx.y * dw.in; ar += blockIdx.y * dw.in2; slab += (size_t)blockIdx.y * slab_chunks * pack_floats;
+  const int r0 = blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+  float* out = slab + (size_t)blockIdx.x * pack_floats;
+  if (blockIdx.z == 0) pgrad_df_part<D, 1>(pack, M, S, xr, ar, r0, r1, out, prior_only);
+  else pgrad_df_part<D, 2>(pack, M, S, xr, ar, r0, r1, out, prior_only);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -815,6 +857,14 @@ static int launch_pgrad_df(const float* pack, int M, int S, const float* xr, con
                            size_t pf, int prior_only, hipStream_t st, Draws dw, int nchunk) {
   if constexpr (D <= 8) {
     if (df_team_ok<D>(M, S)) {
+      // many rows (the rows of a training step): the pack split over two co-resident workgroups per chunk; GPODE_PGRAD_DF_UNSPLIT=1: A/B
+      static const bool unsplit = [] { const char* e = getenv("GPODE_PGRAD_DF_UNSPLIT"); return e && e[0] == '1'; }();
+      if constexpr (D == 6) {
+        if (!unsplit && R >= 1024) {
+          hipLaunchKernelGGL((param_grad_df_split_kernel<D>), dim3(used, dw.nd, 2), 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only, dw, nchunk);
+          return check_launch("param_grad_df_split");
+        }
+      }
       hipLaunchKernelGGL((param_grad_df_kernel<D, 1>), dim3(used, dw.nd), 256, 0, st, pack, M, S, xr, ar, R, rpc, slab, pf, prior_only, dw, nchunk);
       return check_launch("param_grad_df");
     }

@@ -222,6 +222,20 @@ template <int D, int NJ> struct DfTeamEval {
     for (int r = 0; r < NJ * D; ++r) df_rff_bwd<D, true>(rff[r], x, a, gx, G.rff[r]);
     if (!prior_only) df_ind_half_bwd<D, true>(ind, x, uni, half, a, gx, G.ind, G.gwab, G.gil2, G.gvar);
   }
+  // PART 1: the Fourier-feature records only; PART 2: the inducing records (and the uniform tail) only -- the two halves of
+  // grad_row for workgroups that split the pack instead of the rows (param_grad_df_split_kernel)
+  template <int PART> __device__ __forceinline__ void grad_row_part(const float (&x)[D], const float (&a)[D], Grads& G, bool prior_only) const {
+    float gx[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) gx[i] = 0.f;
+    if constexpr (PART != 2) {
+#pragma unroll
+      for (int r = 0; r < NJ * D; ++r) df_rff_bwd<D, true>(rff[r], x, a, gx, G.rff[r]);
+    }
+    if constexpr (PART != 1) {
+      if (!prior_only) df_ind_half_bwd<D, true>(ind, x, uni, half, a, gx, G.ind, G.gwab, G.gil2, G.gvar);
+    }
+  }
   __device__ __forceinline__ void vjp_grad(const float (&x)[D], const float (&a)[D], float (&gx)[D], Grads& G) {
     float acc[D];
 #pragma unroll
