@@ -790,20 +790,32 @@ __global__ __launch_bounds__(64) void k_Kbwd_rbf(int Di, int Do, int M, int np, 
   }
 }
 
-// DF: grid M, block 64: one wave per point n; lanes stride over the other point m.
+// DF: grid M, block 64 * NWK: point n per workgroup; wavefront w takes the rows a = w, w + NWK, ... of the D x D kernel block, its lanes
+// stride over the other point m.  (One wavefront for all 36 entries of a block was a 2000-instruction body run twice by 36 lanes: 29 us on
+// the tail of the backward pass's side branch at configs[1].)  The wavefronts' sums meet in LDS and are added in wavefront order.
 //   kpart[n]: [gvar(D) | gell(D*D)],  gZpart[n][c]
+template <int D> constexpr int kbwd_df_waves() { return D <= 8 ? D : 8; }
+template <int N> __device__ __forceinline__ float kb_pick(const float (&v)[N], int idx) {   // v[idx], idx wave-uniform, no register indexing
+  float r = v[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) r = (idx == i) ? v[i] : r;
+  return r;
+}
 template <int D>
-__global__ __launch_bounds__(64) void k_Kbwd_df(int M, int np, const float* __restrict__ Z, const float* __restrict__ ell,
-                                                 const float* __restrict__ var, const float* __restrict__ Sm,
-                                                 float* __restrict__ gZpart, float* __restrict__ kpart) {
-  const int n = blockIdx.x, lane = threadIdx.x;
-  float gz[D], gvar[D], gell[D][D], zn[D];
+__global__ __launch_bounds__(64 * kbwd_df_waves<D>()) void k_Kbwd_df(int M, int np, const float* __restrict__ Z, const float* __restrict__ ell,
+                                                                       const float* __restrict__ var, const float* __restrict__ Sm,
+                                                                       float* __restrict__ gZpart, float* __restrict__ kpart) {
+  constexpr int NWK = kbwd_df_waves<D>();
+  constexpr int AR = (D + NWK - 1) / NWK;            // rows a per wavefront
+  __shared__ float sred[NWK][2 * D];                 // per wavefront: gz[D] | gvar[D]
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float gz[D], gvar[D], gell[AR][D], zn[D];
 #pragma unroll
-  for (int a = 0; a < D; ++a) {
-    gz[a] = 0.f; gvar[a] = 0.f; zn[a] = Z[n * D + a];
+  for (int a = 0; a < D; ++a) { gz[a] = 0.f; gvar[a] = 0.f; zn[a] = Z[n * D + a]; }
 #pragma unroll
-    for (int b = 0; b < D; ++b) gell[a][b] = 0.f;
-  }
+  for (int q = 0; q < AR; ++q)
+#pragma unroll
+    for (int b = 0; b < D; ++b) gell[q][b] = 0.f;
   for (int m = lane; m < M; m += 64) {
     float dl[D];
     float r2 = 0.f;
@@ -813,33 +825,36 @@ __global__ __launch_bounds__(64) void k_Kbwd_df(int M, int np, const float* __re
 #pragma unroll
     for (int a = 0; a < D; ++a) gd[a] = 0.f;
 #pragma unroll
-    for (int a = 0; a < D; ++a) {
+    for (int q = 0; q < AR; ++q) {
+      const int a = wv + NWK * q;                    // wave-uniform
+      if (a < D) {
 #pragma unroll
-      for (int b = 0; b < D; ++b) {
-        const float l = ell[a * D + b];
-        const float il = 1.f / (l * l), il3 = il / l;  // 1/l^2, 1/l^3
-        const float E = expf(-0.5f * r2 * il);
-        const bool diag = a == b;
-        const float term = dl[a] * dl[b] * il + (diag ? ((float)(D - 1) - r2 * il) : 0.f);
-        const float vb = var[b];
-        // entry (n,a),(m,b) and its point-transposed twin (m,a),(n,b): same value, same d/d z_n
-        const size_t r1 = (size_t)(n * D + a), c1 = (size_t)(m * D + b);
-        const size_t r2i = (size_t)(m * D + a), c2 = (size_t)(n * D + b);
-        const float G1 = 0.5f * (Sm[r1 * np + c1] + Sm[c1 * np + r1]);
-        const float G2 = 0.5f * (Sm[r2i * np + c2] + Sm[c2 * np + r2i]);
-        const float base = vb * E * il;
-        // dT/d delta_c = base * [ -il delta_c term + il (d_ca delta_b + d_cb delta_a) - diag 2 il delta_c ]
-        const float Gs = (G1 + G2) * base;
-        const float common = -il * term - (diag ? 2.f * il : 0.f);
+        for (int b = 0; b < D; ++b) {
+          const float l = ell[a * D + b];
+          const float il = 1.f / (l * l), il3 = il / l;  // 1/l^2, 1/l^3
+          const float E = expf(-0.5f * r2 * il);
+          const bool diag = a == b;
+          const float da = kb_pick<D>(dl, a);
+          const float term = da * dl[b] * il + (diag ? ((float)(D - 1) - r2 * il) : 0.f);
+          const float vb = var[b];
+          // entry (n,a),(m,b) and its point-transposed twin (m,a),(n,b): same value, same d/d z_n
+          const size_t r1 = (size_t)(n * D + a), c1 = (size_t)(m * D + b);
+          const size_t r2i = (size_t)(m * D + a), c2 = (size_t)(n * D + b);
+          const float G1 = 0.5f * (Sm[r1 * np + c1] + Sm[c1 * np + r1]);
+          const float G2 = 0.5f * (Sm[r2i * np + c2] + Sm[c2 * np + r2i]);
+          const float base = vb * E * il;
+          // dT/d delta_c = base * [ -il delta_c term + il (d_ca delta_b + d_cb delta_a) - diag 2 il delta_c ]
+          const float Gs = (G1 + G2) * base;
+          const float common = -il * term - (diag ? 2.f * il : 0.f);
 #pragma unroll
-        for (int c = 0; c < D; ++c) gd[c] = fmaf(Gs, common * dl[c], gd[c]);
-        gd[a] = fmaf(Gs, il * dl[b], gd[a]);
-        gd[b] = fmaf(Gs, il * dl[a], gd[b]);
-        // parameters: entry 1 only
-        gvar[b] = fmaf(G1, E * il * term, gvar[b]);
-        // dT/dl = vb E / l^3 [ r2 il term - 2 term - 2 il (delta_a delta_b - diag r2) ]
-        const float dT = vb * E * il3 * (r2 * il * term - 2.f * term - 2.f * il * (dl[a] * dl[b] - (diag ? r2 : 0.f)));
-        gell[a][b] = fmaf(G1, dT, gell[a][b]);
+          for (int c = 0; c < D; ++c) gd[c] = fmaf(Gs, common * dl[c] + (c == a ? il * dl[b] : 0.f), gd[c]);
+          gd[b] = fmaf(Gs, il * da, gd[b]);
+          // parameters: entry 1 only
+          gvar[b] = fmaf(G1, E * il * term, gvar[b]);
+          // dT/dl = vb E / l^3 [ r2 il term - 2 term - 2 il (delta_a delta_b - diag r2) ]
+          const float dT = vb * E * il3 * (r2 * il * term - 2.f * term - 2.f * il * (da * dl[b] - (diag ? r2 : 0.f)));
+          gell[q][b] = fmaf(G1, dT, gell[q][b]);
+        }
       }
     }
 #pragma unroll
@@ -849,20 +864,29 @@ __global__ __launch_bounds__(64) void k_Kbwd_df(int M, int np, const float* __re
   wave_sum_all<D>(gz, red);
   if (lane == 0)
 #pragma unroll
-    for (int c = 0; c < D; ++c) gZpart[(size_t)n * D + c] = red[c];
-  float* kp = kpart + (size_t)n * (D + D * D);
+    for (int c = 0; c < D; ++c) sred[wv][c] = red[c];
   wave_sum_all<D>(gvar, red);
   if (lane == 0)
 #pragma unroll
-    for (int c = 0; c < D; ++c) kp[c] = red[c];
+    for (int c = 0; c < D; ++c) sred[wv][D + c] = red[c];
+  float* kp = kpart + (size_t)n * (D + D * D);
 #pragma unroll
-  for (int a = 0; a < D; ++a) {
+  for (int q = 0; q < AR; ++q) {
+    const int a = wv + NWK * q;
 #pragma unroll
-    for (int b = 0; b < D; ++b) tmp[b] = gell[a][b];
+    for (int b = 0; b < D; ++b) tmp[b] = gell[q][b];
     wave_sum_all<D>(tmp, red);
-    if (lane == 0)
+    if (lane == 0 && a < D)
 #pragma unroll
       for (int b = 0; b < D; ++b) kp[D + a * D + b] = red[b];
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * D) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWK; ++w) v += sred[w][threadIdx.x];
+    if (threadIdx.x < D) gZpart[(size_t)n * D + threadIdx.x] = v;
+    else kp[threadIdx.x - D] = v;
   }
 }
 
@@ -1211,7 +1235,7 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, int nd, const floa
   }
 #define X(D_)                                                                                                              \
   if (Do == D_) {                                                                                                          \
-    hipLaunchKernelGGL(k_Kbwd_df<D_>, M, 64, 0, st, M, b.np, Z, ws + w.ell, ws + w.var, bws + b.S, bws + b.gZpart,         \
+    hipLaunchKernelGGL(k_Kbwd_df<D_>, M, 64 * kbwd_df_waves<D_>(), 0, st, M, b.np, Z, ws + w.ell, ws + w.var, bws + b.S, bws + b.gZpart, \
                        bws + b.kpart);                                                                                     \
     hipLaunchKernelGGL(k_df_gomega<D_>, dim3(S, nd), ((D_ * D_ + 63) / 64) * 64, 0, st, S, pack, gpack, ws + w.var, bws + b.gom, pf);    \
     hipLaunchKernelGGL(k_chain_df<D_>, D_ * D_ + D_ + cdiv(M * D_, 256), 256, 0, st, M, S, pack, gpack, raw_ell, raw_var, bws + b.gom, bws + b.vjpZ,      \
