@@ -41,8 +41,9 @@ template <class L, int IPB>
 __global__ __launch_bounds__(256) void k_convT_fwd(const float* __restrict__ x, const float* __restrict__ w,
                                                     const float* __restrict__ bias, float* __restrict__ y, int B) {
   constexpr int CI = L::CI, CO = L::CO, HI = L::HI, HO = L::HO, HP = L::HP, K = L::K, S = L::S, P = L::P, PL = L::PL;
-  static_assert(CO % 16 == 0, "16 output channels per thread");
-  constexpr int NG = CO / 16;                      // channel groups of 16 per pixel
+  constexpr int CPT = CO % 16 == 0 ? 16 : 8;       // output channels per thread
+  static_assert(CO % CPT == 0, "8 or 16 output channels per thread");
+  constexpr int NG = CO / CPT;                     // channel groups per pixel
   constexpr int IMG = CI * HP * HP;                // floats per staged image
   float* s_img = tsm;                              // [IPB][CI][HP][HP]
   float* s_w = tsm + IPB * IMG;                    // [tap][CI][CO] for the current parity class (<= 9 taps)
@@ -73,29 +74,30 @@ __global__ __launch_bounds__(256) void k_convT_fwd(const float* __restrict__ x, 
     for (int it = tid; it < items; it += 256) {
       const int g = it % NG, p = (it / NG) % (ny * nx), im = it / (NG * ny * nx);
       const int qy = qy0 + p / nx, qx = qx0 + p % nx;
-      float acc[16];
+      float acc[CPT];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) acc[c] = bias ? bias[g * 16 + c] : 0.f;
+      for (int c = 0; c < CPT; ++c) acc[c] = bias ? bias[g * CPT + c] : 0.f;
       const float* img = s_img + im * IMG;
       for (int ty = 0; ty < nty; ++ty) {
         for (int tx = 0; tx < ntx; ++tx) {
           const float* ip = img + (qy - ty + PL) * HP + (qx - tx + PL);    // iy = qy - ty
-          const float4* wp = reinterpret_cast<const float4*>(s_w + ((ty * ntx + tx) * CI) * CO + g * 16);
+          const float4* wp = reinterpret_cast<const float4*>(s_w + ((ty * ntx + tx) * CI) * CO + g * CPT);
 #pragma unroll 4
           for (int ci = 0; ci < CI; ++ci) {
             const float v = ip[ci * HP * HP];
-            const float4 w0 = wp[ci * (CO / 4) + 0], w1 = wp[ci * (CO / 4) + 1], w2 = wp[ci * (CO / 4) + 2], w3 = wp[ci * (CO / 4) + 3];
-            acc[0] = fmaf(v, w0.x, acc[0]); acc[1] = fmaf(v, w0.y, acc[1]); acc[2] = fmaf(v, w0.z, acc[2]); acc[3] = fmaf(v, w0.w, acc[3]);
-            acc[4] = fmaf(v, w1.x, acc[4]); acc[5] = fmaf(v, w1.y, acc[5]); acc[6] = fmaf(v, w1.z, acc[6]); acc[7] = fmaf(v, w1.w, acc[7]);
-            acc[8] = fmaf(v, w2.x, acc[8]); acc[9] = fmaf(v, w2.y, acc[9]); acc[10] = fmaf(v, w2.z, acc[10]); acc[11] = fmaf(v, w2.w, acc[11]);
-            acc[12] = fmaf(v, w3.x, acc[12]); acc[13] = fmaf(v, w3.y, acc[13]); acc[14] = fmaf(v, w3.z, acc[14]); acc[15] = fmaf(v, w3.w, acc[15]);
+#pragma unroll
+            for (int q = 0; q < CPT / 4; ++q) {
+              const float4 wq = wp[ci * (CO / 4) + q];
+              acc[4 * q] = fmaf(v, wq.x, acc[4 * q]); acc[4 * q + 1] = fmaf(v, wq.y, acc[4 * q + 1]);
+              acc[4 * q + 2] = fmaf(v, wq.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(v, wq.w, acc[4 * q + 3]);
+            }
           }
         }
       }
       const int oy = S * qy + py - P, ox = S * qx + px - P;
-      float* yp = y + (((size_t)(b0 + im) * CO + g * 16) * HO + oy) * HO + ox;
+      float* yp = y + (((size_t)(b0 + im) * CO + g * CPT) * HO + oy) * HO + ox;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) yp[(size_t)c * HO * HO] = acc[c];
+      for (int c = 0; c < CPT; ++c) yp[(size_t)c * HO * HO] = acc[c];
     }
   }
 }
@@ -529,6 +531,18 @@ int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx
       return check_launch("dec1_fwd_mfma");
     }
     return launch_T1<Dec1, 8, 8, 64>(gy, w, bias, gx, B, st, in_bn);
+  }
+  if (matches<Enc3>(Ci, Co, H, Ho, K, S, P) && !in_bn && B >= 96) {
+    // d/d input of the encoder's cnn.3 (16 -> 8 channels: no matrix-core tile shape) from 96 images on: the LDS-tiled vector kernel, two
+    // images per workgroup -- the direct kernel re-reads every gradient value from L2 for each of its taps (256 images: 38 us direct,
+    // 24.5 us tiled with four images per workgroup; 32 images: 21 us direct, 27 us tiled -- 8 workgroups)
+    constexpr int IPB = 2;
+    constexpr int MAXTAPS = ((Enc3::K + Enc3::S - 1) / Enc3::S) * ((Enc3::K + Enc3::S - 1) / Enc3::S);
+    const size_t lds = sizeof(float) * ((size_t)IPB * Enc3::CI * Enc3::HP * Enc3::HP + (size_t)MAXTAPS * Enc3::CI * Enc3::CO);
+    auto kern = k_convT_fwd<Enc3, IPB>;
+    if (set_max_lds((const void*)kern, lds)) return 1;
+    hipLaunchKernelGGL(kern, (B + IPB - 1) / IPB, 256, lds, st, gy, w, bias, gx, B);
+    return check_launch("enc_conv3_bwd_data_tiled");
   }
   if (matches<Enc6>(Ci, Co, H, Ho, K, S, P) && use_mfma() && (reinterpret_cast<uintptr_t>(gy) & 15) == 0)   // d/d input of the encoder's cnn.6
     return launch_igemm<FwdPolicy<Enc6, 16>, 8, 4, 1>(gy, w, bias, gx, B, st, "enc_conv6_bwd_data_mfma", in_bn);
