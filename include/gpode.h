@@ -307,11 +307,13 @@ int gpode_flush_reductions(void* stream);
  * c: the BatchNorm input, gy: B x 1 x 28 x 28, w: decnn.10's weight [16][1][5][5]; scratch: gpode_dec10_bn_scratch_floats() floats.
  * Replaces gpode_conv2d_fwd (as the d/d input of decnn.10) + gpode_bn_bwd / gpode_bn_bwd_sums + gpode_bn_bwd_apply for this stage. */
 /* gpode_dec10_bn_bwd_sums_wgrad: the sums pass that also produces decnn.10's WEIGHT gradient gw [16][1][5][5] (what
- * gpode_conv2d_bwd_weight_bn computes for this stage in a pass of its own over c): both read c and the gy plane in the same lane layout.
- * wscratch: gpode_dec10_bn_wgrad_scratch_floats() floats.  gw's final reduction obeys gpode_defer_reductions like the others. */
+ * gpode_conv2d_bwd_weight_bn computes for this stage in a pass of its own over c) and, unless gbias is NULL, its BIAS gradient gbias[1] =
+ * sum gy (gpode_chan_sum): both read c and the gy plane in the same lane layout.  wscratch: gpode_dec10_bn_wgrad_scratch_floats()
+ * floats.  The final reductions of gw / gbias obey gpode_defer_reductions like the others. */
 int gpode_dec10_bn_wgrad_scratch_floats(void);
 int gpode_dec10_bn_bwd_sums_wgrad(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* save_mean,
-                                  const float* save_invstd, float* sums, float* gw, int B, float* scratch, float* wscratch, void* stream);
+                                  const float* save_invstd, float* sums, float* gw, float* gbias, int B, float* scratch, float* wscratch,
+                                  void* stream);
 int gpode_dec10_bn_scratch_floats(void);
 int gpode_dec10_bn_bwd_sums(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* save_mean,
                             const float* save_invstd, float* sums, int B, float* scratch, void* stream);

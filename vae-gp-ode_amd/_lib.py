@@ -83,7 +83,7 @@ SIGNATURES.update({
     'gpode_flush_reductions': (_i, [_vp]),
     'gpode_dec10_bn_scratch_floats': (_i, []),
     'gpode_dec10_bn_wgrad_scratch_floats': (_i, []),
-    'gpode_dec10_bn_bwd_sums_wgrad': (_i, [_c_float_p] * 9 + [_i, _c_float_p, _c_float_p, _vp]),
+    'gpode_dec10_bn_bwd_sums_wgrad': (_i, [_c_float_p] * 10 + [_i, _c_float_p, _c_float_p, _vp]),
     'gpode_dec10_bn_bwd_sums': (_i, [_c_float_p] * 8 + [_i, _c_float_p, _vp]),
     'gpode_dec10_bn_bwd_apply': (_i, [_c_float_p] * 9 + [_i, _f] + [_c_float_p] * 4 + [_i, _c_float_p, _vp]),
     'gpode_bn_eval': (_i, [_c_float_p] * 6 + [_f, _c_float_p, _i, _i, _i, _i, _vp]),

@@ -356,11 +356,12 @@ int gpode_dec10_bn_bwd_sums(const float* c, const float* gy, const float* w, con
 }
 int gpode_dec10_bn_wgrad_scratch_floats(void) { return gp::dec10_bn_wgrad_scratch_floats(); }
 int gpode_dec10_bn_bwd_sums_wgrad(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* save_mean,
-                                  const float* save_invstd, float* sums, float* gw, int B, float* scratch, float* wscratch, void* stream) {
+                                  const float* save_invstd, float* sums, float* gw, float* gbias, int B, float* scratch, float* wscratch,
+                                  void* stream) {
   if (!c || !gy || !w || !gamma || !beta || !save_mean || !save_invstd || !scratch || !gw || !wscratch)
     return gp::set_error("gpode_dec10_bn_bwd_sums_wgrad: null pointer");
   if (B < 1) return gp::set_error("gpode_dec10_bn_bwd_sums_wgrad: B >= 1");
-  return gp::dec10_bn_bwd_sums(c, gy, w, gamma, beta, save_mean, save_invstd, sums, B, scratch, GP_ST, gw, wscratch);
+  return gp::dec10_bn_bwd_sums(c, gy, w, gamma, beta, save_mean, save_invstd, sums, B, scratch, GP_ST, gw, wscratch, gbias);
 }
 int gpode_dec10_bn_bwd_apply(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* save_mean,
                              const float* save_invstd, const float* sums_gathered, const float* weights, int nranks, float count_all,

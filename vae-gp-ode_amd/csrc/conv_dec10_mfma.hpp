@@ -213,7 +213,7 @@ __global__ __launch_bounds__(512, 4) void k_bwd_data_bn(const float* __restrict_
                                                         int nsplit, float count, const float* __restrict__ gathered,
                                                         const float* __restrict__ wts, int W, float* __restrict__ ggamma,
                                                         float* __restrict__ gbeta, float* __restrict__ gx, float* __restrict__ part_gx,
-                                                        float* __restrict__ part_w = nullptr) {
+                                                        float* __restrict__ part_w = nullptr, float* __restrict__ part_b = nullptr) {
   static_assert(!WGRAD || MODE == 0, "the weight gradient rides in the sums pass");
   float* s_g = igemm_smem;                           // [IPB][32][32], index = o + 2, zero borders
   float* s_red = s_g + IPB * PLANE;                  // [8][4][CI][2]
@@ -263,6 +263,7 @@ __global__ __launch_bounds__(512, 4) void k_bwd_data_bn(const float* __restrict_
     cb = s_B[lr] * ic;
   }
   float a0 = 0.f, a1 = 0.f;
+  float gsum = 0.f;                                  // WGRAD: this thread's share of sum gy = the layer's bias gradient (one output channel)
   const int ngroups = (B + IPB - 1) / IPB;
   float4 pre[NLD];
   auto prefetch = [&](int grp) {
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(512, 4) void k_bwd_data_bn(const float* __restrict_
       const int f = tid + 512 * i;
       if (f < nimg * (NP / 4)) {
         const float v[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+        if (WGRAD) gsum += (v[0] + v[1]) + (v[2] + v[3]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int e = 4 * f + k, im = e / NP, q = e % NP;
@@ -368,6 +370,20 @@ __global__ __launch_bounds__(512, 4) void k_bwd_data_bn(const float* __restrict_
 #pragma unroll
       for (int wv = 0; wv < 8; ++wv) v += s_wred[(wv * CI + ci) * 32 + tap];
       part_w[(size_t)blockIdx.x * (CI * KK) + e] = v;
+    }
+    if (part_b) {                                    // bias gradient: the 512 threads' shares in a fixed order
+      __syncthreads();
+      s_wred[tid] = gsum;
+      __syncthreads();
+      if (tid < 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += s_wred[tid + 64 * q];
+        const float in1[1] = {v};
+        float out1[1];
+        wave_sum_multi<1>(in1, out1);
+        if (tid == 0) part_b[blockIdx.x] = out1[0];
+      }
     }
   }
 }

@@ -141,7 +141,7 @@ int bn_apply(const float* x, const float* table, float* y, int B, int C, int HW,
 // decnn.10's input gradient fused with the BatchNorm + ReLU backward in front of it (vae_conv_tiled.hip)
 int dec10_bn_scratch_floats();
 int dec10_bn_bwd_sums(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* mean,
-                      const float* invstd, float* sums, int B, float* scratch, hipStream_t st, float* gw = nullptr, float* wscratch = nullptr);
+                      const float* invstd, float* sums, int B, float* scratch, hipStream_t st, float* gw = nullptr, float* wscratch = nullptr, float* gbias = nullptr);
 int dec10_bn_wgrad_scratch_floats();
 int dec10_bn_bwd_apply(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* mean,
                        const float* invstd, const float* gathered, const float* wts, int W, float count_all, float* gc, float* ggamma,

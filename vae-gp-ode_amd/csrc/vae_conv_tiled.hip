@@ -638,9 +638,9 @@ static int dec10_bn_nwg(int B, int& ipb) {
 }
 
 // gw != nullptr: the layer's weight gradient (16 x 25) is produced by the same pass (wscratch: dec10_bn_wgrad_scratch_floats() floats)
-int dec10_bn_wgrad_scratch_floats() { return kDec10BnMaxWg * dec10::CI * dec10::KK; }
+int dec10_bn_wgrad_scratch_floats() { return kDec10BnMaxWg * dec10::CI * dec10::KK + kDec10BnMaxWg; }
 int dec10_bn_bwd_sums(const float* c, const float* gy, const float* w, const float* gamma, const float* beta, const float* mean,
-                      const float* invstd, float* sums, int B, float* scratch, hipStream_t st, float* gw, float* wscratch) {
+                      const float* invstd, float* sums, int B, float* scratch, hipStream_t st, float* gw, float* wscratch, float* gbias) {
   if (((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(c)) & 15) != 0) return set_error("gpode_dec10_bn_bwd_sums: c / gy must be 16-byte aligned");
   if (gw && !wscratch) return set_error("gpode_dec10_bn_bwd_sums_wgrad: scratch for the weight-gradient partials missing");
   int ipb;
@@ -649,11 +649,15 @@ int dec10_bn_bwd_sums(const float* c, const float* gy, const float* w, const flo
   const float* cnp = nullptr;
   int rc;
   if (gw) {
-    if (ipb == 4) rc = launch_dec10_bn<4, 0, true>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, 0, 0.f, cnp, cnp, 0, np_, np_, np_, np_, wscratch);
-    else rc = launch_dec10_bn<2, 0, true>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, 0, 0.f, cnp, cnp, 0, np_, np_, np_, np_, wscratch);
-    if (!rc && reduce_job(RedJob{wscratch, gw, nwg, dec10::CI * dec10::KK, 0, 0, 0, 0}, st)) return 1;
-  } else if (ipb == 4) rc = launch_dec10_bn<4, 0>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, 0, 0.f, cnp, cnp, 0, np_, np_, np_, np_, np_);
-  else rc = launch_dec10_bn<2, 0>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, 0, 0.f, cnp, cnp, 0, np_, np_, np_, np_, np_);
+    float* part_b = gbias ? wscratch + (size_t)kDec10BnMaxWg * dec10::CI * dec10::KK : nullptr;
+    if (ipb == 4) rc = launch_dec10_bn<4, 0, true>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, 0, 0.f, cnp, cnp, 0, np_, np_, np_, np_, wscratch, part_b);
+    else rc = launch_dec10_bn<2, 0, true>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, 0, 0.f, cnp, cnp, 0, np_, np_, np_, np_, wscratch, part_b);
+    if (!rc) {
+      const RedJob jobs[2] = {RedJob{wscratch, gw, nwg, dec10::CI * dec10::KK, 0, 0, 0, 0}, RedJob{part_b, gbias, nwg, 1, 0, 0, 0, 0}};
+      if (reduce_jobs(jobs, gbias ? 2 : 1, st)) return 1;
+    }
+  } else if (ipb == 4) rc = launch_dec10_bn<4, 0>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, 0, 0.f, cnp, cnp, 0, np_, np_, np_, np_, np_, np_);
+  else rc = launch_dec10_bn<2, 0>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, 0, 0.f, cnp, cnp, 0, np_, np_, np_, np_, np_, np_);
   if (rc) return rc;
   if (sums) hipLaunchKernelGGL(k_dec10_parts_reduce, 1, 512, 0, st, scratch, nwg, sums, 1);
   return check_launch("dec10_bn_bwd_sums");
@@ -670,8 +674,8 @@ int dec10_bn_bwd_apply(const float* c, const float* gy, const float* w, const fl
   float* part_gx = gc_chansum ? scratch + (size_t)kDec10BnMaxWg * dec10::CI * 2 : nullptr;
   const float count = gathered ? count_all : (float)B * dec10::NP;
   int rc;
-  if (ipb == 4) rc = launch_dec10_bn<4, 1>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, nwg, count, gathered, wts, W, ggamma, gbeta, gc, part_gx, (float*)nullptr);
-  else rc = launch_dec10_bn<2, 1>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, nwg, count, gathered, wts, W, ggamma, gbeta, gc, part_gx, (float*)nullptr);
+  if (ipb == 4) rc = launch_dec10_bn<4, 1>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, nwg, count, gathered, wts, W, ggamma, gbeta, gc, part_gx, (float*)nullptr, (float*)nullptr);
+  else rc = launch_dec10_bn<2, 1>(B, st, gy, w, c, gamma, beta, mean, invstd, B, scratch, nwg, count, gathered, wts, W, ggamma, gbeta, gc, part_gx, (float*)nullptr, (float*)nullptr);
   if (rc) return rc;
   if (gc_chansum && reduce_job(RedJob{part_gx, gc_chansum, nwg, dec10::CI, 2, 0, 0, 0}, st)) return 1;
   return check_launch("dec10_bn_bwd_apply");

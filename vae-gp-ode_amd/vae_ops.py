@@ -192,7 +192,7 @@ _dec10_fused = os.environ.get('GPODE_DEC10_BN_UNFUSED', '0') != '1'
 _DEC10_WGRAD_FUSED = os.environ.get('GPODE_DEC10_WGRAD_PASS', '0') != '1'
 
 
-def _dec10_bn_bwd(sync, c, gy, w, gamma, beta, mean, invstd, gw=None):
+def _dec10_bn_bwd(sync, c, gy, w, gamma, beta, mean, invstd, gw=None, gbias=None):
     """decnn.10's input gradient + the BatchNorm/ReLU backward in front of it in two passes over c (include/gpode.h,
     gpode_dec10_bn_bwd_*): (gc, ggamma, gbeta, channel sums of gc).  ``gw`` (a tensor to fill): the layer's weight gradient rides
     in the first pass (gpode_dec10_bn_bwd_sums_wgrad)."""
@@ -203,7 +203,8 @@ def _dec10_bn_bwd(sync, c, gy, w, gamma, beta, mean, invstd, gw=None):
     sums = _new((32,), c) if sync is not None else None
     if gw is not None:
         ws = _scratch(_lib.load().gpode_dec10_bn_wgrad_scratch_floats(), c)
-        _bwd_call('gpode_dec10_bn_bwd_sums_wgrad', *head, _ptr(sums), _ptr(gw), B, _ptr(scratch), _ptr(ws), _stream(), keep=(ws, scratch))
+        _bwd_call('gpode_dec10_bn_bwd_sums_wgrad', *head, _ptr(sums), _ptr(gw), _ptr(gbias), B, _ptr(scratch), _ptr(ws), _stream(),
+                  keep=(ws, scratch))
     else:
         _lib.call('gpode_dec10_bn_bwd_sums', *head, _ptr(sums), B, _ptr(scratch), _stream())
     if sync is None:
@@ -417,11 +418,22 @@ class _BnReluConvT(torch.autograd.Function):
             if has_b:
                 gb = _fused_chansum(gy, Cout)
                 if gb is None:
-                    gb, bs = _new((Cout,), c), _bn_scratch(B, Cout, c)
-                    _bwd_call('gpode_chan_sum', _ptr(gy), _ptr(gb), B, Cout, Ht * Wt, _ptr(bs), _stream(), keep=(bs,))
+                    gb = _new((Cout,), c)
+                    if not gw_rides:                 # (with the weight gradient, the bias gradient rides in the sums pass too)
+                        bs = _bn_scratch(B, Cout, c)
+                        _bwd_call('gpode_chan_sum', _ptr(gy), _ptr(gb), B, Cout, Ht * Wt, _ptr(bs), _stream(), keep=(bs,))
+                        gb_rides = None
+                    else:
+                        gb_rides = gb
+                else:
+                    gb_rides = None
+            else:
+                gb_rides = None
+        else:
+            gb_rides = None
         if last_stage:
             # the decoder's last stage: the gradient w.r.t. the normalised activation is recomputed inside both BatchNorm passes
-            gc, gg, gbeta, cs = _dec10_bn_bwd(ctx.sync, c, gy, w, gamma, beta, mean, invstd, gw=gw if gw_rides else None)
+            gc, gg, gbeta, cs = _dec10_bn_bwd(ctx.sync, c, gy, w, gamma, beta, mean, invstd, gw=gw if gw_rides else None, gbias=gb_rides)
             gc._gpode_chansum = cs
             return gc, gg, gbeta, None, None, None, None, None, gw, gb, None, None, None, None, None
         # gradient w.r.t. the (never materialised) normalised activation, then through the BatchNorm to c
