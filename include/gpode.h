@@ -372,6 +372,12 @@ int gpode_elbo_all_fwd(const float* lpart, int nl_rows, int nl_values, const flo
 int gpode_elbo_all_bwd(const float* g_loss, const float* g_nll, const float* g_kl, const float* g_klu, int nl_rows, const float* hs,
                        const float* hv, int N, int q, int M, int Do, const float* Um, const float* Us, float nobs, float* glrow, float* ghs,
                        float* ghv, float* dUm, float* dUs, void* stream);
+/* gpode_elbo_all_bwd and gpode_sigmoid_loglik_bwd in one launch: every likelihood row receives the same gradient, so the gradient of the
+ * decoder's logits (ga, n_logits values; X of nX values is broadcast over the Monte-Carlo copies) is produced together with the others. */
+int gpode_elbo_all_bwd_ll(const float* g_loss, const float* g_nll, const float* g_kl, const float* g_klu, int nl_rows, const float* hs,
+                          const float* hv, int N, int q, int M, int Do, const float* Um, const float* Us, float nobs, float* glrow, float* ghs,
+                          float* ghv, float* dUm, float* dUs, const float* X, const float* z, float* ga, size_t n_logits, size_t nX,
+                          void* stream);
 /* All device-side noise of a step in one launch (the reference draws on the host with numpy -- kernels.py:13-26,134-137,
  * svpy.py:12-27,94 -- and with torch.randn_like, vae.py:76; `--device_noise` / DeviceNoise draws here instead):
  *   out[0 .. n_normal) ~ N(0,1), out[n_normal .. n_normal + n_uniform) ~ U[0,1): Philox4x32-10 keyed by `seed`, counter = (element

@@ -108,6 +108,7 @@ SIGNATURES.update({
     'gpode_sigmoid_loglik_bwd': (_i, [_c_float_p] * 4 + [_sz, _sz, _sz, _vp]),
     'gpode_elbo_all_fwd': (_i, [_c_float_p, _i, _i, _c_float_p, _c_float_p, _i, _i, _i, _i, _c_float_p, _c_float_p, _f, _c_float_p, _vp]),
     'gpode_elbo_all_bwd': (_i, [_c_float_p] * 4 + [_i, _c_float_p, _c_float_p, _i, _i, _i, _i, _c_float_p, _c_float_p, _f] + [_c_float_p] * 5 + [_vp]),
+    'gpode_elbo_all_bwd_ll': (_i, [_c_float_p] * 4 + [_i, _c_float_p, _c_float_p, _i, _i, _i, _i, _c_float_p, _c_float_p, _f] + [_c_float_p] * 8 + [_sz, _sz, _vp]),
     'gpode_elbo_fwd': (_i, [_c_float_p, _i, _c_float_p, _i, _c_float_p, _f, _c_float_p, _vp]),
     'gpode_elbo_bwd': (_i, [_c_float_p, _i, _i, _f, _c_float_p, _c_float_p, _c_float_p, _vp]),
     'gpode_gather_multi': (_i, [_vp, _vp, _i, ctypes.c_longlong, _c_float_p, _vp]),

@@ -467,6 +467,15 @@ int gpode_elbo_all_bwd(const float* g_loss, const float* g_nll, const float* g_k
   if (nl_rows < 1 || N < 1 || q < 1 || M < 1 || Do < 1) return gp::set_error("gpode_elbo_all_bwd: bad sizes");
   return gp::elbo_all_bwd(g_loss, g_nll, g_kl, g_klu, nl_rows, hs, hv, N, q, M, Do, Um, Us, nobs, glrow, ghs, ghv, dUm, dUs, GP_ST);
 }
+int gpode_elbo_all_bwd_ll(const float* g_loss, const float* g_nll, const float* g_kl, const float* g_klu, int nl_rows, const float* hs,
+                          const float* hv, int N, int q, int M, int Do, const float* Um, const float* Us, float nobs, float* glrow, float* ghs,
+                          float* ghv, float* dUm, float* dUs, const float* X, const float* z, float* ga, size_t n_logits, size_t nX,
+                          void* stream) {
+  if (!hs || !Um || !Us || !glrow || !ghs || !dUm || !dUs || (hv && !ghv) || !X || !z || !ga) return gp::set_error("gpode_elbo_all_bwd_ll: null pointer");
+  if (nl_rows < 1 || N < 1 || q < 1 || M < 1 || Do < 1 || n_logits < 1 || nX < 1 || n_logits % nX != 0) return gp::set_error("gpode_elbo_all_bwd_ll: bad sizes");
+  return gp::elbo_all_bwd_ll(g_loss, g_nll, g_kl, g_klu, nl_rows, hs, hv, N, q, M, Do, Um, Us, nobs, glrow, ghs, ghv, dUm, dUs, X, z, ga, n_logits,
+                             nX, GP_ST);
+}
 int gpode_elbo_fwd(const float* lhood, int nl, const float* klrow, int nk, const float* kl_u, float nobs, float* out, void* stream) {
   if (!lhood || !klrow || !kl_u || !out || nl < 1 || nk < 1) return gp::set_error("gpode_elbo_fwd: bad argument");
   return gp::elbo_fwd(lhood, nl, klrow, nk, kl_u, nobs, out, GP_ST);

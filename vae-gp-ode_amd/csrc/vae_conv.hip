@@ -761,6 +761,52 @@ __global__ void k_elbo_all_bwd(const float* __restrict__ g0p, const float* __res
   }
 }
 
+// k_elbo_all_bwd and k_sigmoid_loglik_bwd in ONE launch: every likelihood row receives the same gradient (-g0 nobs - g1) / rows, so the
+// logit gradients need no row-gradient tensor in between -- blocks [0, nb_small) do the (N,q)- and (M,D)-sized outputs, the rest the logits.
+__global__ void k_elbo_loglik_bwd(const float* __restrict__ g0p, const float* __restrict__ g1p, const float* __restrict__ g2p,
+                                  const float* __restrict__ g3p, int nl_rows, const float* __restrict__ hs, const float* __restrict__ hv, int N,
+                                  int q, int M, int Do, const float* __restrict__ Um, const float* __restrict__ Us, float nobs,
+                                  float* __restrict__ glrow, float* __restrict__ ghs, float* __restrict__ ghv, float* __restrict__ dUm,
+                                  float* __restrict__ dUs, int nb_small, const float* __restrict__ X, const float* __restrict__ z,
+                                  float* __restrict__ ga, size_t n, size_t nX) {
+  const float g0 = g0p ? *g0p : 0.f, g1 = g1p ? *g1p : 0.f, g2 = g2p ? *g2p : 0.f, g3 = g3p ? *g3p : 0.f;
+  if ((int)blockIdx.x < nb_small) {
+    const size_t P = (size_t)M * (M + 1) / 2;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (size_t)nl_rows) glrow[e] = (-g0 * nobs - g1) / (float)nl_rows;
+    if (e < (size_t)N * q) {
+      const float gk = (g0 * nobs + g2) / (float)N;
+      const int nn = (int)(e / q), d = (int)(e % q);
+      const size_t im = (size_t)nn * 2 * q + d, il = im + q;
+      ghs[im] = gk * hs[im];
+      ghs[il] = gk * 0.5f * (expf(hs[il]) - 1.f);
+      if (hv) {
+        ghv[im] = gk * hv[im];
+        ghv[il] = gk * 0.5f * (expf(hv[il]) - 1.f);
+      }
+    }
+    const float g = g0 + g3;
+    if (e < (size_t)M * Do) dUm[e] = g * Um[e];
+    if (e < P * Do) {
+      const size_t k = e % P;
+      int r = (int)((sqrtf(8.f * (float)k + 1.f) - 1.f) * 0.5f);
+      while ((size_t)(r + 1) * (r + 2) / 2 <= k) ++r;
+      while ((size_t)r * (r + 1) / 2 > k) --r;
+      const bool diag = (k - (size_t)r * (r + 1) / 2) == (size_t)r;
+      const float v = Us[e];
+      dUs[e] = g * (diag ? v - 1.f / v : v);
+    }
+    return;
+  }
+  const float gl = (-g0 * nobs - g1) / (float)nl_rows;
+  const size_t nb = gridDim.x - nb_small;
+  for (size_t e = ((size_t)blockIdx.x - nb_small) * blockDim.x + threadIdx.x; e < n; e += nb * blockDim.x) {
+    const float xv = X[e % nX], zv = z[e];
+    const float gz = gl * (xv / zv - (1.f - xv) / (1.f - zv));
+    ga[e] = gz * zv * (1.f - zv);
+  }
+}
+
 int sigmoid_loglik_splits(size_t rows, size_t inner) {
   size_t ns = (1024 + rows - 1) / rows, cap = (inner + 1023) / 1024;
   if (ns > cap) ns = cap;
@@ -804,6 +850,19 @@ int elbo_all_bwd(const float* g0, const float* g1, const float* g2, const float*
   hipLaunchKernelGGL(k_elbo_all_bwd, (unsigned)((n + 255) / 256), 256, 0, st, g0, g1, g2, g3, nl_rows, hs, hv, N, q, M, Do, Um, Us, nobs, glrow,
                      ghs, ghv, dUm, dUs);
   return check_launch("elbo_all_bwd");
+}
+
+int elbo_all_bwd_ll(const float* g0, const float* g1, const float* g2, const float* g3, int nl_rows, const float* hs, const float* hv, int N,
+                    int q, int M, int Do, const float* Um, const float* Us, float nobs, float* glrow, float* ghs, float* ghv, float* dUm,
+                    float* dUs, const float* X, const float* z, float* ga, size_t n, size_t nX, hipStream_t st) {
+  size_t ns = (size_t)M * (M + 1) / 2 * Do;
+  if ((size_t)N * q > ns) ns = (size_t)N * q;
+  if ((size_t)nl_rows > ns) ns = nl_rows;
+  if ((size_t)M * Do > ns) ns = (size_t)M * Do;
+  const int nb_small = (int)((ns + 255) / 256);
+  hipLaunchKernelGGL(k_elbo_loglik_bwd, (unsigned)(nb_small + ew_grid(n)), 256, 0, st, g0, g1, g2, g3, nl_rows, hs, hv, N, q, M, Do, Um, Us, nobs,
+                     glrow, ghs, ghv, dUm, dUs, nb_small, X, z, ga, n, nX);
+  return check_launch("elbo_loglik_bwd");
 }
 
 int reparam_fwd(const float* mu, const float* logvar, int ld, const float* eps, float* z, int N, int q, hipStream_t st) {

@@ -718,11 +718,15 @@ class _SigmoidLogLikParts(torch.autograd.Function):
         ctx.rows, ctx.inner = rows, inner
         ctx.mark_non_differentiable(z)
         ctx.set_materialize_grads(False)             # no zero-filled stand-in for the gradient of z (a fill of rows x inner floats per step)
+        part._gpode_ll = (X, z)                      # for elbo_all(): its backward can then produce the logit gradients in the same launch
         return part, z
 
     @staticmethod
     def backward(ctx, gpart, _gz):
         X, z = ctx.saved_tensors
+        ga = getattr(gpart, '_gpode_ga', None)       # already computed by _ElboAll.backward (gpode_elbo_all_bwd_ll)
+        if ga is not None and ga.shape == z.shape:
+            return None, ga, None
         # the ELBO hands every slice of a row the row's gradient: column 0 is the row gradient
         grow = gpart[:, 0].contiguous() if gpart.shape[1] > 1 else gpart.contiguous()
         ga = torch.empty_like(z)
@@ -730,12 +734,16 @@ class _SigmoidLogLikParts(torch.autograd.Function):
         return None, ga, None
 
 
+_ELBO_LL_FUSED = os.environ.get('GPODE_ELBO_LL_SEPARATE', '0') != '1'
+
+
 class _ElboAll(torch.autograd.Function):
     """(loss, -mean lhood, mean KL(z0), KL(u)) of create_model.py:61-73 from the likelihood partial sums, the encoder's packed
     (mu | logvar) rows and the inducing posterior, one launch forward and one backward (gpode_elbo_all_fwd / _bwd)."""
 
     @staticmethod
-    def forward(ctx, lpart, hs, hv, Um, Us, rows, M, nobs):
+    def forward(ctx, lpart, hs, hv, Um, Us, rows, M, nobs, ll=None):
+        ctx.ll = ll if (_ELBO_LL_FUSED and ll is not None and ll[1].numel() % ll[0].numel() == 0) else None
         lpart, hs, Um, Us = _chk(lpart, 'lpart'), _chk(hs, 'hs'), _chk(Um, 'Um'), _chk(Us, 'Us_sqrt.optvar')
         hv = _chk(hv, 'hv') if hv is not None else None
         N, q = hs.shape[0], hs.shape[1] // 2
@@ -755,13 +763,26 @@ class _ElboAll(torch.autograd.Function):
         glrow = _new((rows,), hs)
         ghs, ghv = torch.empty_like(hs), (torch.empty_like(hv) if hv is not None else None)
         dUm, dUs = torch.empty_like(Um), torch.empty_like(Us)
-        _lib.call('gpode_elbo_all_bwd', *[_ptr(g) for g in gs], rows, _ptr(hs), _ptr(hv), N, q, M, Um.shape[1], _ptr(Um), _ptr(Us),
-                  ctypes.c_float(nobs), _ptr(glrow), _ptr(ghs), _ptr(ghv), _ptr(dUm), _ptr(dUs), _stream())
+        ga = None
+        if ctx.ll is not None and ctx.needs_input_grad[0]:
+            # the logits' gradient in the same launch (every likelihood row receives the same gradient): _SigmoidLogLikParts.backward
+            # finds it on the row-gradient tensor it is handed and launches nothing
+            X, z = ctx.ll
+            ga = torch.empty_like(z)
+            _lib.call('gpode_elbo_all_bwd_ll', *[_ptr(g) for g in gs], rows, _ptr(hs), _ptr(hv), N, q, M, Um.shape[1], _ptr(Um), _ptr(Us),
+                      ctypes.c_float(nobs), _ptr(glrow), _ptr(ghs), _ptr(ghv), _ptr(dUm), _ptr(dUs), _ptr(X), _ptr(z), _ptr(ga), z.numel(),
+                      X.numel(), _stream())
+        else:
+            _lib.call('gpode_elbo_all_bwd', *[_ptr(g) for g in gs], rows, _ptr(hs), _ptr(hv), N, q, M, Um.shape[1], _ptr(Um), _ptr(Us),
+                      ctypes.c_float(nobs), _ptr(glrow), _ptr(ghs), _ptr(ghv), _ptr(dUm), _ptr(dUs), _stream())
         if (ctx.needs_input_grad[3] and ctx.needs_input_grad[4] and Um.is_leaf and Us.is_leaf and
                 ops.defer_kl_grads((Um, Us), (dUm, dUs))):
             dUm = dUs = None                         # overlap mode: the flow's deferred backward adds its share to them in place
         # every slice of a likelihood row carries the row's gradient (a broadcast view: nothing is copied)
-        return glrow.view(rows, 1).expand(lshape), ghs, ghv, dUm, dUs, None, None, None
+        glr = glrow.view(rows, 1).expand(lshape)
+        if ga is not None:
+            glr._gpode_ga = ga
+        return glr, ghs, ghv, dUm, dUs, None, None, None, None
 
 
 def sigmoid_loglik_parts(X, logits, rows):
@@ -772,7 +793,7 @@ def sigmoid_loglik_parts(X, logits, rows):
 def elbo_all(lpart, mu_s, logvar_s, mu_v, logvar_v, Um, Us_packed, M, nobs):
     """-> (loss, nll, kl_reg, kl_u), see _ElboAll."""
     hv = _pack(mu_v, logvar_v) if mu_v is not None else None
-    return _ElboAll.apply(lpart, _pack(mu_s, logvar_s), hv, Um, Us_packed, lpart.shape[0], M, float(nobs))
+    return _ElboAll.apply(lpart, _pack(mu_s, logvar_s), hv, Um, Us_packed, lpart.shape[0], M, float(nobs), getattr(lpart, '_gpode_ll', None))
 
 
 def _pack(mu, logvar):
