@@ -391,6 +391,19 @@ int gpode_noise_fill(float* out, long long n_normal, long long n_uniform, unsign
  *   klrow[n] = sum_d KL(N(mu, exp(logvar/2)) || N(0,1)) (create_model.py:47-49, torch.distributions closed form) and its backward;
  *   out[4] = {loss = -(mean(lhood) nobs - mean(klrow) nobs - kl_u), -mean(lhood), mean(klrow), kl_u} (create_model.py:61-73);
  *   backward: gout[4] (gradients of the four outputs) -> glhood[nl], gklrow[nk], gklu[1]. */
+/* The KL(q(z0) || N(0, I)) term riding with the reparameterisation (create_model.py:47-49 next to vae.py:75-78): gpode_reparam_kl_fwd
+ * writes z and klpart[ceil(N q / 256)] = partial sums of the KL terms, which gpode_elbo_all_fwd_kl adds up in place of the packed
+ * (mu | logvar) rows of gpode_elbo_all_fwd (klv / nkv: the velocity encoder's partials of a second-order model, or NULL / 0);
+ * gpode_elbo_all_bwd_ll_kl returns the (uniform) gradient of every partial sum, and gpode_reparam_kl_bwd writes the gradients of
+ * (mu, logvar) through z AND through the KL sum in one pass -- no second gradient tensor for autograd to add. */
+int gpode_reparam_kl_fwd(const float* mu, const float* logvar, int ld, const float* eps, float* z, float* klpart, int N, int q, void* stream);
+int gpode_reparam_kl_bwd(const float* gz, const float* gklpart, const float* mu, const float* logvar, int ld, const float* eps, float* gmu,
+                         float* glogvar, int ldg, int N, int q, void* stream);
+int gpode_elbo_all_fwd_kl(const float* lpart, int nl_rows, int nl_values, const float* kls, int nks, const float* klv, int nkv, int N, int M,
+                          int Do, const float* Um, const float* Us, float nobs, float* out, void* stream);
+int gpode_elbo_all_bwd_ll_kl(const float* g_loss, const float* g_nll, const float* g_kl, const float* g_klu, int nl_rows, int N, int M, int Do,
+                             const float* Um, const float* Us, float nobs, float* glrow, float* gkls, int nks, float* gklv, int nkv,
+                             float* dUm, float* dUs, const float* X, const float* z, float* ga, size_t n_logits, size_t nX, void* stream);
 int gpode_reparam_fwd(const float* mu, const float* logvar, int ld, const float* eps, float* z, int N, int q, void* stream);
 int gpode_reparam_bwd(const float* gz, const float* logvar, int ld, const float* eps, float* gmu, float* glogvar, int ldg, int N, int q,
                       void* stream);

@@ -174,5 +174,11 @@ def test_fused_loss_stage_equals_the_separate_launches(name, kw, L, monkeypatch)
     for a, b in zip(*[res[f][0] for f in (True, False)]):
         assert abs(a - b) <= 2e-6 * max(1.0, abs(b)), (res[True][0], res[False][0])
     assert res[True][1].keys() == res[False][1].keys()
+    # a bias in front of a BatchNorm has NO gradient: both paths hold round-off there (1e-4 of sums of ~1e2 terms), not comparable digits
+    no_grad = ('cnn.0.bias', 'cnn.3.bias', 'decnn.1.bias', 'decnn.4.bias', 'decnn.7.bias')
     for k, gb in res[False][1].items():
+        if k.endswith(no_grad):
+            scale = float(res[False][1][k[:-4] + 'weight'].abs().max())      # the layer's weight gradient: the size of the terms summed
+            assert float(res[True][1][k].abs().max()) < 1e-3 * scale and float(gb.abs().max()) < 1e-3 * scale, (k, scale)
+            continue
         assert float((res[True][1][k] - gb).abs().max()) <= 2e-5 * float(gb.abs().max()) + 1e-7, k

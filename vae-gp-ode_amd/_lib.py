@@ -99,6 +99,10 @@ SIGNATURES.update({
     'gpode_loglik_bwd': (_i, [_c_float_p] * 4 + [_sz, _sz, _vp]),
     'gpode_loglik_rowsum_fwd': (_i, [_c_float_p] * 3 + [_sz, _sz, _sz, _vp]),
     'gpode_noise_fill': (_i, [_vp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_ulonglong, _vp, _vp]),
+    'gpode_reparam_kl_fwd': (_i, [_c_float_p, _c_float_p, _i, _c_float_p, _c_float_p, _c_float_p, _i, _i, _vp]),
+    'gpode_reparam_kl_bwd': (_i, [_c_float_p] * 4 + [_i] + [_c_float_p] * 3 + [_i, _i, _i, _vp]),
+    'gpode_elbo_all_fwd_kl': (_i, [_c_float_p, _i, _i, _c_float_p, _i, _c_float_p, _i, _i, _i, _i, _c_float_p, _c_float_p, _f, _c_float_p, _vp]),
+    'gpode_elbo_all_bwd_ll_kl': (_i, [_c_float_p] * 4 + [_i, _i, _i, _i, _c_float_p, _c_float_p, _f, _c_float_p, _c_float_p, _i, _c_float_p, _i] + [_c_float_p] * 5 + [_sz, _sz, _vp]),
     'gpode_reparam_fwd': (_i, [_c_float_p, _c_float_p, _i, _c_float_p, _c_float_p, _i, _i, _vp]),
     'gpode_reparam_bwd': (_i, [_c_float_p, _c_float_p, _i, _c_float_p, _c_float_p, _c_float_p, _i, _i, _i, _vp]),
     'gpode_normal_kl_fwd': (_i, [_c_float_p, _c_float_p, _i, _c_float_p, _i, _i, _vp]),

@@ -419,6 +419,32 @@ int gpode_noise_fill(float* out, long long n_normal, long long n_uniform, unsign
   if (!out || !state) return gp::set_error("gpode_noise_fill: null pointer");
   return gp::noise_fill(out, n_normal, n_uniform, seed, state, GP_ST);
 }
+int gpode_reparam_kl_fwd(const float* mu, const float* logvar, int ld, const float* eps, float* z, float* klpart, int N, int q, void* stream) {
+  if (N == 0) return 0;
+  if (!mu || !logvar || !eps || !z || !klpart || q < 1 || ld < q) return gp::set_error("gpode_reparam_kl_fwd: bad argument");
+  return gp::reparam_kl_fwd(mu, logvar, ld, eps, z, klpart, N, q, GP_ST);
+}
+int gpode_reparam_kl_bwd(const float* gz, const float* gklpart, const float* mu, const float* logvar, int ld, const float* eps, float* gmu,
+                         float* glogvar, int ldg, int N, int q, void* stream) {
+  if (N == 0) return 0;
+  if (!mu || !logvar || !eps || !gmu || !glogvar || q < 1 || ld < q || ldg < q) return gp::set_error("gpode_reparam_kl_bwd: bad argument");
+  return gp::reparam_kl_bwd(gz, gklpart, mu, logvar, ld, eps, gmu, glogvar, ldg, N, q, GP_ST);
+}
+int gpode_elbo_all_fwd_kl(const float* lpart, int nl_rows, int nl_values, const float* kls, int nks, const float* klv, int nkv, int N, int M,
+                          int Do, const float* Um, const float* Us, float nobs, float* out, void* stream) {
+  if (!lpart || !kls || !Um || !Us || !out || (nkv > 0 && !klv)) return gp::set_error("gpode_elbo_all_fwd_kl: null pointer");
+  if (nl_rows < 1 || nl_values < nl_rows || N < 1 || M < 1 || Do < 1 || nks < 1 || nkv < 0) return gp::set_error("gpode_elbo_all_fwd_kl: bad sizes");
+  return gp::elbo_all_fwd_kl(lpart, nl_rows, nl_values, kls, nks, klv, nkv, N, M, Do, Um, Us, nobs, out, GP_ST);
+}
+int gpode_elbo_all_bwd_ll_kl(const float* g_loss, const float* g_nll, const float* g_kl, const float* g_klu, int nl_rows, int N, int M, int Do,
+                             const float* Um, const float* Us, float nobs, float* glrow, float* gkls, int nks, float* gklv, int nkv,
+                             float* dUm, float* dUs, const float* X, const float* z, float* ga, size_t n_logits, size_t nX, void* stream) {
+  if (!Um || !Us || !glrow || !gkls || !dUm || !dUs || (nkv > 0 && !gklv) || !X || !z || !ga) return gp::set_error("gpode_elbo_all_bwd_ll_kl: null pointer");
+  if (nl_rows < 1 || N < 1 || M < 1 || Do < 1 || nks < 1 || nkv < 0 || n_logits < 1 || nX < 1 || n_logits % nX != 0)
+    return gp::set_error("gpode_elbo_all_bwd_ll_kl: bad sizes");
+  return gp::elbo_all_bwd_ll_kl(g_loss, g_nll, g_kl, g_klu, nl_rows, N, M, Do, Um, Us, nobs, glrow, gkls, nks, gklv, nkv, dUm, dUs, X, z, ga,
+                                n_logits, nX, GP_ST);
+}
 int gpode_reparam_fwd(const float* mu, const float* logvar, int ld, const float* eps, float* z, int N, int q, void* stream) {
   if (N == 0) return 0;
   if (!mu || !logvar || !eps || !z || q < 1 || ld < q) return gp::set_error("gpode_reparam_fwd: bad argument");

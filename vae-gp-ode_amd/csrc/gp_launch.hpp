@@ -175,6 +175,14 @@ int loglik_rowsum_bwd(const float* X, const float* z, const float* grow, float* 
 int elbo_all_bwd_ll(const float* g0, const float* g1, const float* g2, const float* g3, int nl_rows, const float* hs, const float* hv, int N,
                     int q, int M, int Do, const float* Um, const float* Us, float nobs, float* glrow, float* ghs, float* ghv, float* dUm,
                     float* dUs, const float* X, const float* z, float* ga, size_t n, size_t nX, hipStream_t st);
+int reparam_kl_fwd(const float* mu, const float* logvar, int ld, const float* eps, float* z, float* klpart, int N, int q, hipStream_t st);
+int reparam_kl_bwd(const float* gz, const float* gklpart, const float* mu, const float* logvar, int ld, const float* eps, float* gmu,
+                   float* glogvar, int ldg, int N, int q, hipStream_t st);
+int elbo_all_fwd_kl(const float* lpart, int nl_rows, int nl_values, const float* kls, int nks, const float* klv, int nkv, int N, int M, int Do,
+                    const float* Um, const float* Us, float nobs, float* out, hipStream_t st);
+int elbo_all_bwd_ll_kl(const float* g0, const float* g1, const float* g2, const float* g3, int nl_rows, int N, int M, int Do, const float* Um,
+                       const float* Us, float nobs, float* glrow, float* gkls, int nks, float* gklv, int nkv, float* dUm, float* dUs,
+                       const float* X, const float* z, float* ga, size_t n, size_t nX, hipStream_t st);
 int reparam_fwd(const float* mu, const float* logvar, int ld, const float* eps, float* z, int N, int q, hipStream_t st);
 int reparam_bwd(const float* gz, const float* logvar, int ld, const float* eps, float* gmu, float* glogvar, int ldg, int N, int q, hipStream_t st);
 int normal_kl_fwd(const float* mu, const float* logvar, int ld, float* klrow, int N, int q, hipStream_t st);

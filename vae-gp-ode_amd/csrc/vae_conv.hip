@@ -561,6 +561,40 @@ __global__ void k_reparam_bwd(const float* __restrict__ gz, const float* __restr
   gmu[(size_t)n * ldg + d] = g;
   glogvar[(size_t)n * ldg + d] = g * eps[e] * (0.5f * expf(0.5f * logvar[(size_t)n * ld + d]));
 }
+// z = mu + exp(logvar / 2) eps AND the workgroup's share of sum_{n,d} KL(N(mu, sigma) || N(0, 1)): klpart[blockIdx.x] (summed by the ELBO
+// kernel, so the KL term needs no pass of its own over (mu, logvar)); backward: the two gradients of (mu, logvar) -- through z and through the
+// KL sum (gkl: the same value for every term) -- in one write, instead of two tensors that autograd then adds
+__global__ __launch_bounds__(256) void k_reparam_kl_fwd(const float* __restrict__ mu, const float* __restrict__ logvar, int ld,
+                                                         const float* __restrict__ eps, float* __restrict__ z, float* __restrict__ klpart, int N,
+                                                         int q) {
+  __shared__ float red[4];
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  float kl = 0.f;
+  if (e < N * q) {
+    const int n = e / q, d = e % q;
+    const float m = mu[(size_t)n * ld + d], sg = expf(0.5f * logvar[(size_t)n * ld + d]);
+    z[e] = m + sg * eps[e];
+    const float vr = sg * sg;
+    kl = 0.5f * (vr + m * m - 1.f - logf(vr));
+  }
+  const float in1[1] = {kl};
+  float out1[1];
+  wave_sum_multi<1>(in1, out1);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = out1[0];
+  __syncthreads();
+  if (threadIdx.x == 0) klpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void k_reparam_kl_bwd(const float* __restrict__ gz, const float* __restrict__ gklpart, const float* __restrict__ mu,
+                                 const float* __restrict__ logvar, int ld, const float* __restrict__ eps, float* __restrict__ gmu,
+                                 float* __restrict__ glogvar, int ldg, int N, int q) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * q) return;
+  const int n = e / q, d = e % q;
+  const float g = gz ? gz[e] : 0.f, gk = gklpart ? gklpart[blockIdx.x] : 0.f;
+  const float m = mu[(size_t)n * ld + d], lv = logvar[(size_t)n * ld + d];
+  gmu[(size_t)n * ldg + d] = g + gk * m;
+  glogvar[(size_t)n * ldg + d] = g * eps[e] * (0.5f * expf(0.5f * lv)) + gk * 0.5f * (expf(lv) - 1.f);
+}
 // one thread per sample
 __global__ void k_normal_kl_fwd(const float* __restrict__ mu, const float* __restrict__ logvar, int ld, float* __restrict__ klrow, int N,
                                 int q) {
@@ -682,7 +716,9 @@ __global__ __launch_bounds__(256) void k_sumsq_parts(const float* __restrict__ v
 __global__ __launch_bounds__(1024) void k_elbo_all_fwd(const float* __restrict__ lpart, int nl_rows, int nl_values, const float* __restrict__ hs,
                                                         const float* __restrict__ hv, int N, int q, int M, int Do,
                                                         const float* __restrict__ Um, const float* __restrict__ Us, float nobs,
-                                                        float* __restrict__ out, const float* __restrict__ usq_part) {
+                                                        float* __restrict__ out, const float* __restrict__ usq_part,
+                                                        const float* __restrict__ kls = nullptr, int nks = 0,
+                                                        const float* __restrict__ klv = nullptr, int nkv = 0) {
   __shared__ float red[16][3];
   const size_t P = (size_t)M * (M + 1) / 2;
   float u = 0.f, a = 0.f, b = 0.f;
@@ -698,7 +734,10 @@ __global__ __launch_bounds__(1024) void k_elbo_all_fwd(const float* __restrict__
     u += v * v - logf(l * l);
   }
   for (int i = threadIdx.x; i < nl_values; i += blockDim.x) a += lpart[i];
-  for (int e = threadIdx.x; e < N * q; e += blockDim.x) {
+  // hs == nullptr: the KL terms arrive summed per workgroup of k_reparam_kl_fwd (kls / klv)
+  for (int e = threadIdx.x; e < nks; e += blockDim.x) b += kls[e];
+  for (int e = threadIdx.x; e < nkv; e += blockDim.x) b += klv[e];
+  for (int e = threadIdx.x; hs && e < N * q; e += blockDim.x) {
     const int n = e / q, d = e % q;
     {
       const float m = hs[(size_t)n * 2 * q + d], sg = expf(0.5f * hs[(size_t)n * 2 * q + q + d]);
@@ -768,13 +807,16 @@ __global__ void k_elbo_loglik_bwd(const float* __restrict__ g0p, const float* __
                                   int q, int M, int Do, const float* __restrict__ Um, const float* __restrict__ Us, float nobs,
                                   float* __restrict__ glrow, float* __restrict__ ghs, float* __restrict__ ghv, float* __restrict__ dUm,
                                   float* __restrict__ dUs, int nb_small, const float* __restrict__ X, const float* __restrict__ z,
-                                  float* __restrict__ ga, size_t n, size_t nX) {
+                                  float* __restrict__ ga, size_t n, size_t nX, float* __restrict__ gkls = nullptr, int nks = 0,
+                                  float* __restrict__ gklv = nullptr, int nkv = 0) {
   const float g0 = g0p ? *g0p : 0.f, g1 = g1p ? *g1p : 0.f, g2 = g2p ? *g2p : 0.f, g3 = g3p ? *g3p : 0.f;
   if ((int)blockIdx.x < nb_small) {
     const size_t P = (size_t)M * (M + 1) / 2;
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < (size_t)nl_rows) glrow[e] = (-g0 * nobs - g1) / (float)nl_rows;
-    if (e < (size_t)N * q) {
+    if (e < (size_t)nks) gkls[e] = (g0 * nobs + g2) / (float)N;         // hs == nullptr: d loss / d (KL partial sum), the same for all
+    if (e < (size_t)nkv) gklv[e] = (g0 * nobs + g2) / (float)N;
+    if (hs && e < (size_t)N * q) {
       const float gk = (g0 * nobs + g2) / (float)N;
       const int nn = (int)(e / q), d = (int)(e % q);
       const size_t im = (size_t)nn * 2 * q + d, il = im + q;
@@ -837,7 +879,7 @@ int elbo_all_fwd(const float* lpart, int nl_rows, int nl_values, const float* hs
     hipLaunchKernelGGL(k_sumsq_parts, kElboParts, 256, 0, st, Us, nus, out + 4);
     usq = out + 4;
   }
-  hipLaunchKernelGGL(k_elbo_all_fwd, 1, 1024, 0, st, lpart, nl_rows, nl_values, hs, hv, N, q, M, Do, Um, Us, nobs, out, usq);
+  hipLaunchKernelGGL(k_elbo_all_fwd, 1, 1024, 0, st, lpart, nl_rows, nl_values, hs, hv, N, q, M, Do, Um, Us, nobs, out, usq, (const float*)nullptr, 0, (const float*)nullptr, 0);
   return check_launch("elbo_all_fwd");
 }
 int elbo_all_bwd(const float* g0, const float* g1, const float* g2, const float* g3, int nl_rows, const float* hs, const float* hv, int N,
@@ -861,10 +903,45 @@ int elbo_all_bwd_ll(const float* g0, const float* g1, const float* g2, const flo
   if ((size_t)M * Do > ns) ns = (size_t)M * Do;
   const int nb_small = (int)((ns + 255) / 256);
   hipLaunchKernelGGL(k_elbo_loglik_bwd, (unsigned)(nb_small + ew_grid(n)), 256, 0, st, g0, g1, g2, g3, nl_rows, hs, hv, N, q, M, Do, Um, Us, nobs,
-                     glrow, ghs, ghv, dUm, dUs, nb_small, X, z, ga, n, nX);
+                     glrow, ghs, ghv, dUm, dUs, nb_small, X, z, ga, n, nX, (float*)nullptr, 0, (float*)nullptr, 0);
   return check_launch("elbo_loglik_bwd");
 }
 
+int reparam_kl_fwd(const float* mu, const float* logvar, int ld, const float* eps, float* z, float* klpart, int N, int q, hipStream_t st) {
+  hipLaunchKernelGGL(k_reparam_kl_fwd, (N * q + 255) / 256, 256, 0, st, mu, logvar, ld, eps, z, klpart, N, q);
+  return check_launch("reparam_kl_fwd");
+}
+int reparam_kl_bwd(const float* gz, const float* gklpart, const float* mu, const float* logvar, int ld, const float* eps, float* gmu,
+                   float* glogvar, int ldg, int N, int q, hipStream_t st) {
+  hipLaunchKernelGGL(k_reparam_kl_bwd, (N * q + 255) / 256, 256, 0, st, gz, gklpart, mu, logvar, ld, eps, gmu, glogvar, ldg, N, q);
+  return check_launch("reparam_kl_bwd");
+}
+int elbo_all_fwd_kl(const float* lpart, int nl_rows, int nl_values, const float* kls, int nks, const float* klv, int nkv, int N, int M, int Do,
+                    const float* Um, const float* Us, float nobs, float* out, hipStream_t st) {
+  const size_t nus = (size_t)M * (M + 1) / 2 * Do;
+  const float* usq = nullptr;
+  if (nus > ((size_t)1 << 16)) {
+    hipLaunchKernelGGL(k_sumsq_parts, kElboParts, 256, 0, st, Us, nus, out + 4);
+    usq = out + 4;
+  }
+  hipLaunchKernelGGL(k_elbo_all_fwd, 1, 1024, 0, st, lpart, nl_rows, nl_values, (const float*)nullptr, (const float*)nullptr, N, 1, M, Do, Um, Us, nobs,
+                     out, usq, kls, nks, klv, nkv);
+  return check_launch("elbo_all_fwd_kl");
+}
+int elbo_all_bwd_ll_kl(const float* g0, const float* g1, const float* g2, const float* g3, int nl_rows, int N, int M, int Do, const float* Um,
+                       const float* Us, float nobs, float* glrow, float* gkls, int nks, float* gklv, int nkv, float* dUm, float* dUs,
+                       const float* X, const float* z, float* ga, size_t n, size_t nX, hipStream_t st) {
+  size_t ns = (size_t)M * (M + 1) / 2 * Do;
+  if ((size_t)nl_rows > ns) ns = nl_rows;
+  if ((size_t)M * Do > ns) ns = (size_t)M * Do;
+  if ((size_t)nks > ns) ns = nks;
+  if ((size_t)nkv > ns) ns = nkv;
+  const int nb_small = (int)((ns + 255) / 256);
+  float* nf = nullptr;
+  hipLaunchKernelGGL(k_elbo_loglik_bwd, (unsigned)(nb_small + ew_grid(n)), 256, 0, st, g0, g1, g2, g3, nl_rows, (const float*)nullptr,
+                     (const float*)nullptr, N, 1, M, Do, Um, Us, nobs, glrow, nf, nf, dUm, dUs, nb_small, X, z, ga, n, nX, gkls, nks, gklv, nkv);
+  return check_launch("elbo_loglik_bwd_kl");
+}
 int reparam_fwd(const float* mu, const float* logvar, int ld, const float* eps, float* z, int N, int q, hipStream_t st) {
   hipLaunchKernelGGL(k_reparam_fwd, (N * q + 255) / 256, 256, 0, st, mu, logvar, ld, eps, z, N, q);
   return check_launch("reparam_fwd");

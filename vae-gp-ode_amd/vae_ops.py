@@ -661,6 +661,33 @@ class _Reparam(torch.autograd.Function):
         return g, None
 
 
+class _ReparamKL(torch.autograd.Function):
+    """_Reparam that also returns the partial sums of KL(q(z0) || N(0, I)) over its workgroups (gpode_reparam_kl_fwd): the ELBO adds
+    them up instead of reading (mu | logvar) again, and the backward writes the gradient of h = [mu | logvar] through z AND through
+    the KL sum in one launch -- otherwise two gradient tensors that autograd adds in a launch of its own."""
+
+    @staticmethod
+    def forward(ctx, h, eps):
+        h = _chk(h, 'h')
+        N, q = h.shape[0], h.shape[1] // 2
+        eps = _chk(eps, 'eps', (N, q))
+        z, klpart = _new((N, q), h), _new(((N * q + 255) // 256,), h)
+        _lib.call('gpode_reparam_kl_fwd', _ptr(h), ctypes.c_void_p(h.data_ptr() + 4 * q), 2 * q, _ptr(eps), _ptr(z), _ptr(klpart), N, q, _stream())
+        ctx.save_for_backward(h, eps)
+        ctx.set_materialize_grads(False)
+        return z, klpart
+
+    @staticmethod
+    def backward(ctx, gz, gkl):
+        h, eps = ctx.saved_tensors
+        N, q = h.shape[0], h.shape[1] // 2
+        g = _new(h.shape, h)
+        _lib.call('gpode_reparam_kl_bwd', _ptr(gz.contiguous() if gz is not None else None), _ptr(gkl.contiguous() if gkl is not None else None),
+                  _ptr(h), ctypes.c_void_p(h.data_ptr() + 4 * q), 2 * q, _ptr(eps), _ptr(g), ctypes.c_void_p(g.data_ptr() + 4 * q), 2 * q, N, q,
+                  _stream())
+        return g, None
+
+
 class _NormalKL(torch.autograd.Function):
     """sum_d KL(N(mu, exp(logvar/2)) || N(0, 1)) per row (what kl_divergence(q_dist, prior).sum(-1) evaluates,
     create_model.py:47-49); h = [mu | logvar] packed (N, 2q)."""
@@ -790,8 +817,52 @@ def sigmoid_loglik_parts(X, logits, rows):
     return _SigmoidLogLikParts.apply(X, logits, rows)
 
 
+class _ElboAllKL(torch.autograd.Function):
+    """_ElboAll on the KL partial sums of _ReparamKL instead of the packed (mu | logvar) rows (gpode_elbo_all_fwd_kl /
+    gpode_elbo_all_bwd_ll_kl); its backward also produces the logits' gradient (ll = (X, z) of sigmoid_loglik_parts)."""
+
+    @staticmethod
+    def forward(ctx, lpart, kls, klv, Um, Us, rows, N, M, nobs, ll):
+        lpart, kls, Um, Us = _chk(lpart, 'lpart'), _chk(kls, 'kl partial sums'), _chk(Um, 'Um'), _chk(Us, 'Us_sqrt.optvar')
+        klv = _chk(klv, 'kl partial sums (v)') if klv is not None else None
+        out = _new((4 + 256,), lpart)
+        _lib.call('gpode_elbo_all_fwd_kl', _ptr(lpart), rows, lpart.numel(), _ptr(kls), kls.numel(), _ptr(klv), klv.numel() if klv is not None else 0,
+                  N, M, Um.shape[1], _ptr(Um), _ptr(Us), ctypes.c_float(nobs), _ptr(out), _stream())
+        ctx.save_for_backward(Um, Us)
+        ctx.dims = (rows, N, M, float(nobs), tuple(lpart.shape), kls.numel(), klv.numel() if klv is not None else 0)
+        ctx.ll = ll
+        ctx.set_materialize_grads(False)
+        return out[0], out[1], out[2], out[3]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2, g3):
+        Um, Us = ctx.saved_tensors
+        rows, N, M, nobs, lshape, nks, nkv = ctx.dims
+        gs = [None if g is None else g.contiguous().float() for g in (g0, g1, g2, g3)]
+        X, z = ctx.ll
+        glrow, gkls, gklv = _new((rows,), Um), _new((nks,), Um), (_new((nkv,), Um) if nkv else None)
+        dUm, dUs, ga = torch.empty_like(Um), torch.empty_like(Us), torch.empty_like(z)
+        _lib.call('gpode_elbo_all_bwd_ll_kl', *[_ptr(g) for g in gs], rows, N, M, Um.shape[1], _ptr(Um), _ptr(Us), ctypes.c_float(nobs),
+                  _ptr(glrow), _ptr(gkls), nks, _ptr(gklv), nkv, _ptr(dUm), _ptr(dUs), _ptr(X), _ptr(z), _ptr(ga), z.numel(), X.numel(), _stream())
+        if (ctx.needs_input_grad[3] and ctx.needs_input_grad[4] and Um.is_leaf and Us.is_leaf and
+                ops.defer_kl_grads((Um, Us), (dUm, dUs))):
+            dUm = dUs = None
+        glr = glrow.view(rows, 1).expand(lshape)
+        glr._gpode_ga = ga
+        return glr, gkls, gklv, dUm, dUs, None, None, None, None, None
+
+
 def elbo_all(lpart, mu_s, logvar_s, mu_v, logvar_v, Um, Us_packed, M, nobs):
     """-> (loss, nll, kl_reg, kl_u), see _ElboAll."""
+    ll = getattr(lpart, '_gpode_ll', None)
+    hs0 = _packed_halves(mu_s, logvar_s)
+    kls = getattr(hs0, '_gpode_klpart', None) if hs0 is not None else None
+    klv = None
+    if mu_v is not None:
+        hv0 = _packed_halves(mu_v, logvar_v)
+        klv = getattr(hv0, '_gpode_klpart', None) if hv0 is not None else None
+    if (_ELBO_LL_FUSED and ll is not None and ll[1].numel() % ll[0].numel() == 0 and kls is not None and (mu_v is None or klv is not None)):
+        return _ElboAllKL.apply(lpart, kls, klv, Um, Us_packed, lpart.shape[0], mu_s.shape[0], M, float(nobs), ll)
     hv = _pack(mu_v, logvar_v) if mu_v is not None else None
     return _ElboAll.apply(lpart, _pack(mu_s, logvar_s), hv, Um, Us_packed, lpart.shape[0], M, float(nobs), getattr(lpart, '_gpode_ll', None))
 
@@ -801,7 +872,16 @@ def _pack(mu, logvar):
     return h if h is not None else torch.cat((mu, logvar), dim=1)
 
 
+_REPARAM_KL = os.environ.get('GPODE_REPARAM_KL_SEPARATE', '0') != '1'
+
+
 def reparam(mu, logvar, eps):
+    h = _packed_halves(mu, logvar)
+    if h is not None and _REPARAM_KL and h.requires_grad:
+        # (mu | logvar) are the halves of the encoder's fc output: the KL term's partial sums ride along for elbo_all()
+        z, klpart = _ReparamKL.apply(h, eps)
+        h._gpode_klpart = klpart
+        return z
     return _Reparam.apply(_pack(mu, logvar), eps)
 
 
