@@ -60,16 +60,23 @@ __device__ __forceinline__ void bn_sink_publish(const BnSink& s, const float* sm
   const int nwg = gridDim.x;
   {
     const int e = tid % (2 * C), sl = tid / (2 * C);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // U independent loads in flight per thread: a device-scope load takes ~1 us, and decnn.1 (C = 64, 512 workgroups, 2 slices)
+    // has 256 of them per thread -- four at a time made this tail as long as the convolution itself
+    constexpr int U = 16;
+    float a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = 0.f;
     int g = sl;
-    for (; g + 3 * NSL < nwg; g += 4 * NSL) {
-      a0 += load_dev(s.part + (size_t)g * (2 * C) + e);
-      a1 += load_dev(s.part + (size_t)(g + NSL) * (2 * C) + e);
-      a2 += load_dev(s.part + (size_t)(g + 2 * NSL) * (2 * C) + e);
-      a3 += load_dev(s.part + (size_t)(g + 3 * NSL) * (2 * C) + e);
+    for (; g + (U - 1) * NSL < nwg; g += U * NSL) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) a[u] += load_dev(s.part + (size_t)(g + u * NSL) * (2 * C) + e);
     }
-    for (; g < nwg; g += NSL) a0 += load_dev(s.part + (size_t)g * (2 * C) + e);
-    s_fin[tid] = (a0 + a1) + (a2 + a3);
+    for (; g < nwg; g += NSL) a[0] += load_dev(s.part + (size_t)g * (2 * C) + e);
+#pragma unroll
+    for (int w = 1; w < U; w *= 2)
+#pragma unroll
+      for (int u = 0; u + w < U; u += 2 * w) a[u] += a[u + w];
+    s_fin[tid] = a[0];
   }
   __syncthreads();
   if (tid < C) {

@@ -157,6 +157,7 @@ class SVGP_Layer(torch.nn.Module):
         # waits for it) and stays referenced by the cache until the step's join
         nz, params = self._cache_inputs(draws=draws)
         side = ops.fork_side_stream()
+        ops.start_marker()
         with ops.launch_on(side):
             self._prebuilt = cache = self._launch_cache_build(nz, params)
         # the flow waits for THIS point of the side stream only; the gradient-independent half of the cache backward (L^-1 from the

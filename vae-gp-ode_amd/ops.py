@@ -107,6 +107,15 @@ def _main_marker():
     d.zero_()
 
 
+_START_MARKER = os.environ.get('GPODE_START_MARKER', '0') == '1'
+
+
+def start_marker():
+    """EXPERIMENT (GPODE_START_MARKER=1): the main branch's node created first at the fork that opens the step as well."""
+    if _START_MARKER and _overlap['on']:
+        _main_marker()
+
+
 def defer_kl_grads(params, grads):
     """Overlap mode: the gradients of KL(q(u)||p(u)) w.r.t. (Um, Us) -- written at the very start of the backward pass -- are
     not handed to autograd (which would add the flow's gradients to them in a launch of its own per tensor) but kept for the
