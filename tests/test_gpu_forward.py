@@ -281,3 +281,21 @@ torch.save(out, sys.argv[1])
         for a, b, what in zip(res['wide'][name], res['team4'][name], ('zt', 'gz0', 'astage')):
             e = relerr(a, b)
             assert e < (2e-5 if what == 'zt' else 2e-4), (name, what, e)
+
+
+def test_deep_back_substitution_matches_the_one_step_prefetch(tmp_path):
+    """k_solve_back_deep (1024 threads, three block rows in flight, n <= 1024) does the arithmetic of k_solve_back in the same order
+    per column: nu is bit-identical to a process that runs with GPODE_SOLVE_BACK_DEEP=0 (the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    names = [('gp_df1_cfg2', 'DF'), ('gp_df1_tiny_q10', 'DF')]      # (600 x 600: the launch chain; the small one is LDS-resident either way)
+    out = str(tmp_path / 'nu.pt')
+    code = ("import sys, torch; sys.path[:0] = [%r, %r]; import conftest; from test_gpu_forward import build; from conftest import load_golden\n"
+            "torch.save({n: build(load_golden(n), k, want_Lu=False).nu.cpu() for n, k in %r}, %r)\n"
+            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), names, out))
+    env = dict(os.environ, GPODE_SOLVE_BACK_DEEP='0')
+    subprocess.run([sys.executable, '-c', code], check=True, env=env, timeout=600)
+    ref = torch.load(out)
+    for n, k in names:
+        assert torch.equal(build(load_golden(n), k, want_Lu=False).nu.cpu(), ref[n]), n

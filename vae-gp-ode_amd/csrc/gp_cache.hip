@@ -767,6 +767,110 @@ __global__ __launch_bounds__(256) void k_solve_back(const float* __restrict__ Aa
   }
 }
 
+// k_solve_back for n <= 1024 with the loads off the chain for good: 1024 threads, thread c owns COLUMN c of the residual and keeps the
+// block rows of the next THREE steps in registers (a load issued at the end of step k is used in step k - 3: ~2 us later, the latency
+// of a line another XCD has just written), and all diagonal blocks sit in LDS from the start.  k_solve_back<1> fetched one step
+// ahead with a quarter of its threads (4 columns each): every one of the 19 steps of the 600 x 600 DF system waited for its block
+// row -- 57 us for 0.7 MB.  Same arithmetic in the same order per column, so the results are bit-identical to k_solve_back's.
+constexpr int SBD_THREADS = 1024, SBD_STAGES = 3;
+__global__ __launch_bounds__(SBD_THREADS) void k_solve_back_deep(const float* __restrict__ Aall, int n, int np, size_t batch_stride,
+                                                                const float* __restrict__ Dfac_all, size_t dfac_stride,
+                                                                const float* __restrict__ u, int u_stride, int u_bstride,
+                                                                float* __restrict__ nu, float* __restrict__ nu_out,
+                                                                int kernel, int Di, int Do, int M, const float* __restrict__ var,
+                                                                float* __restrict__ pack_ind, size_t u_dstride, size_t nu_dstride,
+                                                                size_t pack_dstride) {
+  extern __shared__ __attribute__((aligned(16))) float sv[];  // np floats: residual, overwritten by the solution; then nblk diagonal blocks
+  __shared__ __attribute__((aligned(16))) float sx[NB];
+  const int b = blockIdx.x, dr = blockIdx.y;
+  const float* A = Aall + (size_t)b * batch_stride;
+  const float* Dfac = Dfac_all + (size_t)b * dfac_stride;
+  u += (size_t)dr * u_dstride;
+  nu += (size_t)dr * nu_dstride;
+  if (nu_out) nu_out += (size_t)dr * nu_dstride;
+  if (pack_ind) pack_ind += (size_t)dr * pack_dstride;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nblk = cdiv(n, NB);
+  float* sD = sv + np;
+  float cur[SBD_STAGES][NB];
+  auto prefetch = [&](float (&dst)[NB], int k) {      // rows of block k, this thread's column (left of the diagonal block only)
+    if (k < 1 || tid >= k * NB) return;
+    const float* src = A + (size_t)k * NB * np + tid;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) dst[r] = src[(size_t)r * np];
+  };
+  prefetch(cur[0], nblk - 1);
+  prefetch(cur[1], nblk - 2);
+  prefetch(cur[2], nblk - 3);
+  const int rr = n + dr, kl = rr / NB, cl = kl * NB;  // block holding the rhs row
+  for (int j = tid; j < np; j += SBD_THREADS) {
+    float y = 0.f;
+    if (j < n) y = (j < cl) ? A[(size_t)rr * np + j] : Dfac[(size_t)kl * NB * NB + (rr - cl) * NB + (j - cl)];
+    sv[j] = j < n ? u[(size_t)j * u_stride + (size_t)b * u_bstride] - y : 0.f;
+  }
+  for (int e = tid; e < nblk * NB * NB / 4; e += SBD_THREADS)
+    reinterpret_cast<float4*>(sD)[e] = reinterpret_cast<const float4*>(Dfac)[e];
+  __syncthreads();
+  const int cc = lane & 31;
+  auto step = [&](int k, float (&mine)[NB]) {
+    const int c0 = k * NB;
+    if (tid < 64) {
+      // 32x32 transposed solve in wave 0: lane c holds residual c and reads column c of L_kk from LDS, eight rows at a time
+      const float* Lk = sD + (size_t)k * NB * NB + cc;
+      float res = sv[c0 + cc];
+      const float myinv = 1.f / Lk[cc * NB];
+#pragma unroll
+      for (int rb = NB - 8; rb >= 0; rb -= 8) {
+        float Lc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) Lc[r] = Lk[(rb + r) * NB];
+#pragma unroll
+        for (int r8 = 7; r8 >= 0; --r8) {
+          const int r = rb + r8;
+          float xr = GP_BCAST(res, r) * GP_BCAST(myinv, r);
+          xr = (c0 + r < n) ? xr : 0.f;
+          res = (cc == r) ? xr : fmaf(-Lc[r8], xr, res);
+        }
+      }
+      if (lane < NB) { sx[lane] = res; sv[c0 + lane] = res; }
+    }
+    __syncthreads();
+    if (tid < c0) {
+      float acc = sv[tid];
+#pragma unroll
+      for (int r4 = 0; r4 < NB / 4; ++r4) {
+        const float4 x = reinterpret_cast<const float4*>(sx)[r4];
+        acc = fmaf(-mine[4 * r4 + 0], x.x, acc); acc = fmaf(-mine[4 * r4 + 1], x.y, acc);
+        acc = fmaf(-mine[4 * r4 + 2], x.z, acc); acc = fmaf(-mine[4 * r4 + 3], x.w, acc);
+      }
+      sv[tid] = acc;
+    }
+    prefetch(mine, k - SBD_STAGES);
+    __syncthreads();
+  };
+  for (int k = nblk - 1; k >= 0; k -= SBD_STAGES) {
+    step(k, cur[0]);
+    if (k - 1 >= 0) step(k - 1, cur[1]);
+    if (k - 2 >= 0) step(k - 2, cur[2]);
+  }
+  for (int j = tid; j < n; j += SBD_THREADS) {
+    const float v = sv[j];
+    nu[(size_t)b * n + j] = v;
+    if (nu_out) nu_out[(size_t)b * n + j] = v;
+    if (!pack_ind) continue;
+    const int RQ2 = cdiv(Di + Do, 4);
+    int m, d;
+    float coef;
+    if (kernel == 0) { m = j; d = b; coef = var[d] * v; } else { m = j / Do; d = j % Do; coef = v; }
+    const int field = Di + d;
+    pack_ind[(((size_t)(m >> 6) * RQ2 + (field >> 2)) * 64 + (m & 63)) * 4 + (field & 3)] = coef;
+  }
+}
+inline bool solve_back_deep_fits(int np, int nblk) {
+  static const bool off = [] { const char* e = getenv("GPODE_SOLVE_BACK_DEEP"); return e && e[0] == '0'; }();
+  return !off && np <= SBD_THREADS && sizeof(float) * ((size_t)np + (size_t)nblk * NB * NB) <= 150 * 1024;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_draw_lds: K(Z) + jitter I, its Cholesky factor and nu = L^-T (u - L^-1 f_prior(Z)) in ONE launch, one 512-thread
 // workgroup per system (RBF: one per output dimension; DF: the single (M D)^2 system), the whole matrix resident in LDS
@@ -1306,6 +1410,14 @@ int cache_build_fwd(int kernel, int Di, int Do, int M, int S, int nd,
     hipLaunchKernelGGL(k_nu_publish, dim3(cdiv(w.n, 256), w.batch, nd), 256, 0, st, w.n, ws + w.nu, nu, kernel, Di, Do, ws + w.var, pack_ind,
                        MD, pf);
   } else {
+    if (solve_back_deep_fits(w.np, w.nblk)) {
+      const size_t ldsd = sizeof(float) * ((size_t)w.np + (size_t)w.nblk * NB * NB);
+      if (set_max_lds((const void*)k_solve_back_deep, ldsd)) return 1;
+      hipLaunchKernelGGL(k_solve_back_deep, dim3(w.batch, nd), SBD_THREADS, ldsd, st, Lmat, w.n, w.np, bstride, Dfac, dstride, ws + w.u,
+                         u_stride, u_bstride, ws + w.nu, nu, kernel, Di, Do, M, ws + w.var, pack_ind, MD, MD, pf);
+      if (Lu) hipLaunchKernelGGL(k_copy_L, dim3(cdiv(w.n, 128), w.n, w.batch), 128, 0, st, Lmat, Dfac, dstride, w.n, w.np, bstride, Lu);
+      return check_launch("cache build");
+    }
     const size_t lds = sizeof(float) * w.np;
     const int cpt = cdiv(w.n, 1024);  // 4 columns per thread per unit
 #define GP_SOLVE(CPT)                                                                                              \
@@ -1395,6 +1507,13 @@ int compute_nu(int kernel, int Di, int Do, int M, const float* Ku, const float* 
     hipLaunchKernelGGL(k_nu_publish, dim3(cdiv(w.n, 256), w.batch, 1), 256, 0, st, w.n, ws + w.nu, nu, kernel, Di, Do, (const float*)nullptr,
                        (float*)nullptr, MD, (size_t)0);
   } else {
+    if (solve_back_deep_fits(w.np, w.nblk)) {
+      const size_t ldsd = sizeof(float) * ((size_t)w.np + (size_t)w.nblk * NB * NB);
+      if (set_max_lds((const void*)k_solve_back_deep, ldsd)) return 1;
+      hipLaunchKernelGGL(k_solve_back_deep, dim3(w.batch, 1), SBD_THREADS, ldsd, st, Lmat, w.n, w.np, bstride, Dfac, dstride, u, u_stride,
+                         u_bstride, ws + w.nu, nu, kernel, Di, Do, M, (const float*)nullptr, (float*)nullptr, MD, MD, (size_t)0);
+      return check_launch("kern.compute_nu");
+    }
     const size_t lds = sizeof(float) * w.np;
     if (set_max_lds((const void*)k_solve_back<0>, lds)) return 1;
     hipLaunchKernelGGL(k_solve_back<0>, dim3(w.batch, 1), 256, lds, st, Lmat, w.n, w.np, bstride, Dfac, dstride, u, u_stride, u_bstride,

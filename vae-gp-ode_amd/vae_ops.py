@@ -295,7 +295,7 @@ class _Conv2d(torch.autograd.Function):
 # instead of launching the statistics pass + table kernel (two graph nodes and one read of the tensor per layer).
 _STATS_GEOMS = {(32, 64, 3, 1, 0, 4), (64, 32, 5, 2, 1, 6), (32, 16, 5, 2, 1, 13)}      # (Cin, Cout, K, stride, pad, Hi) of decnn.1/4/7
 _fused_stats = os.environ.get('GPODE_BN_STATS_PASS', '0') != '1'
-_FUSED_STATS_MIN_IMAGES = int(os.environ.get('GPODE_BN_STATS_FUSED_MIN', '1024'))
+_FUSED_STATS_MIN_IMAGES = int(os.environ.get('GPODE_BN_STATS_FUSED_MIN', '512'))
 _slots = {'next': 0}
 
 
@@ -308,8 +308,10 @@ def _stats_slot(bn):
 
 
 def _can_fuse_stats(bn, x, Cin, Cout, K, stride, pad, Hi):
-    # from 1024 images on: below that the statistics pass is a few microseconds and the per-workgroup hand-over at the end of the
-    # convolution costs as much (configs[0], 512 images: 0.754 vs 0.745 ms per step fused vs separate; configs[1], 4096: 2.751 vs 2.767)
+    # from 512 images on: below that the statistics pass is a few microseconds and the per-workgroup hand-over at the end of the
+    # convolution costs as much.  configs[0] (512 images): 0.722 vs 0.724 ms per step fused vs separate -- even, with five graph nodes
+    # less; configs[1] (4096): 2.62 vs 2.66.  (With four loads in flight in the last workgroup's combine, round 3's first version, the
+    # break-even was at 1024 images: bn_sink.hpp.)
     return (_fused_stats and bn is not None and bn.training and _bn_sync is None and (Cin, Cout, K, stride, pad, Hi) in _STATS_GEOMS
             and x.shape[0] >= _FUSED_STATS_MIN_IMAGES and x.data_ptr() % 16 == 0 and os.environ.get('GPODE_CONV_VALU', '0') != '1')
 
