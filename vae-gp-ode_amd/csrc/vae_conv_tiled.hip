@@ -545,7 +545,13 @@ int tiled_bwd_data(const float* gy, const float* w, const float* bias, float* gx
     return check_launch("enc_conv3_bwd_data_tiled");
   }
   if (matches<Enc6>(Ci, Co, H, Ho, K, S, P) && use_mfma() && (reinterpret_cast<uintptr_t>(gy) & 15) == 0)   // d/d input of the encoder's cnn.6
+  {
+    // 8 images per group fill the chip from 2048 images on; a minibatch of 256 made 32 workgroups (73 us on an eighth of the CUs):
+    // 2 images per group below half a wave of groups (GPODE_ENC6_IPB8=1: the former launch, A/B)
+    static const bool ipb8 = [] { const char* e = getenv("GPODE_ENC6_IPB8"); return e && e[0] == '1'; }();
+    if (!ipb8 && B < 4 * num_cus()) return launch_igemm<FwdPolicy<Enc6, 16>, 2, 4, 1>(gy, w, bias, gx, B, st, "enc_conv6_bwd_data_mfma", in_bn);
     return launch_igemm<FwdPolicy<Enc6, 16>, 8, 4, 1>(gy, w, bias, gx, B, st, "enc_conv6_bwd_data_mfma", in_bn);
+  }
   if (matches<Dec10>(Ci, Co, H, Ho, K, S, P)) {
     if (use_mfma()) {
       const size_t ldsm = sizeof(float) * dec10::KK * dec10::PST;
