@@ -258,6 +258,40 @@ __global__ void k_gUs(int M, int Do, int nd, const float* __restrict__ g_u, cons
   g_Us[e] = accum ? g_Us[e] + acc : acc;
 }
 
+// The solve route's form of k_gUs: g_u = q and g_p = -a are rows 1 and 2 of the vector table (element (m, d) of draw l: system b = d,
+// entry m for the RBF kernel; the single system, entry m Do + d for the divergence-free one), so the launch that spread them into
+// (M, Do) rows (k_vec_rv's second half) is folded in: this kernel writes gp_rows itself and reads g_u where it lies.
+__global__ void k_gUs_vec(int kernel, int M, int Do, int nd, int nb, int np, const float* __restrict__ vec_all,
+                          const float* __restrict__ eps_u, float* __restrict__ gp_rows, float* __restrict__ g_Us, float* __restrict__ g_Um,
+                          int accum) {
+  const size_t P = (size_t)M * (M + 1) / 2, MD = (size_t)M * Do;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  auto at = [&](int k, int l, int m, int d) {
+    const int b = kernel == 0 ? d : 0;
+    const size_t j = kernel == 0 ? (size_t)m : (size_t)m * Do + d;
+    return GP_VEC(vec_all, k, l)[j];
+  };
+  if (e < MD) {
+    const int m = (int)(e / Do), d = (int)(e % Do);
+    float acc = 0.f;
+    for (int l = 0; l < nd; ++l) {
+      acc += at(1, l, m, d);
+      gp_rows[l * MD + e] = -at(2, l, m, d);
+    }
+    g_Um[e] = accum ? g_Um[e] + acc : acc;
+  }
+  if (e >= P * Do) return;
+  const int d = (int)(e / P);
+  const size_t k = e % P;
+  int nn = (int)((sqrtf(8.f * (float)k + 1.f) - 1.f) * 0.5f);
+  while ((size_t)(nn + 1) * (nn + 2) / 2 <= k) ++nn;
+  while ((size_t)nn * (nn + 1) / 2 > k) --nn;
+  const int m = (int)(k - (size_t)nn * (nn + 1) / 2);
+  float acc = 0.f;
+  for (int l = 0; l < nd; ++l) acc = fmaf(at(1, l, nn, d), eps_u[l * MD + (size_t)m * Do + d], acc);
+  g_Us[e] = accum ? g_Us[e] + acc : acc;
+}
+
 // Phi[i][j] = sum_l (-r_l[i] q_l[j] + q_l[i] v_l[j]): the Cholesky backward is linear in Phi, so the draws that share the factor are
 // summed HERE, in front of the two triangular products (vectors laid out GP_VEC: [k][draw][system][np])
 __device__ __forceinline__ float phi_sum(const float* __restrict__ vec_all, int nd, int nb, int b, int np, size_t i, size_t j) {
@@ -712,12 +746,26 @@ __global__ __launch_bounds__(64 * TNW) void k_trsm_slab(int n, int np, int nbn, 
 
 // r = u - v, v = row n of the factor (the forward-solved rhs); g_u = q -> g_Um; g_p = -a -> gp_rows  (what k_vec_a does after
 // its product with the explicit inverse); one thread per element
+// gpack_ind != nullptr (first half only): g_nu as well -- k_gnu's element of the same index, one launch less on the solve route
 __global__ void k_vec_rv(int kernel, int Do, int n, int np, const float* __restrict__ Lall, size_t batch_stride,
                          const float* __restrict__ Dfac_all, size_t dfac_stride, const float* __restrict__ u,
                          float* __restrict__ vec_all, int with_a, float* __restrict__ gu_rows, float* __restrict__ gp_rows,
-                         size_t u_dstride) {
+                         size_t u_dstride, const float* __restrict__ gpack_ind, const float* __restrict__ var, int Di,
+                         size_t pack_dstride) {
   const int b = blockIdx.y, nb = gridDim.y, l = blockIdx.z, nd = gridDim.z, j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= np) return;
+  if (gpack_ind) {
+    float v = 0.f;
+    if (j < n) {
+      const int RQ2 = cdiv(Di + Do, 4);
+      int m, d;
+      if (kernel == 0) { m = j; d = b; } else { m = j / Do; d = j % Do; }
+      const int field = Di + d;
+      const float gc = (gpack_ind + (size_t)l * pack_dstride)[(((size_t)(m >> 6) * RQ2 + (field >> 2)) * 64 + (m & 63)) * 4 + (field & 3)];
+      v = kernel == 0 ? gc * var[d] : gc;
+    }
+    GP_VEC(vec_all, 0, l)[j] = v;
+  }
   const float* Lm = Lall + (size_t)b * batch_stride;
   const float* Dfac = Dfac_all + (size_t)b * dfac_stride;
   const int u_stride = kernel == 0 ? Do : 1, u_b = kernel == 0 ? b : 0;
@@ -1180,9 +1228,9 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, int nd, const floa
   float* vec = bws + b.vec;
   (void)MJ;
 
-  hipLaunchKernelGGL(k_gnu, dim3(cdiv(b.np, 128), b.batch, nd), 128, 0, st, kernel, Di, Do, M, b.n, b.np, gpack_ind, ws + w.var, vec, pf);
-  if (!(prepared & 1) && cache_bwd_prepare(kernel, Di, Do, M, S, nd, ws, bws, st)) return 1;
   const bool solves = use_trsm(b.np);
+  if (!solves) hipLaunchKernelGGL(k_gnu, dim3(cdiv(b.np, 128), b.batch, nd), 128, 0, st, kernel, Di, Do, M, b.n, b.np, gpack_ind, ws + w.var, vec, pf);
+  if (!(prepared & 1) && cache_bwd_prepare(kernel, Di, Do, M, S, nd, ws, bws, st)) return 1;
   const size_t trsm_lds = sizeof(float) * (size_t)(b.nbn + 2) * NB * TSL;
   const int nslab = (b.nbn * NB + TSW - 1) / TSW, vslab = cdiv(nd, TSW);     // slabs of Phi columns; slabs of per-draw vectors
   if (solves) {
@@ -1190,13 +1238,12 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, int nd, const floa
     if (set_max_lds((const void*)k_trsm_slab<0>, trsm_lds) || set_max_lds((const void*)k_trsm_slab<1>, trsm_lds) ||
         set_max_lds((const void*)k_trsm_slab<2>, trsm_lds)) return 1;
     hipLaunchKernelGGL(k_vec_rv, dim3(cdiv(b.np, 128), b.batch, nd), 128, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, ws + w.u, vec,
-                       0, bws + b.gu_rows, bws + b.gp_rows, MD);
+                       0, bws + b.gu_rows, bws + b.gp_rows, MD, gpack_ind, ws + w.var, Di, pf);
     hipLaunchKernelGGL(k_trsm_slab<0>, dim3(vslab, b.batch), 64 * TNW, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, Dfac, dstride, bws + b.Dinv, dinv_stride, vec,
                        (const float*)nullptr, (float*)nullptr, nd);
     hipLaunchKernelGGL(k_trsm_slab<1>, dim3(nslab + vslab, b.batch), 64 * TNW, trsm_lds, st, b.n, b.np, b.nbn, Lmat, bstride, Dfac, dstride, bws + b.Dinv, dinv_stride,
                        vec, (const float*)nullptr, bws + b.X, nd);
-    hipLaunchKernelGGL(k_vec_rv, dim3(cdiv(b.np, 128), b.batch, nd), 128, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, ws + w.u, vec,
-                       1, bws + b.gu_rows, bws + b.gp_rows, MD);
+    // (g_u, g_p into (M, Do) rows: k_gUs_vec below)
   } else {
     hipLaunchKernelGGL(k_vec_q, dim3(cdiv(b.np, 4), b.batch, nd), 256, 0, st, b.n, b.np, bws + b.Linv, bstride, vec);
     hipLaunchKernelGGL(k_vec_a, dim3(cdiv(b.np, 4), b.batch, nd), 256, 0, st, kernel, Do, b.n, b.np, Lmat, bstride, Dfac, dstride, bws + b.Linv,
@@ -1205,7 +1252,11 @@ int cache_build_bwd(int kernel, int Di, int Do, int M, int S, int nd, const floa
   if (check_launch("cache bwd: solves")) return 1;
   {
     const size_t P = (size_t)M * (M + 1) / 2 * Do;   // >= M * Do: the same launch sums g_Um
-    hipLaunchKernelGGL(k_gUs, (unsigned)((P + 255) / 256), 256, 0, st, M, Do, nd, bws + b.gu_rows, eps_u, g_Us, g_Um, (prepared >> 1) & 1);
+    if (solves)
+      hipLaunchKernelGGL(k_gUs_vec, (unsigned)((P + 255) / 256), 256, 0, st, kernel, M, Do, nd, b.batch, b.np, vec, eps_u, bws + b.gp_rows, g_Us, g_Um,
+                         (prepared >> 1) & 1);
+    else
+      hipLaunchKernelGGL(k_gUs, (unsigned)((P + 255) / 256), 256, 0, st, M, Do, nd, bws + b.gu_rows, eps_u, g_Us, g_Um, (prepared >> 1) & 1);
   }
   // f_prior(Z) path, every draw through its own pack: d/dZ and parameter gradients (prior only), added to the pack gradient
   Draws dv; dv.nd = nd; dv.pack = pf; dv.in = 0; dv.in2 = MD; dv.out = (size_t)M * Di;
