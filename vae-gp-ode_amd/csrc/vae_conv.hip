@@ -722,10 +722,25 @@ __global__ __launch_bounds__(1024) void k_elbo_all_fwd(const float* __restrict__
   __shared__ float red[16][3];
   const size_t P = (size_t)M * (M + 1) / 2;
   float u = 0.f, a = 0.f, b = 0.f;
+  // one workgroup walks 30 000 + 16 000 values: eight independent loads per thread in flight instead of one per dependent add
+  auto strided = [&](const float* __restrict__ p, size_t n, bool square) {
+    const size_t bd = blockDim.x;
+    float sacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    size_t e = threadIdx.x;
+    for (; e + 7 * bd < n; e += 8 * bd) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = p[e + k * bd];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sacc[k] = square ? fmaf(v[k], v[k], sacc[k]) : sacc[k] + v[k];
+    }
+    for (; e < n; e += bd) sacc[0] = square ? fmaf(p[e], p[e], sacc[0]) : sacc[0] + p[e];
+    return ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) + ((sacc[4] + sacc[5]) + (sacc[6] + sacc[7]));
+  };
   if (usq_part) {                                    // ||Us||_F^2 arrives as kElboParts partial sums
     for (int e = threadIdx.x; e < kElboParts; e += blockDim.x) u += usq_part[e];
   } else {
-    for (size_t e = threadIdx.x; e < P * Do; e += blockDim.x) u = fmaf(Us[e], Us[e], u);
+    u = strided(Us, P * Do, true);
   }
   for (int e = threadIdx.x; e < M * Do; e += blockDim.x) {
     const int m = e / Do, d = e % Do;
@@ -733,10 +748,10 @@ __global__ __launch_bounds__(1024) void k_elbo_all_fwd(const float* __restrict__
     const float v = Um[e];
     u += v * v - logf(l * l);
   }
-  for (int i = threadIdx.x; i < nl_values; i += blockDim.x) a += lpart[i];
+  a = strided(lpart, (size_t)nl_values, false);
   // hs == nullptr: the KL terms arrive summed per workgroup of k_reparam_kl_fwd (kls / klv)
-  for (int e = threadIdx.x; e < nks; e += blockDim.x) b += kls[e];
-  for (int e = threadIdx.x; e < nkv; e += blockDim.x) b += klv[e];
+  if (nks > 0) b += strided(kls, (size_t)nks, false);
+  if (nkv > 0) b += strided(klv, (size_t)nkv, false);
   for (int e = threadIdx.x; hs && e < N * q; e += blockDim.x) {
     const int n = e / q, d = e % q;
     {
