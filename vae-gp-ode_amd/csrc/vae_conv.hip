@@ -1051,10 +1051,14 @@ int gather_multi(const float* const* grads, const long long* offs, int ntensors,
 int adam_multi(float* const* params, const float* const* grads, float* const* m1, float* const* m2, const long long* offs,
                int ntensors, long long total, float lr, float beta1, float beta2, float eps, int step, int* step_dev, hipStream_t st) {
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  // with the device-side count every workgroup takes a ticket on ONE address (the last one publishes the count): keep them few --
-  // at most 128 workgroups of grid-stride loops
+  // with the device-side count every workgroup takes a ticket on ONE address (the last one publishes the count).  The cap used to be
+  // 128 workgroups "to keep the tickets few"; an iteration of the grid-stride loop is a chain of dependent loads (binary search of the
+  // offsets, the tensor's pointers, its data: ~1.5 us), and the divergence-free model's 0.6 M parameters made that 18 iterations per
+  // thread.  2048 workgroups: configs[1] 2.62 -> 2.59 ms on one box and no change on another, configs[2] / [3] -8 us, configs[0]
+  // unchanged (GPODE_ADAM_MAX_WG, A/B in profiles/r03d_ab_switches.txt)
   unsigned grid = ew_grid((size_t)total);
-  if (step_dev && grid > 128) grid = 128;
+  static const unsigned cap = [] { const char* e = getenv("GPODE_ADAM_MAX_WG"); return e ? (unsigned)atoi(e) : 2048u; }();
+  if (step_dev && grid > cap) grid = cap;
   hipLaunchKernelGGL(k_adam_multi, grid, 256, 0, st, params, grads, m1, m2, offs, ntensors, total, lr, beta1, beta2, eps, bc1, bc2,
                      step_dev);
   return check_launch("adam_multi");
