@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256) void k_linear_fwd_fanout(const float* __restri
                                                             const float* __restrict__ bias, float* __restrict__ y, int B, int In, int Out,
                                                             int rows_per_block) {
   const int b0 = blockIdx.x * rows_per_block, b1 = min(B, b0 + rows_per_block);
-  for (int o = threadIdx.x; o < Out; o += 256) {
+  // (grid.y splits Out: one pass per thread -- a second pass waited out a second round of weight loads)
+  for (int o = blockIdx.y * 256 + threadIdx.x; o < Out; o += 256 * gridDim.y) {
     float wr[LIN_MAXIN];
 #pragma unroll
     for (int i = 0; i < LIN_MAXIN; ++i) wr[i] = i < In ? w[(size_t)o * In + i] : 0.f;
@@ -461,7 +462,7 @@ int act_bwd(const float* y, const float* gy, float* gx, size_t n, int mode, hipS
 int linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int In, int Out, hipStream_t st) {
   if (In <= LIN_MAXIN && Out % 64 == 0 && B >= 256) {
     const int rows = 8;
-    hipLaunchKernelGGL(k_linear_fwd_fanout, (B + rows - 1) / rows, 256, 0, st, x, w, bias, y, B, In, Out, rows);
+    hipLaunchKernelGGL(k_linear_fwd_fanout, dim3((B + rows - 1) / rows, (Out + 255) / 256), 256, 0, st, x, w, bias, y, B, In, Out, rows);
     return check_launch("linear_fwd_fanout");
   }
   if (In >= 128 && (size_t)B * Out <= (size_t)1 << 22) {
